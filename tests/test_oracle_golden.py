@@ -1,0 +1,128 @@
+"""Pins the oracle (oracle/reference_path.py) to the golden vectors recorded from the
+real reference.  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import reference_path as O
+from tests import golden_util as G
+
+TOL = dict(rtol=1e-5, atol=1e-6)
+
+
+def _obatch(bd):
+    return O.OBatch(bd["node_features"], bd["edge_index"], bd["edge_weight"], bd["batch"],
+                    bd.get("labels"), bd["ptr"])
+
+
+def test_g1_collate_bit_exact():
+    d = G.load("g1_collate_8x20.npz")
+    bd = G.group(d, "batch")
+    gs = G.split_graphs(bd, d["edge_counts"])
+    b = O.collate([g[0] for g in gs], [g[1] for g in gs], [g[2] for g in gs], [g[3] for g in gs])
+    assert torch.equal(b.edge_index, bd["edge_index"]) and b.edge_index.dtype == torch.int64
+    assert torch.equal(b.batch, bd["batch"]) and torch.equal(b.ptr, bd["ptr"])
+    assert torch.equal(b.labels, bd["labels"])
+    assert torch.equal(b.node_features, bd["node_features"])
+    assert torch.equal(b.edge_weight, bd["edge_weight"])
+
+
+@pytest.mark.parametrize("name,fn", [("gcn", O.gcn_layer), ("sage", O.sage_layer)])
+@pytest.mark.parametrize("tag", ["sum", "cot"])
+def test_g2_layers(name, fn, tag):
+    d = G.load("g2_layers_6node.npz")
+    x = torch.from_numpy(d["x"]).requires_grad_(True)
+    ei, ew = torch.from_numpy(d["edge_index"]), torch.from_numpy(d["edge_weight"])
+    p = G.group(d, f"{name}_param")
+    w = p["linear.weight"].clone().requires_grad_(True)
+    b = (p["bias"] if name == "gcn" else p["linear.bias"]).clone().requires_grad_(True)
+    out = fn(x, ei, ew, w, b)
+    c = torch.ones_like(out) if tag == "sum" else torch.from_numpy(d["cotangent"])
+    (out * c).sum().backward()
+    g = G.group(d, f"{name}_{tag}")
+    torch.testing.assert_close(out, g["out"], **TOL)
+    torch.testing.assert_close(x.grad, g["dx"], **TOL)
+    torch.testing.assert_close(w.grad, g["d_linear.weight"], **TOL)
+    torch.testing.assert_close(b.grad, g["d_bias" if name == "gcn" else "d_linear.bias"], **TOL)
+    # independent dense fp64 formulation agrees with the golden output too
+    dense = (O.gcn_layer_dense64 if name == "gcn" else O.sage_layer_dense64)(
+        x.detach(), ei, ew, w.detach(), b.detach())
+    torch.testing.assert_close(dense.float(), g["out"], **TOL)
+
+
+MODEL_FILES = [
+    ("g3_models_8x20_h32.npz", 32, 32),
+    ("g4_models_4x84_h64.npz", 64, 64),
+    ("g5_models_2x360.npz", 64, 128),
+    ("g6_mixed_20_35_84.npz", 32, 32),
+]
+
+
+@pytest.mark.parametrize("fname,h_gcn,h_sage", MODEL_FILES)
+@pytest.mark.parametrize("kind", ["gcn", "sage"])
+def test_models_init_eval_train(fname, h_gcn, h_sage, kind):
+    d = G.load(fname)
+    b = _obatch(G.group(d, "batch"))
+    hidden = h_gcn if kind == "gcn" else h_sage
+    # a7/a9: same RNG consumption order as the reference constructors
+    torch.manual_seed(42)
+    st = O.INIT[kind](b.node_features.shape[1], hidden)
+    init = G.group(d, f"{kind}_init")
+    assert list(st.keys()) != [] and set(st.keys()) == set(init.keys())
+    for k in init:
+        assert torch.equal(st[k], init[k]), k
+    # eval forward
+    with torch.no_grad():
+        torch.testing.assert_close(O.FORWARD[kind](st, b, 0.3, False),
+                                   G.group(d, f"{kind}_eval")["logits"], **TOL)
+        torch.testing.assert_close(O.ENCODE[kind](st, b, 0.3, False),
+                                   G.group(d, f"{kind}_eval")["encode"], **TOL)
+    # train forward/backward, dropout 0
+    st = O.require_grad({k: v.clone() for k, v in init.items()})
+    logits = O.FORWARD[kind](st, b, 0.0, True)
+    loss = torch.nn.functional.cross_entropy(logits, b.labels)
+    loss.backward()
+    tr = G.group(d, f"{kind}_train")
+    torch.testing.assert_close(logits, tr["logits"], **TOL)
+    torch.testing.assert_close(loss, tr["loss"], **TOL)
+    for k, g in G.group(d, f"{kind}_grad").items():
+        torch.testing.assert_close(st[k].grad, g, rtol=1e-4, atol=1e-6, msg=lambda m: f"{k}: {m}")
+    for k, v in G.group(d, f"{kind}_after").items():
+        torch.testing.assert_close(st[k], v, **TOL)
+
+
+@pytest.mark.parametrize("kind", ["gcn", "sage"])
+def test_g7_trainer_trajectory(kind):
+    d = G.load("g7_trainer_40x20.npz")
+    gs = G.split_graphs(G.group(d, "all"), d["edge_counts"])
+
+    def batches(sub):
+        return [O.collate([g[0] for g in sub[i:i + 10]], [g[1] for g in sub[i:i + 10]],
+                          [g[2] for g in sub[i:i + 10]], [g[3] for g in sub[i:i + 10]])
+                for i in range(0, len(sub), 10)]
+
+    torch.manual_seed(42)
+    st = O.require_grad(O.INIT[kind](5, 32))
+    opt = torch.optim.Adam([st[k] for k in O.param_keys(st)], lr=1e-3)
+    hist = O.fit(kind, st, batches(gs[:30]), batches(gs[30:]), opt, num_epochs=3, patience=8,
+                 dropout=0.0)
+    gh = G.group(d, f"{kind}_hist")
+    # train-mode BN cancels the conv bias exactly -> train_loss is tight; eval-mode BN sees the
+    # (chaotic, see below) GCN bias through running_mean's lag -> val_loss gets 1e-3.
+    np.testing.assert_allclose(np.asarray(hist["train_loss"]), gh["train_loss"].numpy(),
+                               rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(np.asarray(hist["val_loss"]), gh["val_loss"].numpy(),
+                               rtol=1e-3 if kind == "gcn" else 1e-4, atol=1e-5)
+    np.testing.assert_allclose(np.asarray(hist["val_acc"]), gh["val_acc"].numpy(), atol=0.1001)
+    for k, v in G.group(d, f"{kind}_final").items():
+        if kind == "gcn" and k.startswith("convs.") and k.endswith(".bias"):
+            # A bias in front of BatchNorm has an exactly-zero true gradient; what Adam sees is
+            # rounding noise, which it normalises to +-lr steps.  Its trajectory is chaotic in
+            # the reference itself (thread count changes it), so only its magnitude is pinned,
+            # and running_mean (which absorbs it) gets the matching 3-epoch * 3-step * lr slack.
+            assert float(st[k].detach().abs().max()) <= 9 * 1e-3 + 1e-6
+            continue
+        slack = 1e-2 if (kind == "gcn" and "running_mean" in k) else 1e-5
+        torch.testing.assert_close(st[k].detach(), v, rtol=1e-4, atol=slack, msg=lambda m: f"{k}: {m}")
+    ev = O.evaluate(kind, st, batches(gs[30:]))
+    assert ev["correct"] == int(d[f"{kind}_eval__correct"]) and ev["total"] == 10
