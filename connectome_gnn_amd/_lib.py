@@ -1,0 +1,89 @@
+"""ctypes binding of libcgnn_hip.so (the C ABI declared in include/cgnn.h).
+
+This is the binding a maintainer of the reference would add: the reference
+reaches its hot path only through ATen calls in connectome_gnn/models.py:40-152, so the
+"FFI" is a ctypes stub that hands raw device pointers, sizes and the current HIP stream to
+the library.  There is NO fallback: if the library is missing or fails to load, importing the
+compute path raises (a CPU/eager substitute would void every parity claim).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_int, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcgnn_hip.so")
+ABI_VERSION = 1
+
+CGNN_OK, CGNN_EINVAL, CGNN_ELAUNCH, CGNN_EUNSUPPORTED = 0, -1, -2, -3
+_ERR = {CGNN_EINVAL: "CGNN_EINVAL (bad argument)", CGNN_ELAUNCH: "CGNN_ELAUNCH (kernel launch failed)",
+        CGNN_EUNSUPPORTED: "CGNN_EUNSUPPORTED (shape not covered by this build)"}
+
+P, I32, I64 = c_void_p, c_int32, c_int64
+
+# name -> (restype, argtypes).  Order and meaning follow include/cgnn.h exactly.
+PROTOTYPES = {
+    "cgnn_abi_version": (c_int, []),
+    "cgnn_build_target": (c_char_p, []),
+    "cgnn_csr_workspace_bytes": (I64, [I64, I64]),
+    "cgnn_csr_build": (c_int, [P, P, I64, I64, P, P, P, P, P, P, P, P, P]),
+    "cgnn_gcn_norm": (c_int, [P, P, I64, I64, P, P, P, P, P, P, P, P, P]),
+    "cgnn_sage_norm": (c_int, [P, P, I64, I64, P, P, P, P, P, P, P, P]),
+    "cgnn_aggregate_f32": (c_int, [P, P, P, P, P, P, P, I64, P, I64, I64, I32, P]),
+    "cgnn_linear_fwd_f32": (c_int, [P, I64, I32, P, I64, I32, P, P, I32, P, I64, I64, I32, P]),
+    "cgnn_linear_bwd_input_f32": (c_int, [P, I64, P, I32, I32, P, I64, I64, I32, I32, P]),
+    "cgnn_linear_bwd_weight_workspace_bytes": (I64, [I64, I32, I32]),
+    "cgnn_linear_bwd_weight_f32": (c_int, [P, I64, P, I64, P, I32, I32, I64, I32, I32, P, P]),
+    "cgnn_colsum_workspace_bytes": (I64, [I64, I32]),
+    "cgnn_colsum_f32": (c_int, [P, I64, P, I64, I32, P, P]),
+    "cgnn_pool_mean_fwd_f32": (c_int, [P, I64, P, P, I32, I32, P]),
+    "cgnn_pool_mean_bwd_f32": (c_int, [P, P, P, I64, I32, I32, P]),
+}
+
+
+class CgnnError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load libcgnn_hip.so once; raise loudly if it is absent or has the wrong ABI."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CgnnError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C connectome_gnn_amd/csrc`.  connectome_gnn_amd has no "
+            "CPU/eager fallback for the message-passing path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # pragma: no cover
+            raise CgnnError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype, fn.argtypes = res, args
+    v = lib.cgnn_abi_version()
+    if v != ABI_VERSION:
+        raise CgnnError(f"libcgnn_hip.so ABI {v} != binding ABI {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != CGNN_OK:
+        raise CgnnError(f"{what} failed: {_ERR.get(rc, rc)}")
+
+
+def ptr(t) -> int:
+    """Device pointer of a tensor (None -> NULL)."""
+    return 0 if t is None else t.data_ptr()
+
+
+def stream_ptr() -> int:
+    """The HIP stream torch is currently enqueuing on (kernels join torch's ordering)."""
+    import torch
+    return torch.cuda.current_stream().cuda_stream

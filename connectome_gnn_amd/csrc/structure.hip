@@ -1,0 +1,308 @@
+// structure.hip -- batch structure kernels: dst-/src-sorted CSR of the block-diagonal COO,
+// GCN and GraphSAGE normalisation coefficients.  Integer work is bit-exact by construction:
+// slots inside a row are in COO order (stable bucket sort = count, scan, fill, per-row sort).
+//
+// Reference arithmetic replaced: models.py:94-108 (GCN norm), :146-149 (SAGE w_sum), and the
+// index plumbing of scatter_add_/index (models.py:50-54,112-113).
+#include "common.h"
+
+namespace {
+
+constexpr int kScanItems = 8;             // items per thread
+constexpr int kScanBlock = 256;
+constexpr int kScanTile = kScanItems * kScanBlock;
+
+__global__ void k_zero_i32(int32_t* p, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0;
+}
+
+// counts: cnt_dst[dst]++, cnt_src[src]++ ; flags[0] out-of-range, flags[1] cross-graph
+__global__ void k_count(const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
+                        const int64_t* __restrict__ node_graph, int64_t nn, int64_t ne,
+                        int32_t* cnt_dst, int32_t* cnt_src, int32_t* flags) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ne) return;
+  int64_t s = src[e], d = dst[e];
+  if (s < 0 || s >= nn || d < 0 || d >= nn) {
+    atomicAdd(&flags[0], 1);
+    return;
+  }
+  if (node_graph && node_graph[s] != node_graph[d]) atomicAdd(&flags[1], 1);
+  atomicAdd(&cnt_dst[d], 1);
+  atomicAdd(&cnt_src[s], 1);
+}
+
+// block-level exclusive scan helpers ------------------------------------------------------
+__device__ __forceinline__ int block_excl_scan(int v, int* total, int* lds /*>= 4+1 ints*/) {
+  // 256 threads = 4 waves
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  int x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int y = __shfl_up(x, o, 64);
+    if (lane >= o) x += y;
+  }
+  if (lane == 63) lds[wid] = x;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wid; ++w) base += lds[w];
+  int tot = lds[0] + lds[1] + lds[2] + lds[3];
+  __syncthreads();
+  *total = tot;
+  return base + x - v;
+}
+
+__global__ void __launch_bounds__(kScanBlock) k_scan_tile_sums(const int32_t* in, int64_t n,
+                                                                int32_t* tile_sums) {
+  __shared__ int lds[8];
+  int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < kScanItems; ++i)
+    if (base + i < n) s += in[base + i];
+  int tot;
+  block_excl_scan(s, &tot, lds);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(kScanBlock) k_scan_top(int32_t* tile_sums, int nt) {
+  __shared__ int lds[8];
+  int carry = 0;
+  for (int b = 0; b < nt; b += kScanBlock) {
+    int i = b + threadIdx.x;
+    int v = i < nt ? tile_sums[i] : 0;
+    int tot;
+    int ex = block_excl_scan(v, &tot, lds);
+    if (i < nt) tile_sums[i] = carry + ex;
+    carry += tot;
+  }
+}
+
+__global__ void __launch_bounds__(kScanBlock) k_scan_apply(const int32_t* in, int64_t n,
+                                                            const int32_t* tile_offs,
+                                                            int32_t* out) {
+  __shared__ int lds[8];
+  int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  int v[kScanItems];
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < kScanItems; ++i) {
+    v[i] = base + i < n ? in[base + i] : 0;
+    s += v[i];
+  }
+  int tot;
+  int ex = block_excl_scan(s, &tot, lds) + tile_offs[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < kScanItems; ++i) {
+    if (base + i < n) out[base + i] = ex;
+    ex += v[i];
+  }
+}
+
+__global__ void k_fill(const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
+                       int64_t nn, int64_t ne, const int32_t* __restrict__ rowptr_dst,
+                       const int32_t* __restrict__ rowptr_src, int32_t* cur_dst,
+                       int32_t* cur_src, int32_t* eid_dst, int32_t* eid_src) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ne) return;
+  int64_t s = src[e], d = dst[e];
+  if (s < 0 || s >= nn || d < 0 || d >= nn) return;
+  eid_dst[rowptr_dst[d] + atomicAdd(&cur_dst[d], 1)] = (int32_t)e;
+  eid_src[rowptr_src[s] + atomicAdd(&cur_src[s], 1)] = (int32_t)e;
+}
+
+// One thread per row: restore COO order inside the row (the atomic fill order is arbitrary),
+// then emit the neighbour id of every slot.  Rows are short (in-degree ~k of the
+// Watts-Strogatz graphs), so an insertion sort in place is the cheapest stable choice.
+__global__ void k_sort_rows(const int32_t* __restrict__ rowptr, int32_t* eid,
+                            const int64_t* __restrict__ other_end, int32_t* col, int64_t nn,
+                            int32_t* max_deg) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int deg = 0;
+  if (r < nn) {
+    int b = rowptr[r], e = rowptr[r + 1];
+    deg = e - b;
+    for (int i = b + 1; i < e; ++i) {
+      int key = eid[i];
+      int j = i - 1;
+      while (j >= b && eid[j] > key) {
+        eid[j + 1] = eid[j];
+        --j;
+      }
+      eid[j + 1] = key;
+    }
+    for (int i = b; i < e; ++i) col[i] = (int32_t)other_end[eid[i]];
+  }
+  // wave max -> one atomic per wave
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) deg = max(deg, __shfl_xor(deg, o, 64));
+  if ((threadIdx.x & 63) == 0 && deg > 0) atomicMax(max_deg, deg);
+}
+
+// GCN: deg (source side) + self loop, dis, selfc -- one thread per node, COO order sum.
+__global__ void k_gcn_deg(const float* __restrict__ w, const int32_t* __restrict__ rowptr_src,
+                          const int32_t* __restrict__ eid_src, int64_t nn, float* dis,
+                          float* selfc) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nn) return;
+  float deg = 0.f;
+  for (int s = rowptr_src[i]; s < rowptr_src[i + 1]; ++s) deg += w[eid_src[s]];
+  deg += 1.0f;                                  // self-loop appended last (models.py:97-100)
+  float d = 1.0f / sqrtf(deg + 1e-8f);          // pow(-0.5) == rsqrt on the CPU path
+  dis[i] = d;
+  selfc[i] = d * 1.0f * d;
+}
+
+__global__ void k_gcn_coef(const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
+                           const float* __restrict__ w, const float* __restrict__ dis,
+                           const int32_t* __restrict__ eid_dst,
+                           const int32_t* __restrict__ eid_src, int64_t nslots,
+                           float* coef_dst, float* coef_src) {
+  int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nslots) return;
+  int e = eid_dst[s];
+  coef_dst[s] = dis[src[e]] * w[e] * dis[dst[e]];   // models.py:108, left to right
+  e = eid_src[s];
+  coef_src[s] = dis[src[e]] * w[e] * dis[dst[e]];
+}
+
+__global__ void k_sage_den(const float* __restrict__ w, const int32_t* __restrict__ rowptr_dst,
+                           const int32_t* __restrict__ eid_dst, int64_t nn, float* den,
+                           float* w_dst) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nn) return;
+  float sum = 0.f;
+  for (int s = rowptr_dst[i]; s < rowptr_dst[i + 1]; ++s) {
+    float v = w[eid_dst[s]];
+    w_dst[s] = v;
+    sum += v;
+  }
+  den[i] = sum + 1e-8f;                          // models.py:149
+}
+
+__global__ void k_sage_coef_bwd(const int64_t* __restrict__ dst, const float* __restrict__ w,
+                                const float* __restrict__ den,
+                                const int32_t* __restrict__ eid_src, int64_t nslots,
+                                float* coef_src_bwd) {
+  int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nslots) return;
+  int e = eid_src[s];
+  coef_src_bwd[s] = w[e] / den[dst[e]];
+}
+
+inline unsigned blocks_for(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+
+// in-place exclusive scan of counts[0..n) (n = Nn+1, counts[Nn] = 0) using tile_sums scratch
+int scan_i32(int32_t* counts, int64_t n, int32_t* tile_sums, hipStream_t st) {
+  int nt = (int)((n + kScanTile - 1) / kScanTile);
+  k_scan_tile_sums<<<nt, kScanBlock, 0, st>>>(counts, n, tile_sums);
+  k_scan_top<<<1, kScanBlock, 0, st>>>(tile_sums, nt);
+  k_scan_apply<<<nt, kScanBlock, 0, st>>>(counts, n, tile_sums, counts);
+  return hipGetLastError() == hipSuccess ? CGNN_OK : CGNN_ELAUNCH;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cgnn_abi_version(void) { return CGNN_ABI_VERSION; }
+const char* cgnn_build_target(void) { return "gfx950"; }
+
+int64_t cgnn_csr_workspace_bytes(int64_t nn, int64_t ne) {
+  if (nn < 0 || ne < 0) return CGNN_EINVAL;
+  int64_t nt = (nn + 1 + kScanTile - 1) / kScanTile;
+  // two cursor arrays [nn] + two tile-sum arrays [nt]
+  return cgnn_align_up((2 * nn + 2 * nt + 8) * (int64_t)sizeof(int32_t), 256);
+}
+
+int cgnn_csr_build(const int64_t* edge_index, const int64_t* node_graph, int64_t nn, int64_t ne,
+                   int32_t* rowptr_dst, int32_t* eid_dst, int32_t* col_dst,
+                   int32_t* rowptr_src, int32_t* eid_src, int32_t* col_src, int32_t* flags,
+                   void* workspace, void* stream) {
+  if (nn < 0 || ne < 0 || nn >= INT32_MAX || ne >= INT32_MAX) return CGNN_EINVAL;
+  if (!rowptr_dst || !rowptr_src || !flags || !workspace) return CGNN_EINVAL;
+  if (ne > 0 && (!edge_index || !eid_dst || !col_dst || !eid_src || !col_src)) return CGNN_EINVAL;
+  hipStream_t st = cgnn_stream(stream);
+  const int64_t* src = edge_index;
+  const int64_t* dst = edge_index + ne;
+  int32_t* cur_dst = static_cast<int32_t*>(workspace);
+  int32_t* cur_src = cur_dst + nn;
+  int32_t* tiles_a = cur_src + nn;
+  int64_t nt = (nn + 1 + kScanTile - 1) / kScanTile;
+  int32_t* tiles_b = tiles_a + nt;
+
+  k_zero_i32<<<blocks_for(nn + 1, 256), 256, 0, st>>>(rowptr_dst, nn + 1);
+  k_zero_i32<<<blocks_for(nn + 1, 256), 256, 0, st>>>(rowptr_src, nn + 1);
+  k_zero_i32<<<blocks_for(2 * nn, 256), 256, 0, st>>>(cur_dst, 2 * nn);
+  k_zero_i32<<<1, 64, 0, st>>>(flags, 4);
+  CGNN_CHECK_LAUNCH();
+  if (ne > 0) {
+    k_count<<<blocks_for(ne, 256), 256, 0, st>>>(src, dst, node_graph, nn, ne, rowptr_dst,
+                                                 rowptr_src, flags);
+    CGNN_CHECK_LAUNCH();
+  }
+  int rc = scan_i32(rowptr_dst, nn + 1, tiles_a, st);
+  if (rc) return rc;
+  rc = scan_i32(rowptr_src, nn + 1, tiles_b, st);
+  if (rc) return rc;
+  if (ne > 0) {
+    k_fill<<<blocks_for(ne, 256), 256, 0, st>>>(src, dst, nn, ne, rowptr_dst, rowptr_src, cur_dst,
+                                                cur_src, eid_dst, eid_src);
+    CGNN_CHECK_LAUNCH();
+    if (nn > 0) {
+      k_sort_rows<<<blocks_for(nn, 256), 256, 0, st>>>(rowptr_dst, eid_dst, src, col_dst, nn,
+                                                       flags + 2);
+      k_sort_rows<<<blocks_for(nn, 256), 256, 0, st>>>(rowptr_src, eid_src, dst, col_src, nn,
+                                                       flags + 3);
+      CGNN_CHECK_LAUNCH();
+    }
+  }
+  return CGNN_OK;
+}
+
+int cgnn_gcn_norm(const int64_t* edge_index, const float* w, int64_t nn, int64_t ne,
+                  const int32_t* rowptr_dst, const int32_t* eid_dst, const int32_t* rowptr_src,
+                  const int32_t* eid_src, float* dis, float* selfc, float* coef_dst,
+                  float* coef_src, void* stream) {
+  if (nn < 0 || ne < 0) return CGNN_EINVAL;
+  if (nn > 0 && (!rowptr_src || !dis || !selfc)) return CGNN_EINVAL;
+  if (ne > 0 && (!edge_index || !w || !eid_dst || !eid_src || !coef_dst || !coef_src))
+    return CGNN_EINVAL;
+  (void)rowptr_dst;
+  hipStream_t st = cgnn_stream(stream);
+  if (nn > 0) {
+    k_gcn_deg<<<blocks_for(nn, 256), 256, 0, st>>>(w, rowptr_src, eid_src, nn, dis, selfc);
+    CGNN_CHECK_LAUNCH();
+  }
+  if (ne > 0) {
+    k_gcn_coef<<<blocks_for(ne, 256), 256, 0, st>>>(edge_index, edge_index + ne, w, dis, eid_dst,
+                                                    eid_src, ne, coef_dst, coef_src);
+    CGNN_CHECK_LAUNCH();
+  }
+  return CGNN_OK;
+}
+
+int cgnn_sage_norm(const int64_t* edge_index, const float* w, int64_t nn, int64_t ne,
+                   const int32_t* rowptr_dst, const int32_t* eid_dst, const int32_t* rowptr_src,
+                   const int32_t* eid_src, float* den, float* w_dst, float* coef_src_bwd,
+                   void* stream) {
+  if (nn < 0 || ne < 0) return CGNN_EINVAL;
+  if (nn > 0 && (!rowptr_dst || !den)) return CGNN_EINVAL;
+  if (ne > 0 && (!edge_index || !w || !eid_dst || !eid_src || !w_dst || !coef_src_bwd))
+    return CGNN_EINVAL;
+  (void)rowptr_src;
+  hipStream_t st = cgnn_stream(stream);
+  if (nn > 0) {
+    k_sage_den<<<blocks_for(nn, 256), 256, 0, st>>>(w, rowptr_dst, eid_dst, nn, den, w_dst);
+    CGNN_CHECK_LAUNCH();
+  }
+  if (ne > 0) {
+    k_sage_coef_bwd<<<blocks_for(ne, 256), 256, 0, st>>>(edge_index + ne, w, den, eid_src, ne,
+                                                         coef_src_bwd);
+    CGNN_CHECK_LAUNCH();
+  }
+  return CGNN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,156 @@
+"""GCN / GraphSAGE connectome classifiers on the MI355X message-passing kernels.
+
+Drop-in for the reference's model API (connectome_gnn/models.py:159-266): same class names,
+constructor signatures, attributes (``convs``, ``batch_norms``, ``classifier``, ``dropout``),
+``encode``/``forward``, identical ``state_dict`` keys/shapes and -- because parameters are
+created in the same order with the same initialisers -- identical initial weights under
+``torch.manual_seed``.
+
+What differs is how a layer is evaluated.  The reference issues ~13 ATen ops per GCN layer on
+an int64 COO and materialises [E+N, F] message tensors (models.py:90-114).  Here a batch is
+bucket-sorted once into CSR (structure.py) and a layer is
+    projection   : fp32 MFMA GEMM                     (cgnn_linear_*)
+    aggregation  : atomics-free segment reduction      (cgnn_aggregate_f32)
+    readout      : contiguous segment mean             (cgnn_pool_mean_*)
+all hand-written HIP for gfx950, reached through the C ABI in include/cgnn.h.  BatchNorm,
+ReLU, dropout, the 2-layer classifier head and the loss stay PyTorch-ROCm host code in this
+execution path (``impl="layered"``); the fused per-graph path replaces them as well.
+
+There is no CPU path: CPU tensors raise (the oracle under oracle/ is test infrastructure).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .graph import ConnectomeBatch
+from .structure import BatchStructure, GcnNorm, SageNorm, _require_device
+
+
+class _AdHocBatch:
+    """Lets a layer be called with raw (x, edge_index, edge_weight) like the reference's
+    GCNLayer/SAGELayer (models.py:84-89,136-141): one graph, no batch vector."""
+
+    def __init__(self, x, edge_index, edge_weight):
+        n = x.shape[0]
+        self.edge_index, self.edge_weight = edge_index, edge_weight
+        self.batch = None
+        self.ptr = torch.tensor([0, n], dtype=torch.long, device=x.device)
+        self.num_nodes, self.num_graphs = n, 1
+
+
+class GCNLayer(nn.Module):
+    """Y = (D^-1/2 (A + I) D^-1/2)^T X W^T + b with source-side weighted degree
+    (reference models.py:66-114).  Parameters: ``linear.weight [out,in]``, ``bias [out]``."""
+
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        self.linear = nn.Linear(in_channels, out_channels, bias=False)
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        nn.init.xavier_uniform_(self.linear.weight)
+
+    def forward(self, x, edge_index, edge_weight, *, structure: Optional[BatchStructure] = None,
+                norm: Optional[GcnNorm] = None):
+        _require_device(x, "x")
+        if structure is None:
+            structure = BatchStructure.build(_AdHocBatch(x, edge_index, edge_weight))
+        if norm is None:
+            norm = structure.gcn_norm()
+        s = structure
+        fwd = (s.rowptr_dst, s.col_dst, norm.coef_dst, norm.selfc, None)
+        bwd = (s.rowptr_src, s.col_src, norm.coef_src)
+        w = self.linear.weight
+        if w.shape[1] < w.shape[0]:
+            # A_hat (X W^T) == (A_hat X) W^T: aggregate at the narrower width first
+            return ops.linear(ops.aggregate(x, None, fwd, bwd), None, w, self.bias)
+        return ops.aggregate(ops.linear(x, None, w, None), self.bias, fwd, bwd)
+
+
+class SAGELayer(nn.Module):
+    """relu(Linear([x || weighted-mean of in-neighbours])) (reference models.py:121-152)."""
+
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        self.linear = nn.Linear(in_channels * 2, out_channels)
+        nn.init.xavier_uniform_(self.linear.weight)
+
+    def forward(self, x, edge_index, edge_weight, *, structure: Optional[BatchStructure] = None,
+                norm: Optional[SageNorm] = None):
+        _require_device(x, "x")
+        if structure is None:
+            structure = BatchStructure.build(_AdHocBatch(x, edge_index, edge_weight))
+        if norm is None:
+            norm = structure.sage_norm()
+        s = structure
+        agg = ops.aggregate(x, None, (s.rowptr_dst, s.col_dst, norm.w_dst, None, norm.den),
+                            (s.rowptr_src, s.col_src, norm.coef_src_bwd))
+        # the [x || agg] concat is never materialised: two K-panels of one GEMM, ReLU epilogue
+        return ops.linear(x, agg, self.linear.weight, self.linear.bias, relu=True)
+
+
+def _head(hidden_dim: int, num_classes: int, dropout: float) -> nn.Sequential:
+    return nn.Sequential(nn.Linear(hidden_dim, hidden_dim // 2), nn.ReLU(), nn.Dropout(dropout),
+                         nn.Linear(hidden_dim // 2, num_classes))
+
+
+class _ConnectomeModel(nn.Module):
+    _layer_cls = None
+
+    def __init__(self, in_channels: int, hidden_dim: int = 64, num_classes: int = 2,
+                 num_layers: int = 3, dropout: float = 0.3):
+        super().__init__()
+        self.dropout = dropout
+        widths = [in_channels] + [hidden_dim] * num_layers
+        self.convs = nn.ModuleList(self._layer_cls(a, b) for a, b in zip(widths, widths[1:]))
+        self.batch_norms = nn.ModuleList(nn.BatchNorm1d(hidden_dim) for _ in range(num_layers))
+        self.classifier = _head(hidden_dim, num_classes, dropout)
+
+    def _norm(self, structure: BatchStructure):
+        raise NotImplementedError
+
+    def _post(self, x):
+        raise NotImplementedError
+
+    def encode(self, batch: ConnectomeBatch) -> torch.Tensor:
+        """Graph embeddings [B, hidden] (reference models.py:203-211 / 256-262)."""
+        _require_device(batch.node_features, "batch.node_features")
+        s = batch.structure()
+        norm = self._norm(s)                  # once per forward pass, shared by all layers
+        x = batch.node_features
+        for conv, bn in zip(self.convs, self.batch_norms):
+            x = conv(x, batch.edge_index, batch.edge_weight, structure=s, norm=norm)
+            x = self._post(bn(x))
+            x = F.dropout(x, p=self.dropout, training=self.training)
+        return ops.pool_mean(x, s.gptr, batch.num_graphs)
+
+    def forward(self, batch: ConnectomeBatch) -> torch.Tensor:
+        """Class logits [B, num_classes]."""
+        return self.classifier(self.encode(batch))
+
+
+class GCNConnectome(_ConnectomeModel):
+    """conv -> BatchNorm1d -> ReLU -> dropout per layer, mean-pool, MLP head
+    (reference models.py:159-216)."""
+    _layer_cls = GCNLayer
+
+    def _norm(self, structure):
+        return structure.gcn_norm()
+
+    def _post(self, x):
+        return F.relu(x)
+
+
+class GraphSAGEConnectome(_ConnectomeModel):
+    """conv (ReLU inside) -> BatchNorm1d -> dropout per layer -- no ReLU after BN
+    (reference models.py:219-266)."""
+    _layer_cls = SAGELayer
+
+    def _norm(self, structure):
+        return structure.sage_norm()
+
+    def _post(self, x):
+        return x

@@ -1,0 +1,194 @@
+"""torch.autograd bridges over the C ABI (include/cgnn.h).
+
+Each Function is a thin shim: it allocates outputs/scratch with torch's caching allocator,
+passes raw device pointers + the current HIP stream to libcgnn_hip.so, and wires the
+matching backward kernels.  No arithmetic of the message-passing path happens in torch here.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from .structure import _require_device
+
+
+def _prep(t: Optional[torch.Tensor], what: str) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    _require_device(t, what)
+    if t.dtype != torch.float32:
+        # the reference is fp32-only on this path (SURVEY: .half()/.double() raise)
+        raise TypeError(f"{what} must be float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _scratch(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+# ------------------------------------------------------------------------------ raw launchers
+def aggregate_raw(rowptr, col, coef, selfc, rowdiv, bias, x) -> torch.Tensor:
+    lib = _lib.load()
+    n, f = x.shape
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.cgnn_aggregate_f32(
+            _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(coef), _lib.ptr(selfc), _lib.ptr(rowdiv),
+            _lib.ptr(bias), _lib.ptr(x), x.stride(0), _lib.ptr(y), y.stride(0), n, f,
+            _lib.stream_ptr()), "cgnn_aggregate_f32")
+    return y
+
+
+def colsum_raw(a: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    m, n = a.shape
+    out = torch.empty(n, dtype=torch.float32, device=a.device)
+    slab = _scratch(lib.cgnn_colsum_workspace_bytes(m, n), a.device)
+    with torch.cuda.device(a.device):
+        _lib.check(lib.cgnn_colsum_f32(_lib.ptr(a), a.stride(0), _lib.ptr(out), m, n,
+                                       _lib.ptr(slab), _lib.stream_ptr()), "cgnn_colsum_f32")
+    return out
+
+
+def linear_fwd_raw(x1, x2, w, bias, relu: bool) -> torch.Tensor:
+    lib = _lib.load()
+    m, k1 = x1.shape
+    k2 = 0 if x2 is None else x2.shape[1]
+    n = w.shape[0]
+    if w.shape[1] != k1 + k2:
+        raise ValueError(f"weight is {tuple(w.shape)}, inputs give K = {k1}+{k2}")
+    y = torch.empty(m, n, dtype=torch.float32, device=x1.device)
+    with torch.cuda.device(x1.device):
+        _lib.check(lib.cgnn_linear_fwd_f32(
+            _lib.ptr(x1), x1.stride(0), k1, _lib.ptr(x2), 0 if x2 is None else x2.stride(0), k2,
+            _lib.ptr(w), _lib.ptr(bias), int(relu), _lib.ptr(y), y.stride(0), m, n,
+            _lib.stream_ptr()), "cgnn_linear_fwd_f32")
+    return y
+
+
+def linear_bwd_input_raw(dy, w, k0: int, k: int) -> torch.Tensor:
+    lib = _lib.load()
+    m, n = dy.shape
+    dx = torch.empty(m, k, dtype=torch.float32, device=dy.device)
+    with torch.cuda.device(dy.device):
+        _lib.check(lib.cgnn_linear_bwd_input_f32(
+            _lib.ptr(dy), dy.stride(0), _lib.ptr(w), w.stride(0), k0, _lib.ptr(dx), dx.stride(0),
+            m, n, k, _lib.stream_ptr()), "cgnn_linear_bwd_input_f32")
+    return dx
+
+
+def linear_bwd_weight_raw(dy, x, dw, k0: int) -> None:
+    lib = _lib.load()
+    m, n = dy.shape
+    k = x.shape[1]
+    slab = _scratch(lib.cgnn_linear_bwd_weight_workspace_bytes(m, n, k), dy.device)
+    with torch.cuda.device(dy.device):
+        _lib.check(lib.cgnn_linear_bwd_weight_f32(
+            _lib.ptr(dy), dy.stride(0), _lib.ptr(x), x.stride(0), _lib.ptr(dw), dw.stride(0), k0,
+            m, n, k, _lib.ptr(slab), _lib.stream_ptr()), "cgnn_linear_bwd_weight_f32")
+
+
+# ------------------------------------------------------------------------- autograd Functions
+class _Aggregate(torch.autograd.Function):
+    """Y = A_coef X (+ selfc*X) (/rowdiv) (+bias); backward runs the transposed CSR."""
+
+    @staticmethod
+    def forward(ctx, x, bias, fwd, bwd):
+        rowptr, col, coef, selfc, rowdiv = fwd
+        x = _prep(x, "x")
+        bias_c = _prep(bias, "bias")
+        y = aggregate_raw(rowptr, col, coef, selfc, rowdiv, bias_c, x)
+        ctx.bwd = bwd
+        ctx.selfc = selfc
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _prep(dy, "grad")
+        t_rowptr, t_col, t_coef = ctx.bwd
+        dx = db = None
+        if ctx.needs_input_grad[0]:
+            dx = aggregate_raw(t_rowptr, t_col, t_coef, ctx.selfc, None, None, dy)
+        if ctx.has_bias and ctx.needs_input_grad[1]:
+            db = colsum_raw(dy)
+        return dx, db, None, None
+
+
+def aggregate(x, bias, fwd, bwd) -> torch.Tensor:
+    """fwd = (rowptr, col, coef, selfc|None, rowdiv|None) on the dst-sorted CSR;
+    bwd = (rowptr, col, coef) on the src-sorted CSR (coef already divided by rowdiv)."""
+    return _Aggregate.apply(x, bias, fwd, bwd)
+
+
+class _Linear(torch.autograd.Function):
+    """Y = act(X1 W[:, :K1]^T + X2 W[:, K1:]^T + b) on the matrix cores."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, w, bias, relu):
+        x1, x2, w, bias_c = _prep(x1, "x"), _prep(x2, "x2"), _prep(w, "weight"), _prep(bias, "bias")
+        y = linear_fwd_raw(x1, x2, w, bias_c, relu)
+        ctx.relu = relu
+        ctx.has_x2 = x2 is not None
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x1, x2, w, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x1, x2, w, y = ctx.saved_tensors
+        dy = _prep(dy, "grad")
+        if ctx.relu:
+            dy = dy * (y > 0)            # elementwise mask; the GEMMs below are the HIP kernels
+        k1 = x1.shape[1]
+        k2 = x2.shape[1] if x2 is not None else 0
+        dx1 = dx2 = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx1 = linear_bwd_input_raw(dy, w, 0, k1)
+        if x2 is not None and ctx.needs_input_grad[1]:
+            dx2 = linear_bwd_input_raw(dy, w, k1, k2)
+        if ctx.needs_input_grad[2]:
+            dw = torch.empty_like(w)
+            linear_bwd_weight_raw(dy, x1, dw, 0)
+            if x2 is not None:
+                linear_bwd_weight_raw(dy, x2, dw, k1)
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            db = colsum_raw(dy)
+        return dx1, dx2, dw, db, None
+
+
+def linear(x1, x2, w, bias, relu: bool = False) -> torch.Tensor:
+    return _Linear.apply(x1, x2, w, bias, relu)
+
+
+class _PoolMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gptr, num_graphs):
+        lib = _lib.load()
+        x = _prep(x, "x")
+        f = x.shape[1]
+        p = torch.empty(num_graphs, f, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.cgnn_pool_mean_fwd_f32(_lib.ptr(x), x.stride(0), _lib.ptr(gptr),
+                                                  _lib.ptr(p), num_graphs, f, _lib.stream_ptr()),
+                       "cgnn_pool_mean_fwd_f32")
+        ctx.gptr, ctx.shape = gptr, x.shape
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        lib = _lib.load()
+        dp = _prep(dp, "grad")
+        n, f = ctx.shape
+        dx = torch.empty(n, f, dtype=torch.float32, device=dp.device)
+        with torch.cuda.device(dp.device):
+            _lib.check(lib.cgnn_pool_mean_bwd_f32(_lib.ptr(dp), _lib.ptr(ctx.gptr), _lib.ptr(dx),
+                                                  dx.stride(0), dp.shape[0], f, _lib.stream_ptr()),
+                       "cgnn_pool_mean_bwd_f32")
+        return dx, None, None
+
+
+def pool_mean(x, gptr, num_graphs: int) -> torch.Tensor:
+    return _PoolMean.apply(x, gptr, num_graphs)

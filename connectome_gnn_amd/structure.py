@@ -1,0 +1,132 @@
+"""Device-side structure of a ConnectomeBatch: what the HIP kernels index with.
+
+The reference never builds this -- it re-derives everything from the int64 COO inside every
+layer call (models.py:94-113, 146-149).  Here the COO is bucket-sorted once per batch into a
+destination-sorted CSR (forward segment sums) and a source-sorted CSR (their transposes in
+backward), both int32 and stable (COO order inside a row), by ``cgnn_csr_build``.
+
+All arrays are torch tensors only so that their memory comes from torch's caching
+allocator; every number in them is produced by the HIP library.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+
+def _require_device(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{what} is on {t.device}: connectome_gnn_amd runs the message-passing path on a "
+            "ROCm device only (there is no CPU fallback; move the batch/model with .to('cuda')).")
+
+
+@dataclass
+class GcnNorm:
+    dis: torch.Tensor        # [Nn]  (deg + 1e-8)^-1/2, source-side degree incl. self-loop
+    selfc: torch.Tensor      # [Nn]  dis^2  (coefficient of the appended self-loop)
+    coef_dst: torch.Tensor   # [Ee]  c_e in dst-CSR slot order
+    coef_src: torch.Tensor   # [Ee]  c_e in src-CSR slot order
+
+
+@dataclass
+class SageNorm:
+    den: torch.Tensor            # [Nn]  sum of in-edge weights + 1e-8
+    w_dst: torch.Tensor          # [Ee]  w_e in dst-CSR slot order
+    coef_src_bwd: torch.Tensor   # [Ee]  w_e / den[dst_e] in src-CSR slot order
+
+
+class BatchStructure:
+    """dst-/src-sorted CSR (+ per-graph node ranges) of one batch, on its device."""
+
+    def __init__(self):
+        self.num_nodes = 0
+        self.num_edges = 0
+        self.num_graphs = 0
+        self.max_nodes_per_graph = 0
+        self.max_in_degree = 0
+        self.max_out_degree = 0
+        self.block_diagonal = True
+        self.gptr: Optional[torch.Tensor] = None         # int32 [B+1]
+        self.rowptr_dst = self.eid_dst = self.col_dst = None
+        self.rowptr_src = self.eid_src = self.col_src = None
+        self._edge_index = None
+        self._edge_weight = None
+
+    @staticmethod
+    def build(batch) -> "BatchStructure":
+        ei, ew = batch.edge_index, batch.edge_weight
+        _require_device(ei, "batch.edge_index")
+        if ei.dtype != torch.int64 or ei.dim() != 2 or ei.shape[0] != 2:
+            raise ValueError("edge_index must be int64 [2, E]")
+        if ew.dtype != torch.float32:
+            raise TypeError(f"edge_weight must be float32 (the reference is fp32-only), got {ew.dtype}")
+        lib = _lib.load()
+        dev = ei.device
+        ei = ei.contiguous()
+        nn_, ne = batch.num_nodes, int(ei.shape[1])
+        s = BatchStructure()
+        s.num_nodes, s.num_edges, s.num_graphs = nn_, ne, batch.num_graphs
+        s._edge_index, s._edge_weight = ei, ew.contiguous()
+        i32 = dict(dtype=torch.int32, device=dev)
+        s.rowptr_dst = torch.empty(nn_ + 1, **i32)
+        s.rowptr_src = torch.empty(nn_ + 1, **i32)
+        s.eid_dst, s.col_dst = torch.empty(ne, **i32), torch.empty(ne, **i32)
+        s.eid_src, s.col_src = torch.empty(ne, **i32), torch.empty(ne, **i32)
+        flags = torch.empty(4, **i32)
+        ws = torch.empty(int(lib.cgnn_csr_workspace_bytes(nn_, ne)), dtype=torch.uint8, device=dev)
+        node_graph = batch.batch.contiguous() if batch.batch is not None else None
+        if node_graph is not None and (node_graph.dtype != torch.int64 or node_graph.numel() != nn_):
+            raise ValueError("batch.batch must be int64 [num_nodes]")
+        with torch.cuda.device(dev):
+            _lib.check(lib.cgnn_csr_build(
+                _lib.ptr(ei), _lib.ptr(node_graph), nn_, ne,
+                _lib.ptr(s.rowptr_dst), _lib.ptr(s.eid_dst), _lib.ptr(s.col_dst),
+                _lib.ptr(s.rowptr_src), _lib.ptr(s.eid_src), _lib.ptr(s.col_src),
+                _lib.ptr(flags), _lib.ptr(ws), _lib.stream_ptr()), "cgnn_csr_build")
+            s.gptr = batch.ptr.to(device=dev, dtype=torch.int32)
+            f = flags.tolist()                      # one sync per batch, at build time only
+            sizes = (batch.ptr[1:] - batch.ptr[:-1])
+            s.max_nodes_per_graph = int(sizes.max()) if sizes.numel() else 0
+        if f[0]:
+            # the reference would raise from scatter_add_/index (models.py:104,112)
+            raise IndexError(f"{f[0]} edge(s) reference a node outside [0, {nn_})")
+        s.block_diagonal = f[1] == 0
+        s.max_in_degree, s.max_out_degree = f[2], f[3]
+        return s
+
+    # -- normalisations: layer independent, recomputed once per forward pass ----------------
+    def gcn_norm(self) -> GcnNorm:
+        """models.py:94-108 via cgnn_gcn_norm."""
+        lib = _lib.load()
+        dev = self.rowptr_dst.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        n = GcnNorm(torch.empty(self.num_nodes, **f32), torch.empty(self.num_nodes, **f32),
+                    torch.empty(self.num_edges, **f32), torch.empty(self.num_edges, **f32))
+        with torch.cuda.device(dev):
+            _lib.check(lib.cgnn_gcn_norm(
+                _lib.ptr(self._edge_index), _lib.ptr(self._edge_weight), self.num_nodes,
+                self.num_edges, _lib.ptr(self.rowptr_dst), _lib.ptr(self.eid_dst),
+                _lib.ptr(self.rowptr_src), _lib.ptr(self.eid_src), _lib.ptr(n.dis),
+                _lib.ptr(n.selfc), _lib.ptr(n.coef_dst), _lib.ptr(n.coef_src),
+                _lib.stream_ptr()), "cgnn_gcn_norm")
+        return n
+
+    def sage_norm(self) -> SageNorm:
+        """models.py:146-149 via cgnn_sage_norm."""
+        lib = _lib.load()
+        dev = self.rowptr_dst.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        n = SageNorm(torch.empty(self.num_nodes, **f32), torch.empty(self.num_edges, **f32),
+                     torch.empty(self.num_edges, **f32))
+        with torch.cuda.device(dev):
+            _lib.check(lib.cgnn_sage_norm(
+                _lib.ptr(self._edge_index), _lib.ptr(self._edge_weight), self.num_nodes,
+                self.num_edges, _lib.ptr(self.rowptr_dst), _lib.ptr(self.eid_dst),
+                _lib.ptr(self.rowptr_src), _lib.ptr(self.eid_src), _lib.ptr(n.den),
+                _lib.ptr(n.w_dst), _lib.ptr(n.coef_src_bwd), _lib.stream_ptr()), "cgnn_sage_norm")
+        return n

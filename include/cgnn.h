@@ -1,0 +1,145 @@
+/* cgnn.h -- C ABI of libcgnn_hip.so: the MI355X (gfx950) kernels behind the
+ * batched message-passing path of connectome-gnn-suite.
+ *
+ * The reference has no FFI seam on this path (it is pure PyTorch); each entry
+ * point below names the reference lines whose arithmetic it replaces.  The reference-side
+ * binding (ctypes) is shown in INTEGRATION.md and implemented in connectome_gnn_amd/_lib.py.
+ *
+ * Conventions
+ *   - extern "C"; every function returns int: CGNN_OK or a negative CGNN_E* code.  Nothing
+ *     throws, aborts, allocates, frees or synchronises.
+ *   - Pointers are DEVICE pointers unless the name ends in _host.  Sizes are element counts.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All work is
+ *     enqueued on it; outputs are valid once the stream reaches that point.
+ *   - Re-entrant and thread-safe for distinct buffers/streams; no global mutable state.
+ *   - Floating point is fp32 storage / fp32 accumulate unless a name says otherwise
+ *     (BatchNorm statistics are accumulated in fp64).  Indices inside the library are int32;
+ *     the int64 COO of the reference (graph.py:104-105) is read only by cgnn_csr_build.
+ *
+ * Layout vocabulary (graph.py:101-140): a ConnectomeBatch packs B graphs block-diagonally:
+ *   Nn nodes, Ee directed edges, node n of graph g has global id ptr[g] + n;
+ *   edge_index is [2, Ee] int64 row-major (row 0 = src, row 1 = dst).
+ */
+#ifndef CGNN_H
+#define CGNN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CGNN_OK            0
+#define CGNN_EINVAL       (-1)  /* bad argument (null pointer, negative size, unsupported width) */
+#define CGNN_ELAUNCH      (-2)  /* hipGetLastError() != hipSuccess after a launch */
+#define CGNN_EUNSUPPORTED (-3)  /* shape outside what this build of the kernels covers */
+
+#define CGNN_ABI_VERSION 1
+
+/* Library/ABI version and the gfx target the kernels were compiled for ("gfx950"). */
+int cgnn_abi_version(void);
+const char* cgnn_build_target(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Structure: destination- and source-sorted CSR of the batch COO.
+ * Replaces the implicit index handling of scatter_add_/index in models.py:40-54,103-113,
+ * 146-149 (forward = rows by dst; autograd's backward of x[src] = rows by src).
+ * Slots inside a row keep COO order (stable), so per-row sums run in the reference's order
+ * and duplicate edges survive.
+ * ------------------------------------------------------------------------------------- */
+
+/* Bytes of scratch cgnn_csr_build needs for (num_nodes, num_edges). */
+int64_t cgnn_csr_workspace_bytes(int64_t num_nodes, int64_t num_edges);
+
+/* edge_index : int64 [2, Ee]         (graph.py:152 offsets already applied)
+ * node_graph : int64 [Nn] or NULL    (ConnectomeBatch.batch; enables the cross-graph check)
+ * rowptr_dst : int32 [Nn+1] out      in-edge row pointer       rowptr_src: same for out-edges
+ * eid_dst    : int32 [Ee]   out      COO edge id of each slot  eid_src
+ * col_dst    : int32 [Ee]   out      src node of each slot     col_src  : dst node of each slot
+ * flags      : int32 [4]    out      [0] edges with an endpoint outside [0,Nn) (dropped),
+ *                                    [1] edges whose endpoints lie in different graphs,
+ *                                    [2] max in-degree, [3] max out-degree
+ * workspace  : cgnn_csr_workspace_bytes() bytes, 16-byte aligned */
+int cgnn_csr_build(const int64_t* edge_index, const int64_t* node_graph,
+                   int64_t num_nodes, int64_t num_edges,
+                   int32_t* rowptr_dst, int32_t* eid_dst, int32_t* col_dst,
+                   int32_t* rowptr_src, int32_t* eid_src, int32_t* col_src,
+                   int32_t* flags, void* workspace, void* stream);
+
+/* GCN symmetric normalisation, models.py:94-108: self-loop weight 1 appended last,
+ * deg[i] = sum_{e: src=i} w_e + 1 (SOURCE side), dis = (deg + 1e-8)^-1/2,
+ * c_e = dis[src]*w_e*dis[dst].  Layer independent -> once per batch.
+ * dis [Nn], selfc [Nn] = dis^2, coef_dst [Ee] (dst-CSR slot order), coef_src [Ee]. */
+int cgnn_gcn_norm(const int64_t* edge_index, const float* edge_weight,
+                  int64_t num_nodes, int64_t num_edges,
+                  const int32_t* rowptr_dst, const int32_t* eid_dst,
+                  const int32_t* rowptr_src, const int32_t* eid_src,
+                  float* dis, float* selfc, float* coef_dst, float* coef_src, void* stream);
+
+/* GraphSAGE weighted-mean normalisation, models.py:146-149:
+ * den[d] = sum_{e: dst=d} w_e + 1e-8; w_dst [Ee] = w permuted to dst-CSR slots;
+ * coef_src_bwd [Ee] = w_e / den[dst_e] in src-CSR slots (backward of the mean). */
+int cgnn_sage_norm(const int64_t* edge_index, const float* edge_weight,
+                   int64_t num_nodes, int64_t num_edges,
+                   const int32_t* rowptr_dst, const int32_t* eid_dst,
+                   const int32_t* rowptr_src, const int32_t* eid_src,
+                   float* den, float* w_dst, float* coef_src_bwd, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Edge-weighted segment reduction (the "scatter"), models.py:50-54,112-114,146-149.
+ *   Y[r, :] = ( sum_{s in row r} coef[s] * X[col[s], :] ) / rowdiv[r]
+ *             + selfc[r] * X[r, :] + bias[:]
+ * rowdiv, selfc, bias may be NULL (treated as 1, 0, 0).  No atomics: one wave owns a row,
+ * slots are summed in order.  The transposed pass (autograd of x[src]) is the same call on
+ * the src-sorted CSR.  ldx/ldy are row strides in elements (>= F).
+ * ------------------------------------------------------------------------------------- */
+int cgnn_aggregate_f32(const int32_t* rowptr, const int32_t* col, const float* coef,
+                       const float* selfc, const float* rowdiv, const float* bias,
+                       const float* X, int64_t ldx, float* Y, int64_t ldy,
+                       int64_t num_rows, int32_t F, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Feature projection on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32),
+ * models.py:111 (GCN, no bias) and :151-152 (SAGE: Linear([X || agg]) + bias, ReLU).
+ *   fwd        : Y[M,N]  = act( X1[M,K1] W[:, 0:K1]^T + X2[M,K2] W[:, K1:K1+K2]^T + bias )
+ *   bwd_input  : dX[M,K] = dY[M,N] W[:, k0:k0+K]        (ldw = K1+K2)
+ *   bwd_weight : dW[N, k0:k0+K] = dY^T X                 (partials in `slab`, then reduced
+ *                                                          in fp64, deterministic)
+ * W is the nn.Linear weight [N, K1+K2] row-major.  X2/K2 = NULL/0 for one panel.
+ * relu != 0 applies max(.,0) in the epilogue.
+ * ------------------------------------------------------------------------------------- */
+int cgnn_linear_fwd_f32(const float* X1, int64_t ldx1, int32_t K1,
+                        const float* X2, int64_t ldx2, int32_t K2,
+                        const float* W, const float* bias, int32_t relu,
+                        float* Y, int64_t ldy, int64_t M, int32_t N, void* stream);
+
+int cgnn_linear_bwd_input_f32(const float* dY, int64_t lddy, const float* W, int32_t ldw,
+                              int32_t k0, float* dX, int64_t lddx,
+                              int64_t M, int32_t N, int32_t K, void* stream);
+
+/* Bytes of `slab` scratch for bwd_weight. */
+int64_t cgnn_linear_bwd_weight_workspace_bytes(int64_t M, int32_t N, int32_t K);
+
+int cgnn_linear_bwd_weight_f32(const float* dY, int64_t lddy, const float* X, int64_t ldx,
+                               float* dW, int32_t ldw, int32_t k0,
+                               int64_t M, int32_t N, int32_t K, void* slab, void* stream);
+
+/* Column sums (bias gradients, models.py:81,114): out[j] = sum_r A[r, j]; fp64 combine.
+ * slab: cgnn_colsum_workspace_bytes(M, N) bytes. */
+int64_t cgnn_colsum_workspace_bytes(int64_t M, int32_t N);
+int cgnn_colsum_f32(const float* A, int64_t lda, float* out, int64_t M, int32_t N,
+                    void* slab, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Per-graph mean-pool readout, models.py:40-47,57-59: P[g,:] = sum_{n in g} X[n,:] / (n_g+1e-8)
+ * using the contiguous node ranges gptr (int32 [B+1], = ConnectomeBatch.ptr).
+ * ------------------------------------------------------------------------------------- */
+int cgnn_pool_mean_fwd_f32(const float* X, int64_t ldx, const int32_t* gptr, float* P,
+                           int32_t num_graphs, int32_t F, void* stream);
+int cgnn_pool_mean_bwd_f32(const float* dP, const int32_t* gptr, float* dX, int64_t lddx,
+                           int32_t num_graphs, int32_t F, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CGNN_H */
