@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py -- training graphs/sec of the batched message-passing path on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one full training step of the reference's loop (train.py:46-51): zero_grad,
+forward (normalisation + 3 layers + pool + head), CrossEntropy, backward, gradient all-reduce
+(N > 1), Adam(lr 1e-3, wd 1e-4) -- on a batch that is already resident in HBM with its CSR
+structure built (the reference's collate is outside its step as well).
+Default workload = BASELINE.json's headline: 3-layer GCN, hidden 64, 4096 graphs x 360 ROI
+(Watts-Strogatz k=14, beta 0.15) per GPU, fp32, dropout 0.3.  Weak scaling: every rank trains
+on its own 4096-graph shard of a global batch of N*4096 (graphs shard with no data-path
+collective; one gradient all-reduce per step).
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel of the step, timed live
+with HIP events on its own stream; `cpu_baseline` is the oracle (a port of the reference's
+pure-PyTorch CPU path) timed on this box's host cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+WORKLOADS = {
+    # name: model, n ROI, k, hidden, per-GPU batch, subjects per GPU
+    "cfg4-headline-gcn-4096x360-h64": dict(model="gcn", n=360, k=14, hidden=64, batch=4096),
+    "cfg2-gcn-512x84-h64": dict(model="gcn", n=84, k=8, hidden=64, batch=512),
+    "cfg3-sage-512x360-h128": dict(model="sage", n=360, k=14, hidden=128, batch=512),
+}
+
+
+def algorithmic_bytes_per_graph(model: str, n: int, e: int, hidden: int, s: int = 4) -> float:
+    """GCN Nn*s*(34H+10) + 48*Ee ; SAGE Nn*s*(37H+10) + 48*Ee (per graph)."""
+    c = 34 if model == "gcn" else 37
+    return n * s * (c * hidden + 10) + 48.0 * e
+
+
+def cpu_baseline(model: str, n: int, k: int, hidden: int, budget_s: float = 20.0) -> dict:
+    """Time the oracle's full train step (same ATen op sequence as the reference) on the host."""
+    from oracle import reference_path as O
+    from connectome_gnn_amd.synthetic import generate_packed
+    from connectome_gnn_amd.resident import assemble_batch
+    sample = 128 if n >= 360 else 512
+    ds = generate_packed(sample, n, k, seed=42)
+    b = assemble_batch(ds, torch.arange(sample))
+    ob = O.OBatch(b.node_features, b.edge_index, b.edge_weight, b.batch, b.labels, b.ptr)
+    torch.manual_seed(42)
+    st = O.require_grad(O.INIT[model](5, hidden))
+    opt = torch.optim.Adam([st[kk] for kk in O.param_keys(st)], lr=1e-3, weight_decay=1e-4)
+    times = []
+    t_end = time.perf_counter() + budget_s
+    for i in range(3 + 10):
+        t0 = time.perf_counter()
+        O.train_step(model, st, ob, opt, 0.3)
+        dt = time.perf_counter() - t0
+        if i >= 3:
+            times.append(dt)
+        if time.perf_counter() > t_end and len(times) >= 3:
+            break
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": sample / med, "unit": "graphs/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"oracle train step (dropout 0.3, Adam), batch {sample}x{n}-ROI, "
+                      f"median of {len(times)} steps after 3 warm-up, collate excluded"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cfg4-headline-gcn-4096x360-h64", choices=list(WORKLOADS))
+    ap.add_argument("--impl", default=os.environ.get("CGNN_IMPL", "auto"))
+    ap.add_argument("--batch", type=int, default=0, help="override per-GPU batch")
+    ap.add_argument("--nbuf", type=int, default=2, help="distinct resident batches cycled through")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-bn", action="store_true", help="full-batch BN statistics across ranks")
+    args = ap.parse_args()
+
+    import connectome_gnn_amd as C
+    from connectome_gnn_amd import _lib, dist as cdist
+    from connectome_gnn_amd.resident import assemble_batch
+    from connectome_gnn_amd.synthetic import generate_packed
+
+    rank, world, local = cdist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    wl = dict(WORKLOADS[args.workload])
+    if args.batch:
+        wl["batch"] = args.batch
+    model_kind, n, k, hidden, bsz = wl["model"], wl["n"], wl["k"], wl["hidden"], wl["batch"]
+    e = n * k
+
+    # ---- data: this rank's shard of the synthetic dataset, resident in HBM ------------------
+    ds = generate_packed(bsz, n, k, seed=42 + rank).to(dev)
+    g = torch.Generator().manual_seed(1234 + rank)
+    batches = []
+    for _ in range(max(1, args.nbuf)):
+        b = assemble_batch(ds, torch.randperm(bsz, generator=g))
+        b.structure()                       # CSR build = collate-time work, outside the step
+        batches.append(b)
+
+    torch.manual_seed(42)
+    cls = C.GCNConnectome if model_kind == "gcn" else C.GraphSAGEConnectome
+    kw = {} if args.impl == "auto" else {"impl": args.impl}
+    model = cls(5, hidden, 2, 3, 0.3, **kw).to(dev).train()
+    if world > 1:
+        cdist.broadcast_parameters(model)
+        if args.sync_bn:
+            model = cdist.convert_sync_batchnorm(model)
+    sync = cdist.GradSync(model.parameters()) if world > 1 else None
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4, fused=True)
+    loss_fn = torch.nn.CrossEntropyLoss()
+
+    def step(i: int):
+        b = batches[i % len(batches)]
+        opt.zero_grad(set_to_none=True)
+        loss = loss_fn(model(b), b.labels)
+        loss.backward()
+        if sync is not None:
+            sync()
+        opt.step()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    impl_used = getattr(model, "impl_used", "layered")
+    dom = getattr(model, "dominant_kernel", None) or f"cgnn_aggregate_f32[F={hidden}]"
+    _lib.TIMER = _lib.KernelTimer([dom])
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    timer, _lib.TIMER = _lib.TIMER, None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    final_loss = float(loss)
+
+    if rank == 0:
+        graphs_per_s = world * bsz * args.steps / dt
+        bpg = algorithmic_bytes_per_graph(model_kind, n, e, hidden)
+        kms = timer.ms(dom)
+        nn_, ee = bsz * n, bsz * e
+        dom_bytes = getattr(model, "dominant_kernel_bytes", None)
+        if dom_bytes is None:                 # aggregate: 2*Nn*F*s + 8*Ee + 4*(Nn+1)  
+            dom_bytes = 2.0 * nn_ * hidden * 4 + 8.0 * ee + 4.0 * (nn_ + 1)
+        else:
+            dom_bytes = dom_bytes(nn_, ee)
+        avg_ms = sum(kms) / max(len(kms), 1)
+        achieved = dom_bytes / (avg_ms * 1e-3) / 1e9 if kms else 0.0
+        out = {
+            "metric": "training graphs/sec, 3-layer GCN, batch=4096x360-ROI connectomes"
+            if args.workload.startswith("cfg4") else f"training graphs/sec, {args.workload}",
+            "value": graphs_per_s, "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": args.workload, "model": model_kind, "rois": n, "ws_k": k,
+                       "edges_per_graph": e, "hidden": hidden, "layers": 3,
+                       "graphs_per_gpu": bsz, "global_batch": world * bsz, "dropout": 0.3,
+                       "optimizer": "Adam lr1e-3 wd1e-4", "impl": impl_used,
+                       "bn": "sync" if (world > 1 and args.sync_bn) else "per-rank",
+                       "parallelism": f"graph-sharded dp{world}"},
+            "step_algorithmic": {"bytes_per_graph": bpg,
+                                 "GBps": bpg * graphs_per_s / world / 1e9,
+                                 "frac_of_hbm_peak": bpg * graphs_per_s / world / (HBM_PEAK_GBS * 1e9)},
+            "roofline": {"bound": "hbm", "kernel": dom, "launches_timed": len(kms),
+                         "avg_ms": avg_ms, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None},
+            "final_loss": final_loss,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(model_kind, n, k, hidden)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -87,3 +87,46 @@ def stream_ptr() -> int:
     """The HIP stream torch is currently enqueuing on (kernels join torch's ordering)."""
     import torch
     return torch.cuda.current_stream().cuda_stream
+
+
+# ---------------------------------------------------------------------------------------------
+# Optional per-kernel timing for bench.py's roofline line: HIP events recorded on the stream
+# the kernel is launched on, around selected C-ABI calls.  Off (zero overhead) by default.
+# ---------------------------------------------------------------------------------------------
+class KernelTimer:
+    def __init__(self, names):
+        self.names = set(names)
+        self.events = {n: [] for n in self.names}
+
+    def ms(self, name):
+        """Per-launch durations in ms (call after a device synchronise)."""
+        return [a.elapsed_time(b) for a, b in self.events[name]]
+
+
+TIMER = None
+
+
+class timed:
+    """``with timed("cgnn_x", tag):`` brackets one C-ABI call with HIP events when a
+    KernelTimer that names it is installed in ``_lib.TIMER``."""
+    __slots__ = ("key", "pair")
+
+    def __init__(self, name, tag=None):
+        self.key = name if tag is None else f"{name}[{tag}]"
+        self.pair = None
+
+    def __enter__(self):
+        t = TIMER
+        if t is not None and self.key in t.names:
+            import torch
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(torch.cuda.current_stream())
+            self.pair = (a, b)
+        return self
+
+    def __exit__(self, *exc):
+        if self.pair is not None:
+            import torch
+            self.pair[1].record(torch.cuda.current_stream())
+            TIMER.events[self.key].append(self.pair)
+        return False

@@ -33,7 +33,7 @@ def aggregate_raw(rowptr, col, coef, selfc, rowdiv, bias, x) -> torch.Tensor:
     lib = _lib.load()
     n, f = x.shape
     y = torch.empty_like(x)
-    with torch.cuda.device(x.device):
+    with torch.cuda.device(x.device), _lib.timed("cgnn_aggregate_f32", f"F={f}"):
         _lib.check(lib.cgnn_aggregate_f32(
             _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(coef), _lib.ptr(selfc), _lib.ptr(rowdiv),
             _lib.ptr(bias), _lib.ptr(x), x.stride(0), _lib.ptr(y), y.stride(0), n, f,
