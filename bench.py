@@ -54,6 +54,8 @@ def cpu_baseline(model: str, n: int, k: int, hidden: int, budget_s: float = 20.0
     from connectome_gnn_amd.synthetic import generate_packed
     from connectome_gnn_amd.resident import assemble_batch
     sample = 128 if n >= 360 else 512
+    # a 1-GPU box's CPU share is 16 cores; more threads only oversubscribe the ATen loops
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     ds = generate_packed(sample, n, k, seed=42)
     b = assemble_batch(ds, torch.arange(sample))
     ob = O.OBatch(b.node_features, b.edge_index, b.edge_weight, b.batch, b.labels, b.ptr)
@@ -147,7 +149,15 @@ def main() -> None:
     for i in range(args.warmup):
         step(i)
     impl_used = getattr(model, "impl_used", "layered")
-    dom = getattr(model, "dominant_kernel", None) or f"cgnn_aggregate_f32[F={hidden}]"
+    # dominant kernel of the step and its ALGORITHMIC bytes per launch (SURVEY 8d per-unit
+    # figures): fused path -> the per-layer backward kernel: BN-backward 5*Nn*H*s +
+    # Nn*s*(H + 2*F_l) + 8*Ee; layered path -> the aggregate: 2*Nn*F*s + 8*Ee + 4*(Nn+1).
+    if impl_used == "fused":
+        dom = "cgnn_gcn_fused_bwd"
+        dom_bytes_fn = lambda nn_, ee: nn_ * 4.0 * (5 * hidden + hidden + 2 * hidden) + 8.0 * ee
+    else:
+        dom = f"cgnn_aggregate_f32[F={hidden}]"
+        dom_bytes_fn = lambda nn_, ee: 2.0 * nn_ * hidden * 4 + 8.0 * ee + 4.0 * (nn_ + 1)
     _lib.TIMER = _lib.KernelTimer([dom])
     fence()
     t0 = time.perf_counter()
@@ -160,18 +170,14 @@ def main() -> None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     if rank == 0:
         graphs_per_s = world * bsz * args.steps / dt
         bpg = algorithmic_bytes_per_graph(model_kind, n, e, hidden)
         kms = timer.ms(dom)
         nn_, ee = bsz * n, bsz * e
-        dom_bytes = getattr(model, "dominant_kernel_bytes", None)
-        if dom_bytes is None:                 # aggregate: 2*Nn*F*s + 8*Ee + 4*(Nn+1)  
-            dom_bytes = 2.0 * nn_ * hidden * 4 + 8.0 * ee + 4.0 * (nn_ + 1)
-        else:
-            dom_bytes = dom_bytes(nn_, ee)
+        dom_bytes = dom_bytes_fn(nn_, ee)
         avg_ms = sum(kms) / max(len(kms), 1)
         achieved = dom_bytes / (avg_ms * 1e-3) / 1e9 if kms else 0.0
         out = {

@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_int, c_int32, c_int64, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcgnn_hip.so")
@@ -20,7 +20,19 @@ CGNN_OK, CGNN_EINVAL, CGNN_ELAUNCH, CGNN_EUNSUPPORTED = 0, -1, -2, -3
 _ERR = {CGNN_EINVAL: "CGNN_EINVAL (bad argument)", CGNN_ELAUNCH: "CGNN_ELAUNCH (kernel launch failed)",
         CGNN_EUNSUPPORTED: "CGNN_EUNSUPPORTED (shape not covered by this build)"}
 
-P, I32, I64 = c_void_p, c_int32, c_int64
+P, I32, I64, U64, F32, F64 = c_void_p, c_int32, c_int64, c_uint64, c_float, c_double
+
+
+class CgnnTiles(ctypes.Structure):
+    """Mirror of `struct cgnn_tiles` (include/cgnn.h): host block of device pointers."""
+    _fields_ = [("num_nodes", c_int64), ("num_tiles", c_int32), ("max_tile_rows", c_int32),
+                ("tile_ptr", c_void_p),
+                ("rowptr_dst", c_void_p), ("col_dst", c_void_p), ("coef_dst", c_void_p),
+                ("rowptr_src", c_void_p), ("col_src", c_void_p), ("coef_src", c_void_p),
+                ("selfc", c_void_p)]
+
+
+TP = ctypes.POINTER(CgnnTiles)
 
 # name -> (restype, argtypes).  Order and meaning follow include/cgnn.h exactly.
 PROTOTYPES = {
@@ -39,6 +51,19 @@ PROTOTYPES = {
     "cgnn_colsum_f32": (c_int, [P, I64, P, I64, I32, P, P]),
     "cgnn_pool_mean_fwd_f32": (c_int, [P, I64, P, P, I32, I32, P]),
     "cgnn_pool_mean_bwd_f32": (c_int, [P, P, P, I64, I32, I32, P]),
+    # fused per-tile GCN path
+    "cgnn_fused_grid": (c_int, []),
+    "cgnn_gcn_fused_fwd_first": (c_int, [TP, P, I32, P, P, P, P, P]),
+    "cgnn_gcn_fused_fwd": (c_int, [TP, P, P, F32, U64, P, P, P, P, P, P]),
+    "cgnn_bn_reduce": (c_int, [P, I32, I32, P, P]),
+    "cgnn_bn_finalize": (c_int, [P, F64, P, P, P, P, F32, F32, I32, P, P]),
+    "cgnn_gcn_fused_pool_fwd": (c_int, [P, P, F32, U64, P, P, I32, P, P]),
+    "cgnn_gcn_fused_pool_bwd": (c_int, [P, P, P, F32, P, P, I32, P, P, P]),
+    "cgnn_bn_bwd_finalize": (c_int, [P, F64, P, P, P, P]),
+    "cgnn_gcn_fused_bwd": (c_int, [TP, P, P, P, P, P, P, F32, P, P, P, P, P, P, P]),
+    "cgnn_gcn_fused_bwd_first": (c_int, [TP, P, P, P, P, P, I32, P, P, P]),
+    "cgnn_slab_reduce_f32": (c_int, [P, I32, I32, I32, I32, P, I32, P]),
+    "cgnn_slab_reduce_f64": (c_int, [P, I32, I32, P, P]),
 }
 
 

@@ -1,0 +1,236 @@
+"""Fused per-tile GCN encoder (hidden = 64): host orchestration of csrc/fused_gcn.hip.
+
+One ``torch.autograd.Function`` covers GCNConnectome.encode end to end (reference
+models.py:203-211): per layer one persistent HIP kernel that keeps each tile's [rows x 64]
+feature block in LDS, plus two tiny kernels for the batch-wide BatchNorm reduction.  What
+touches HBM per layer is the previous layer's pre-BatchNorm output (read), the CSR (read)
+and this layer's pre-BatchNorm output (write); BatchNorm-apply, ReLU, dropout, the
+projection and the BatchNorm statistics never make a round trip.
+
+Saved for backward: the pre-BatchNorm outputs Y_l, the 4x64 BatchNorm coefficient blocks and
+one dropout keep-byte per (node, 4-column chunk); activations are rebuilt in LDS.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .structure import BatchStructure, GcnNorm
+
+HID = 64
+MAX_ROWS = 384
+MAX_F0 = 16
+
+
+def eligible(model, batch, structure: BatchStructure) -> Optional[str]:
+    """None if the fused path covers this (model, batch); else the reason it does not."""
+    if model.convs[0].linear.weight.shape[0] != HID:
+        return f"hidden_dim != {HID}"
+    if model.convs[0].linear.weight.shape[1] > MAX_F0:
+        return f"in_channels > {MAX_F0}"
+    if not structure.block_diagonal:
+        return "edges cross graph boundaries"
+    if structure.max_nodes_per_graph > MAX_ROWS:
+        return f"a graph has more than {MAX_ROWS} nodes"
+    if batch.node_features.requires_grad:
+        return "node_features require grad"
+    for bn in model.batch_norms:
+        if not (bn.affine and bn.track_running_stats) or bn.momentum is None:
+            return "BatchNorm without affine/running stats/momentum"
+    return None
+
+
+def _tiles_struct(s: BatchStructure, norm: GcnNorm, grid: int):
+    tptr, rows = s.tile_ptr(MAX_ROWS, grid)
+    t = _lib.CgnnTiles()
+    t.num_nodes = s.num_nodes
+    t.num_tiles = int(tptr.numel()) - 1
+    t.max_tile_rows = rows
+    t.tile_ptr = tptr.data_ptr()
+    t.rowptr_dst, t.col_dst, t.coef_dst = s.rowptr_dst.data_ptr(), s.col_dst.data_ptr(), norm.coef_dst.data_ptr()
+    t.rowptr_src, t.col_src, t.coef_src = s.rowptr_src.data_ptr(), s.col_src.data_ptr(), norm.coef_src.data_ptr()
+    t.selfc = norm.selfc.data_ptr()
+    return t, tptr          # keep tptr alive with the struct
+
+
+class _Ctx:
+    """Everything of one forward pass that backward needs and autograd must not track."""
+    __slots__ = ("s", "norm", "tiles", "tptr", "grid", "ys", "bns", "masks", "p", "x0", "f0",
+                 "count", "sync_group", "num_layers", "training")
+
+
+def _sync_sums(sums: torch.Tensor, count: float, group) -> float:
+    """Full-batch BatchNorm across ranks: all-reduce [sum|sumsq|rows] (SURVEY 8e option i)."""
+    buf = torch.cat([sums, sums.new_tensor([count])])
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    sums.copy_(buf[:-1])
+    return float(buf[-1])
+
+
+class FusedGCNEncode(torch.autograd.Function):
+    """P[B,64] = mean-pool(GCN stack(x0)); args = x0, then (W, b, gamma, beta) per layer."""
+
+    @staticmethod
+    def forward(ctx, x0, meta, *params):
+        lib = _lib.load()
+        s: BatchStructure = meta["structure"]
+        norm: GcnNorm = meta["norm"]
+        bns_mod = meta["batch_norms"]
+        training: bool = meta["training"]
+        p: float = meta["dropout"] if training else 0.0
+        sync_group = meta.get("sync_group")
+        L = len(params) // 4
+        dev = x0.device
+        x0 = x0.contiguous()
+        nn_, B = s.num_nodes, s.num_graphs
+        grid = lib.cgnn_fused_grid()
+        tiles, tptr = _tiles_struct(s, norm, grid)
+        tp = ctypes.byref(tiles)
+        f32 = dict(dtype=torch.float32, device=dev)
+        stat_slab = torch.empty(grid, 128, dtype=torch.float64, device=dev) if training else None
+        sums = torch.empty(128, dtype=torch.float64, device=dev) if training else None
+        ys: List[torch.Tensor] = []
+        bns: List[torch.Tensor] = []
+        masks: List[Optional[torch.Tensor]] = []
+        local_count = count = float(nn_)
+        st = _lib.stream_ptr
+        with torch.cuda.device(dev):
+            for l in range(L):
+                w, b, gamma, beta = (t.contiguous() for t in params[4 * l:4 * l + 4])
+                y = torch.empty(nn_, HID, **f32)
+                if l == 0:
+                    with _lib.timed("cgnn_gcn_fused_fwd_first"):
+                        _lib.check(lib.cgnn_gcn_fused_fwd_first(
+                            tp, _lib.ptr(x0), x0.shape[1], _lib.ptr(w), _lib.ptr(b), _lib.ptr(y),
+                            _lib.ptr(stat_slab), st()), "cgnn_gcn_fused_fwd_first")
+                else:
+                    mask = torch.empty(nn_ * 16, dtype=torch.uint8, device=dev) if p > 0 else None
+                    seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0
+                    with _lib.timed("cgnn_gcn_fused_fwd"):
+                        _lib.check(lib.cgnn_gcn_fused_fwd(
+                            tp, _lib.ptr(ys[-1]), _lib.ptr(bns[-1]), p, seed, _lib.ptr(mask),
+                            _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), _lib.ptr(stat_slab), st()),
+                            "cgnn_gcn_fused_fwd")
+                    masks.append(mask)
+                bn_mod = bns_mod[l]
+                bn = torch.empty(4 * HID, **f32)
+                cnt = count
+                if training:
+                    _lib.check(lib.cgnn_bn_reduce(_lib.ptr(stat_slab), grid, 128, _lib.ptr(sums), st()),
+                               "cgnn_bn_reduce")
+                    if sync_group is not None:
+                        cnt = _sync_sums(sums, local_count, sync_group)
+                    bn_mod.num_batches_tracked.add_(1)
+                _lib.check(lib.cgnn_bn_finalize(
+                    _lib.ptr(sums), cnt, _lib.ptr(gamma), _lib.ptr(beta),
+                    _lib.ptr(bn_mod.running_mean), _lib.ptr(bn_mod.running_var),
+                    float(bn_mod.momentum), float(bn_mod.eps), int(training), _lib.ptr(bn), st()),
+                    "cgnn_bn_finalize")
+                if l == 0:
+                    count = cnt
+                ys.append(y)
+                bns.append(bn)
+            mask = torch.empty(nn_ * 16, dtype=torch.uint8, device=dev) if p > 0 else None
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0
+            pooled = torch.empty(B, HID, **f32)
+            _lib.check(lib.cgnn_gcn_fused_pool_fwd(
+                _lib.ptr(ys[-1]), _lib.ptr(bns[-1]), p, seed, _lib.ptr(mask), _lib.ptr(s.gptr), B,
+                _lib.ptr(pooled), st()), "cgnn_gcn_fused_pool_fwd")
+            masks.append(mask)
+        c = _Ctx()
+        c.s, c.norm, c.tiles, c.tptr, c.grid = s, norm, tiles, tptr, grid
+        c.ys, c.bns, c.masks, c.p, c.x0, c.f0 = ys, bns, masks, p, x0, x0.shape[1]
+        c.count, c.sync_group, c.num_layers, c.training = count, sync_group, L, training
+        ctx.c = c
+        ctx.save_for_backward(*params)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, d_pooled):
+        lib = _lib.load()
+        c: _Ctx = ctx.c
+        params = ctx.saved_tensors
+        L, grid, s = c.num_layers, c.grid, c.s
+        dev = d_pooled.device
+        nn_, B = s.num_nodes, s.num_graphs
+        f32 = dict(dtype=torch.float32, device=dev)
+        f64 = dict(dtype=torch.float64, device=dev)
+        tp = ctypes.byref(c.tiles)
+        st = _lib.stream_ptr
+        d_pooled = d_pooled.contiguous()
+        s_slab = torch.empty(grid, 128, **f64)
+        sums = torch.empty(128, **f64)
+        dw_slab = torch.empty(grid, HID * HID, **f32)
+        db_slab = torch.empty(grid, HID, **f64)
+        dz = torch.empty(nn_, HID, **f32)
+        dz_prev = torch.empty(nn_, HID, **f32) if L > 1 else None
+        grads: List[Optional[torch.Tensor]] = [None] * (4 * L)
+
+        def bn_backward(l: int) -> torch.Tensor:
+            """sums of layer l (in s_slab) -> dgamma/dbeta of layer l and its c1|c2 block."""
+            _lib.check(lib.cgnn_bn_reduce(_lib.ptr(s_slab), grid, 128, _lib.ptr(sums), st()),
+                       "cgnn_bn_reduce")
+            if c.sync_group is not None:
+                dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=c.sync_group)
+            dgamma, dbeta, bwc = torch.empty(HID, **f32), torch.empty(HID, **f32), torch.empty(2 * HID, **f32)
+            _lib.check(lib.cgnn_bn_bwd_finalize(_lib.ptr(sums), c.count, _lib.ptr(dgamma),
+                                                _lib.ptr(dbeta), _lib.ptr(bwc), st()),
+                       "cgnn_bn_bwd_finalize")
+            grads[4 * l + 2], grads[4 * l + 3] = dgamma, dbeta
+            if not c.training:
+                bwc.zero_()      # eval-mode BatchNorm is a fixed affine map: dY = a * dZ
+            return bwc
+
+        with torch.cuda.device(dev):
+            _lib.check(lib.cgnn_gcn_fused_pool_bwd(
+                _lib.ptr(d_pooled), _lib.ptr(c.ys[-1]), _lib.ptr(c.bns[-1]), c.p,
+                _lib.ptr(c.masks[-1]), _lib.ptr(s.gptr), B, _lib.ptr(dz), _lib.ptr(s_slab), st()),
+                "cgnn_gcn_fused_pool_bwd")
+            bwc = bn_backward(L - 1)
+            for l in range(L - 1, 0, -1):
+                w = params[4 * l].contiguous()
+                with _lib.timed("cgnn_gcn_fused_bwd"):
+                    _lib.check(lib.cgnn_gcn_fused_bwd(
+                        tp, _lib.ptr(dz), _lib.ptr(c.ys[l]), _lib.ptr(c.bns[l]), _lib.ptr(bwc),
+                        _lib.ptr(c.ys[l - 1]), _lib.ptr(c.bns[l - 1]), c.p, _lib.ptr(c.masks[l - 1]),
+                        _lib.ptr(w), _lib.ptr(dz_prev), _lib.ptr(s_slab), _lib.ptr(dw_slab),
+                        _lib.ptr(db_slab), st()), "cgnn_gcn_fused_bwd")
+                dw, db = torch.empty(HID, HID, **f32), torch.empty(HID, **f32)
+                _lib.check(lib.cgnn_slab_reduce_f32(_lib.ptr(dw_slab), grid, HID, HID, HID,
+                                                    _lib.ptr(dw), HID, st()), "cgnn_slab_reduce_f32")
+                _lib.check(lib.cgnn_slab_reduce_f64(_lib.ptr(db_slab), grid, HID, _lib.ptr(db), st()),
+                           "cgnn_slab_reduce_f64")
+                grads[4 * l], grads[4 * l + 1] = dw, db
+                bwc = bn_backward(l - 1)
+                dz, dz_prev = dz_prev, dz
+            with _lib.timed("cgnn_gcn_fused_bwd_first"):
+                _lib.check(lib.cgnn_gcn_fused_bwd_first(
+                    tp, _lib.ptr(dz), _lib.ptr(c.ys[0]), _lib.ptr(c.bns[0]), _lib.ptr(bwc),
+                    _lib.ptr(c.x0), c.f0, _lib.ptr(dw_slab), _lib.ptr(db_slab), st()),
+                    "cgnn_gcn_fused_bwd_first")
+            dw0, db0 = torch.empty(HID, c.f0, **f32), torch.empty(HID, **f32)
+            _lib.check(lib.cgnn_slab_reduce_f32(_lib.ptr(dw_slab), grid, HID, 16, c.f0,
+                                                _lib.ptr(dw0), c.f0, st()), "cgnn_slab_reduce_f32")
+            _lib.check(lib.cgnn_slab_reduce_f64(_lib.ptr(db_slab), grid, HID, _lib.ptr(db0), st()),
+                       "cgnn_slab_reduce_f64")
+            grads[0], grads[1] = dw0, db0
+        ctx.c = None
+        return (None, None, *grads)
+
+
+def encode(model, batch, structure: BatchStructure, norm: GcnNorm) -> torch.Tensor:
+    params = []
+    for conv, bn in zip(model.convs, model.batch_norms):
+        params += [conv.linear.weight, conv.bias, bn.weight, bn.bias]
+    sync_group = None
+    for bn in model.batch_norms:
+        if isinstance(bn, torch.nn.SyncBatchNorm) and model.training and dist.is_initialized() \
+                and dist.get_world_size(bn.process_group) > 1:
+            sync_group = bn.process_group if bn.process_group is not None else dist.group.WORLD
+    meta = {"structure": structure, "norm": norm, "batch_norms": list(model.batch_norms),
+            "training": model.training, "dropout": float(model.dropout), "sync_group": sync_group}
+    return FusedGCNEncode.apply(batch.node_features, meta, *params)

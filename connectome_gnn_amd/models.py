@@ -101,9 +101,13 @@ class _ConnectomeModel(nn.Module):
     _layer_cls = None
 
     def __init__(self, in_channels: int, hidden_dim: int = 64, num_classes: int = 2,
-                 num_layers: int = 3, dropout: float = 0.3):
+                 num_layers: int = 3, dropout: float = 0.3, *, impl: str = "auto"):
         super().__init__()
+        if impl not in ("auto", "fused", "layered"):
+            raise ValueError("impl must be 'auto', 'fused' or 'layered'")
         self.dropout = dropout
+        self.impl = impl              # execution path; not part of the reference API/state_dict
+        self.impl_used = None
         widths = [in_channels] + [hidden_dim] * num_layers
         self.convs = nn.ModuleList(self._layer_cls(a, b) for a, b in zip(widths, widths[1:]))
         self.batch_norms = nn.ModuleList(nn.BatchNorm1d(hidden_dim) for _ in range(num_layers))
@@ -120,6 +124,11 @@ class _ConnectomeModel(nn.Module):
         _require_device(batch.node_features, "batch.node_features")
         s = batch.structure()
         norm = self._norm(s)                  # once per forward pass, shared by all layers
+        if self._try_fused(batch, s):
+            from . import fused
+            self.impl_used = "fused"
+            return fused.encode(self, batch, s, norm)
+        self.impl_used = "layered"
         x = batch.node_features
         for conv, bn in zip(self.convs, self.batch_norms):
             x = conv(x, batch.edge_index, batch.edge_weight, structure=s, norm=norm)
@@ -130,6 +139,9 @@ class _ConnectomeModel(nn.Module):
     def forward(self, batch: ConnectomeBatch) -> torch.Tensor:
         """Class logits [B, num_classes]."""
         return self.classifier(self.encode(batch))
+
+    def _try_fused(self, batch, structure) -> bool:
+        return False
 
 
 class GCNConnectome(_ConnectomeModel):
@@ -142,6 +154,17 @@ class GCNConnectome(_ConnectomeModel):
 
     def _post(self, x):
         return F.relu(x)
+
+    def _try_fused(self, batch, structure) -> bool:
+        """Fused per-tile kernels (fused.py) when the shape is covered: hidden 64, <= 16 input
+        features, graphs of <= 384 nodes, block-diagonal edges."""
+        if self.impl == "layered":
+            return False
+        from . import fused
+        why = fused.eligible(self, batch, structure)
+        if why is not None and self.impl == "fused":
+            raise RuntimeError(f"impl='fused' requested but not applicable: {why}")
+        return why is None
 
 
 class GraphSAGEConnectome(_ConnectomeModel):

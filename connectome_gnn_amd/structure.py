@@ -13,6 +13,7 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Optional
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -56,6 +57,8 @@ class BatchStructure:
         self.rowptr_src = self.eid_src = self.col_src = None
         self._edge_index = None
         self._edge_weight = None
+        self._ptr_host = None
+        self._tiles = {}
 
     @staticmethod
     def build(batch) -> "BatchStructure":
@@ -90,8 +93,9 @@ class BatchStructure:
                 _lib.ptr(flags), _lib.ptr(ws), _lib.stream_ptr()), "cgnn_csr_build")
             s.gptr = batch.ptr.to(device=dev, dtype=torch.int32)
             f = flags.tolist()                      # one sync per batch, at build time only
-            sizes = (batch.ptr[1:] - batch.ptr[:-1])
-            s.max_nodes_per_graph = int(sizes.max()) if sizes.numel() else 0
+            s._ptr_host = batch.ptr.detach().cpu().numpy().astype(np.int64)
+            sizes = np.diff(s._ptr_host)
+            s.max_nodes_per_graph = int(sizes.max()) if sizes.size else 0
         if f[0]:
             # the reference would raise from scatter_add_/index (models.py:104,112)
             raise IndexError(f"{f[0]} edge(s) reference a node outside [0, {nn_})")
@@ -130,3 +134,34 @@ class BatchStructure:
                 _lib.ptr(self.rowptr_src), _lib.ptr(self.eid_src), _lib.ptr(n.den),
                 _lib.ptr(n.w_dst), _lib.ptr(n.coef_src_bwd), _lib.stream_ptr()), "cgnn_sage_norm")
         return n
+
+    # -- tiling for the fused per-tile kernels ----------------------------------------------
+    def tile_ptr(self, max_rows: int, num_workgroups: int) -> torch.Tensor:
+        """int32 [T+1] node offsets of tiles = runs of consecutive whole graphs with at most
+        ``max_rows`` nodes (LDS capacity).  The row cap is lowered when the batch is small so
+        that there are several tiles per persistent workgroup."""
+        key = (max_rows, num_workgroups)
+        if key not in self._tiles:
+            ptr = self._ptr_host
+            if self.max_nodes_per_graph > max_rows:
+                raise ValueError("a graph exceeds the tile capacity")
+            cap = min(max_rows, max(self.max_nodes_per_graph,
+                                    -(-self.num_nodes // (4 * max(num_workgroups, 1)))))
+            sizes = np.diff(ptr)
+            if sizes.size and (sizes == sizes[0]).all():
+                per = max(1, cap // max(int(sizes[0]), 1))
+                cuts = ptr[::per]
+                if cuts[-1] != ptr[-1]:
+                    cuts = np.append(cuts, ptr[-1])
+            else:
+                cuts, start = [0], 0
+                for g in range(sizes.size):            # greedy: close a tile before it overflows
+                    if ptr[g + 1] - start > cap:
+                        cuts.append(int(ptr[g]))
+                        start = int(ptr[g])
+                cuts.append(int(ptr[-1]))
+                cuts = np.asarray(cuts, dtype=np.int64)
+            rows = int(np.diff(cuts).max()) if cuts.size > 1 else 0
+            t = torch.from_numpy(cuts.astype(np.int32)).to(self.rowptr_dst.device)
+            self._tiles[key] = (t, rows)
+        return self._tiles[key]

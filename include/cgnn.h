@@ -139,6 +139,108 @@ int cgnn_pool_mean_fwd_f32(const float* X, int64_t ldx, const int32_t* gptr, flo
 int cgnn_pool_mean_bwd_f32(const float* dP, const int32_t* gptr, float* dX, int64_t lddx,
                            int32_t num_graphs, int32_t F, void* stream);
 
+
+/* =======================================================================================
+ * FUSED PER-TILE GCN PATH (hidden = 64, fp32): the MI355X-first form of models.py:84-114 +
+ * 203-216 and of its autograd backward.
+ *
+ * A *tile* is a run of consecutive whole graphs with at most CGNN_FUSED_MAX_ROWS nodes; its
+ * [rows x 64] fp32 feature tile (<= 96 KB) lives in the CU's 160 KB LDS for the whole layer.
+ * One persistent workgroup (8 waves) per CU walks the tiles.  Per layer, HBM sees exactly:
+ * read the previous layer's pre-BatchNorm output, read the CSR once, write this layer's
+ * pre-BatchNorm output.  BatchNorm-apply + ReLU + dropout are applied while the tile is being
+ * staged, the projection runs on the matrix cores out of LDS, BatchNorm statistics are
+ * accumulated (fp64) in the epilogue.  The batch-wide BatchNorm reduction is the only global
+ * barrier, hence one launch per layer.
+ *
+ *   forward  l=0 : T = X0 W0^T (MFMA) -> LDS ; Y0 = A_hat T + b                (fwd_first)
+ *   forward  l>0 : X = drop(relu(a*Yprev+b)) -> LDS ; Y = (A_hat X) W^T + b    (fwd)
+ *   backward l   : dY = BN'(dZ) -> LDS ; dT = A_hat^T dY ; dW += dT^T X ;
+ *                  dZprev = (dT W) * drop' * relu'                              (bwd, bwd_first)
+ *
+ * `bn` blocks are float[4*64]: a = gamma*invstd | b = beta - mean*a | mean | invstd.
+ * `bwc` blocks are float[2*64]: c1 = sum(dZ)/N | c2 = sum(dZ*xhat)/N.
+ * Dropout keep-bits are produced by a counter-based hash of (seed, element) when a layer's
+ * output is first consumed and stored as one byte per (node, 4-column chunk) in `mask`
+ * ([Nn*16] bytes); mask == NULL or p == 0 means no dropout.
+ * Per-workgroup partial sums go to `*_slab` arrays with cgnn_fused_grid() rows and are
+ * combined by cgnn_slab_reduce_* / cgnn_bn_reduce in a fixed order (deterministic, no atomics).
+ * ===================================================================================== */
+#define CGNN_FUSED_HIDDEN   64
+#define CGNN_FUSED_MAX_ROWS 384
+#define CGNN_FUSED_MAX_F0   16
+
+/* HOST-side parameter block (plain device pointers) describing the tiling of one batch. */
+typedef struct cgnn_tiles {
+  int64_t num_nodes;
+  int32_t num_tiles;
+  int32_t max_tile_rows;        /* <= CGNN_FUSED_MAX_ROWS */
+  const int32_t* tile_ptr;      /* [num_tiles+1] node offsets; tiles are unions of whole graphs */
+  const int32_t* rowptr_dst; const int32_t* col_dst; const float* coef_dst;
+  const int32_t* rowptr_src; const int32_t* col_src; const float* coef_src;
+  const float* selfc;           /* [num_nodes] dis^2 */
+} cgnn_tiles;
+
+/* Number of persistent workgroups every fused kernel launches (= rows of every slab). */
+int cgnn_fused_grid(void);
+
+/* Layer 0 forward.  X0 [Nn,F0] (F0 <= 16), W0 [64,F0], bias [64] -> Y [Nn,64];
+ * stat_slab [grid][128] fp64 (sum(y) | sum(y^2)) or NULL (eval). */
+int cgnn_gcn_fused_fwd_first(const cgnn_tiles* t, const float* X0, int32_t F0, const float* W0,
+                             const float* bias, float* Y, double* stat_slab, void* stream);
+
+/* Layer l>0 forward.  Yprev [Nn,64] + bn_prev -> X on the fly; W [64,64]; mask_out nullable. */
+int cgnn_gcn_fused_fwd(const cgnn_tiles* t, const float* Yprev, const float* bn_prev,
+                       float p_drop, uint64_t seed, uint8_t* mask_out, const float* W,
+                       const float* bias, float* Y, double* stat_slab, void* stream);
+
+/* slab [rows][width] fp64 -> sums [width] fp64 (fixed-order tree). */
+int cgnn_bn_reduce(const double* slab, int32_t rows, int32_t width, double* sums, void* stream);
+
+/* BatchNorm1d forward coefficients (models.py:191-193 semantics: biased batch variance,
+ * eps, momentum; running_var gets the unbiased variance).  training != 0: from sums
+ * (sum(y)|sum(y^2), [128]) over `count` rows, and running stats are updated in place;
+ * training == 0: from running stats.  bn_out float[4*64]. */
+int cgnn_bn_finalize(const double* sums, double count, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, float momentum, float eps,
+                     int32_t training, float* bn_out, void* stream);
+
+/* Readout: P[g,:] = mean over nodes of drop(relu(a*Y+b)) (models.py:209-211,57-59). */
+int cgnn_gcn_fused_pool_fwd(const float* Y, const float* bn, float p_drop, uint64_t seed,
+                            uint8_t* mask_out, const int32_t* gptr, int32_t num_graphs, float* P,
+                            void* stream);
+
+/* Backward of the readout through dropout/ReLU: dZ = dP[g]/(n_g+1e-8) * drop' * relu';
+ * also the BatchNorm-backward sums of the last layer: s_slab [grid][128] = sum dZ | sum dZ*xhat. */
+int cgnn_gcn_fused_pool_bwd(const float* dP, const float* Y, const float* bn, float p_drop,
+                            const uint8_t* mask, const int32_t* gptr, int32_t num_graphs,
+                            float* dZ, double* s_slab, void* stream);
+
+/* BatchNorm backward coefficients: dgamma = sum dZ*xhat, dbeta = sum dZ, bwc = [c1|c2]. */
+int cgnn_bn_bwd_finalize(const double* sums, double count, float* dgamma, float* dbeta,
+                         float* bwc, void* stream);
+
+/* Layer l>0 backward.  Inputs: dZ (grad wrt BN output of layer l), Y (its pre-BN output), bn,
+ * bwc; previous layer's Yprev/bn_prev/mask_prev (to rebuild X_l and apply relu'/drop').
+ * Outputs: dZprev [Nn,64]; s_slab_prev [grid][128]; dW_slab [grid][64*64]; db_slab [grid][64]. */
+int cgnn_gcn_fused_bwd(const cgnn_tiles* t, const float* dZ, const float* Y, const float* bn,
+                       const float* bwc, const float* Yprev, const float* bn_prev, float p_drop,
+                       const uint8_t* mask_prev, const float* W, float* dZprev,
+                       double* s_slab_prev, float* dW_slab, double* db_slab, void* stream);
+
+/* Layer 0 backward: dW0 = dT^T X0 only.  dW_slab [grid][64*16] (columns >= F0 are zero). */
+int cgnn_gcn_fused_bwd_first(const cgnn_tiles* t, const float* dZ, const float* Y,
+                             const float* bn, const float* bwc, const float* X0, int32_t F0,
+                             float* dW_slab, double* db_slab, void* stream);
+
+/* Fixed-order combination of per-workgroup partials (fp64 accumulate):
+ * f32 slab [rows][width] -> out[r*ld_out + c] for width = out_rows*out_cols (take the first
+ * `take_cols` of every `out_cols` columns); f64 slab [rows][width] -> f32 out [width]. */
+int cgnn_slab_reduce_f32(const float* slab, int32_t rows, int32_t out_rows, int32_t out_cols,
+                         int32_t take_cols, float* out, int32_t ld_out, void* stream);
+int cgnn_slab_reduce_f64(const double* slab, int32_t rows, int32_t width, float* out,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif
