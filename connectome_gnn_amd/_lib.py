@@ -26,10 +26,10 @@ P, I32, I64, U64, F32, F64 = c_void_p, c_int32, c_int64, c_uint64, c_float, c_do
 class CgnnTiles(ctypes.Structure):
     """Mirror of `struct cgnn_tiles` (include/cgnn.h): host block of device pointers."""
     _fields_ = [("num_nodes", c_int64), ("num_tiles", c_int32), ("max_tile_rows", c_int32),
-                ("tile_ptr", c_void_p),
-                ("rowptr_dst", c_void_p), ("col_dst", c_void_p), ("coef_dst", c_void_p),
-                ("rowptr_src", c_void_p), ("col_src", c_void_p), ("coef_src", c_void_p),
-                ("selfc", c_void_p)]
+                ("tile_ptr", c_void_p), ("tile_blk", c_void_p),
+                ("blk_off_dst", c_void_p), ("ent_dst", c_void_p),
+                ("blk_off_src", c_void_p), ("ent_src", c_void_p),
+                ("dis", c_void_p)]
 
 
 TP = ctypes.POINTER(CgnnTiles)
@@ -52,6 +52,10 @@ PROTOTYPES = {
     "cgnn_pool_mean_fwd_f32": (c_int, [P, I64, P, P, I32, I32, P]),
     "cgnn_pool_mean_bwd_f32": (c_int, [P, P, P, I64, I32, I32, P]),
     # fused per-tile GCN path
+    "cgnn_bell_plan": (c_int, [P, P, I32, I32, P, P, P, P]),
+    "cgnn_bell_fill": (c_int, [P, P, I32, P, P, P, P, P, P, P]),
+    "cgnn_gather_f32": (c_int, [P, P, I64, P, P]),
+    "cgnn_gcn_dis": (c_int, [P, P, I64, P, P]),
     "cgnn_fused_grid": (c_int, []),
     "cgnn_gcn_fused_fwd_first": (c_int, [TP, P, I32, P, P, P, P, P]),
     "cgnn_gcn_fused_fwd": (c_int, [TP, P, P, F32, U64, P, P, P, P, P, P]),

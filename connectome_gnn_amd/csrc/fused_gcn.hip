@@ -79,52 +79,72 @@ __device__ __forceinline__ float4 act4(const float4& y, const float4& a, const f
 }
 
 // ------------------------------------------------------------------------------------------
-// 4 rows per wave (16 lanes x float4 each): acc = sum_slots coef * tile[col - base] (+ self).
-// `row` is this lane-group's local row, `valid` whether it exists.
+// Aggregate one 16-row block out of the LDS tile.  Lane (q, j): rows 4q..4q+3 of the block,
+// columns 4j..4j+3.  `mp` = the block's blocked-ELL entries (8 uint4 = 16 entries per step);
+// the lane group reads its 4 entries of a step as two 16-byte loads (group-uniform address)
+// and is always one step ahead of the LDS reads.  Branch-free: padding entries have weight 0.
 // ------------------------------------------------------------------------------------------
-#define CGNN_AGG_STEP(S)                                                                        \
-  {                                                                                             \
-    const int c_ = __builtin_amdgcn_update_dpp(0, mycol, 0x150 + (S), 0xf, 0xf, false);         \
-    const float w_ = __int_as_float(                                                            \
-        __builtin_amdgcn_update_dpp(0, __float_as_int(myw), 0x150 + (S), 0xf, 0xf, false));     \
-    if ((S) < cnt) {                                                                            \
-      const float4 v_ = ld4(tile + c_ * HID + 4 * j);                                           \
-      acc.x = fmaf(w_, v_.x, acc.x); acc.y = fmaf(w_, v_.y, acc.y);                             \
-      acc.z = fmaf(w_, v_.z, acc.z); acc.w = fmaf(w_, v_.w, acc.w);                             \
-    }                                                                                           \
-  }
+__device__ __forceinline__ void fma4(float4& acc, uint32_t wbits, const float4& v) {
+  const float w = __uint_as_float(wbits);
+  acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y);
+  acc.z = fmaf(w, v.z, acc.z); acc.w = fmaf(w, v.w, acc.w);
+}
 
-__device__ __forceinline__ float4 agg_rows4(const float* __restrict__ tile, int base, int row,
-                                            bool valid, int j, const int32_t* __restrict__ rowptr,
-                                            const int32_t* __restrict__ col,
-                                            const float* __restrict__ coef,
-                                            const float* __restrict__ selfc) {
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  int beg = 0, end = 0;
-  if (valid) {
-    beg = rowptr[base + row];
-    end = rowptr[base + row + 1];
+__device__ __forceinline__ float4 ldsrow(const char* tb, uint32_t off) {
+  return *reinterpret_cast<const float4*>(tb + off);
+}
+
+// Per-wave metadata pipeline: a block's entries (<= META_STEPS steps = 3 KB) are fetched with
+// three coalesced 1 KB wave loads issued one block ahead (in flight during the previous
+// block's MFMAs), committed to the wave's LDS buffer (the staging buffer, dead at that point)
+// and read from there by the aggregation loop.  Steps beyond META_STEPS (very high degree)
+// come straight from global memory.
+constexpr int META_STEPS = 24;
+struct MetaRegs { uint4 r0, r1, r2; };
+
+__device__ __forceinline__ MetaRegs meta_issue(const uint4* __restrict__ mp, int width, int lane) {
+  const int nq = min(width, META_STEPS) * 8;      // uint4 count
+  MetaRegs m;
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  m.r0 = lane < nq ? mp[lane] : z;
+  m.r1 = lane + 64 < nq ? mp[lane + 64] : z;
+  m.r2 = lane + 128 < nq ? mp[lane + 128] : z;
+  return m;
+}
+
+__device__ __forceinline__ void meta_commit(uint4* mbuf, const MetaRegs& m, int lane) {
+  mbuf[lane] = m.r0;
+  mbuf[lane + 64] = m.r1;
+  mbuf[lane + 128] = m.r2;
+}
+
+__device__ __forceinline__ void agg_block(const float* __restrict__ tile, const uint4* mbuf,
+                                          const uint4* __restrict__ mp, int width, int q, int j,
+                                          float4 (&acc)[4]) {
+  const char* tb = reinterpret_cast<const char*>(tile) + 16 * j;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const uint4* p = mbuf + 2 * q;
+  const int wl = min(width, META_STEPS);
+  uint4 a0 = p[0], a1 = p[1];
+#pragma unroll 2
+  for (int s = 1; s < wl; ++s) {
+    const uint4 n0 = p[8 * s], n1 = p[8 * s + 1];
+    fma4(acc[0], a0.y, ldsrow(tb, a0.x)); fma4(acc[1], a0.w, ldsrow(tb, a0.z));
+    fma4(acc[2], a1.y, ldsrow(tb, a1.x)); fma4(acc[3], a1.w, ldsrow(tb, a1.z));
+    a0 = n0; a1 = n1;
   }
-  for (int s0 = beg; __any(s0 < end); s0 += 16) {
-    const int cnt = end - s0;                 // may be <= 0 for finished groups
-    int mycol = 0;
-    float myw = 0.f;
-    if (j < cnt) {
-      mycol = col[s0 + j] - base;
-      myw = coef[s0 + j];
-    }
-    CGNN_AGG_STEP(0) CGNN_AGG_STEP(1) CGNN_AGG_STEP(2) CGNN_AGG_STEP(3)
-    CGNN_AGG_STEP(4) CGNN_AGG_STEP(5) CGNN_AGG_STEP(6) CGNN_AGG_STEP(7)
-    CGNN_AGG_STEP(8) CGNN_AGG_STEP(9) CGNN_AGG_STEP(10) CGNN_AGG_STEP(11)
-    CGNN_AGG_STEP(12) CGNN_AGG_STEP(13) CGNN_AGG_STEP(14) CGNN_AGG_STEP(15)
+  fma4(acc[0], a0.y, ldsrow(tb, a0.x)); fma4(acc[1], a0.w, ldsrow(tb, a0.z));
+  fma4(acc[2], a1.y, ldsrow(tb, a1.x)); fma4(acc[3], a1.w, ldsrow(tb, a1.z));
+  for (int s = wl; s < width; ++s) {              // overflow steps: from global
+    a0 = mp[8 * s + 2 * q]; a1 = mp[8 * s + 2 * q + 1];
+    fma4(acc[0], a0.y, ldsrow(tb, a0.x)); fma4(acc[1], a0.w, ldsrow(tb, a0.z));
+    fma4(acc[2], a1.y, ldsrow(tb, a1.x)); fma4(acc[3], a1.w, ldsrow(tb, a1.z));
   }
-  if (valid && selfc) {                       // the appended self-loop, last (models.py:98-100)
-    const float sc = selfc[base + row];
-    const float4 v = ld4(tile + row * HID + 4 * j);
-    acc.x = fmaf(sc, v.x, acc.x); acc.y = fmaf(sc, v.y, acc.y);
-    acc.z = fmaf(sc, v.z, acc.z); acc.w = fmaf(sc, v.w, acc.w);
-  }
-  return acc;
+}
+
+__device__ __forceinline__ float4 scale4(const float4& v, float s) {
+  return make_float4(v.x * s, v.y * s, v.z * s, v.w * s);
 }
 
 // Reduce per-lane fp64 column partials (lane (q,j): columns 4j..4j+3) over the workgroup and
@@ -165,8 +185,10 @@ __global__ void __launch_bounds__(NTHR) k_gcn_fwd(
     const float* __restrict__ bias, float* __restrict__ Y, double* __restrict__ stat_slab) {
   __shared__ __attribute__((aligned(16))) float tile[MAXR * HID];
   __shared__ __attribute__((aligned(16))) float stg_all[NWAVE * STG_FLOATS];
+  __shared__ float disl[MAXR];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, j = lane & 15;
   float* stg = stg_all + wave * STG_FLOATS;
+  const uint4* ent = static_cast<const uint4*>(t.ent_dst);
 
   // B-operand fragments of the projection, resident in registers for the whole kernel.
   //   generic: B[k][col] = W[col][k], lane (kk=q, jj=j), tile tj <-> col 4j+tj, k = 16q + s
@@ -202,8 +224,19 @@ __global__ void __launch_bounds__(NTHR) k_gcn_fwd(
     const int base = t.tile_ptr[tid];
     const int n = t.tile_ptr[tid + 1] - base;
     const int nblk = (n + 15) >> 4;
+    const int gb0 = t.tile_blk[tid];
+    // metadata of this wave's first block: in flight during phase A
+    int off0 = 0, width = 0;
+    MetaRegs pre;
+    if (wave < nblk) {
+      off0 = cgnn_uniform(t.blk_off_dst[gb0 + wave]);
+      width = (cgnn_uniform(t.blk_off_dst[gb0 + wave + 1]) - off0) >> 4;
+      pre = meta_issue(ent + (off0 >> 1), width, lane);
+    }
 
     // ---------------------------------------------------------------- phase A: fill the tile
+    // (rows are pre-scaled by dis[row]: A_hat X = dis * (A_w + I)(dis * X))
+    for (int r = threadIdx.x; r < nblk * 16; r += NTHR) disl[r] = r < n ? t.dis[base + r] : 0.f;
     if (FIRST) {
       // T = X0 W0^T on the matrix core, written straight into the tile.
       for (int b = wave; b < nblk; b += NWAVE) {
@@ -221,9 +254,12 @@ __global__ void __launch_bounds__(NTHR) k_gcn_fwd(
           }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          st4(tile + (16 * b + 4 * q + r) * HID + 4 * j,
-              make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]));
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * b + 4 * q + r;
+          const float dv = row < n ? t.dis[base + row] : 0.f;
+          st4(tile + row * HID + 4 * j,
+              make_float4(acc[0][r] * dv, acc[1][r] * dv, acc[2][r] * dv, acc[3][r] * dv));
+        }
       }
     } else {
       for (int idx = threadIdx.x; idx < nblk * 256; idx += NTHR) {
@@ -237,7 +273,7 @@ __global__ void __launch_bounds__(NTHR) k_gcn_fwd(
             if (mask_out) mask_out[(int64_t)(base + row) * 16 + j] = (uint8_t)keep;
           }
           float4 f;
-          x = act4(y, pa, pb, keep, drop.scale, f);
+          x = scale4(act4(y, pa, pb, keep, drop.scale, f), t.dis[base + row]);
         }
         st4(tile + row * HID + 4 * j, x);
       }
@@ -247,14 +283,28 @@ __global__ void __launch_bounds__(NTHR) k_gcn_fwd(
     // ------------------------------------------------- phase B: aggregate (+ project) blocks
     for (int b = wave; b < nblk; b += NWAVE) {
       f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+      uint4* mbuf = reinterpret_cast<uint4*>(stg);
+      meta_commit(mbuf, pre, lane);
+      int off1 = 0, width1 = 0;
+      if (b + NWAVE < nblk) {
+        off1 = cgnn_uniform(t.blk_off_dst[gb0 + b + NWAVE]);
+        width1 = (cgnn_uniform(t.blk_off_dst[gb0 + b + NWAVE + 1]) - off1) >> 4;
+      }
+      __builtin_amdgcn_wave_barrier();
+      float4 ag[4];
+      agg_block(tile, mbuf, ent + (off0 >> 1), width, q, j, ag);
+      __builtin_amdgcn_wave_barrier();
+      if (b + NWAVE < nblk) pre = meta_issue(ent + (off1 >> 1), width1, lane);
+      const int cur_off = off0;
+      (void)cur_off;
+      off0 = off1; width = width1;
       if (FIRST) {
-        // tile already holds T: Y = A_hat T + b, block rows come out in registers directly.
+        // tile already holds dis*T: Y = dis * (A_w + I)(dis*T) + b, straight from registers.
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-          const int row = 16 * b + 4 * it + q;
-          const float4 a = agg_rows4(tile, base, row, row < n, j, t.rowptr_dst, t.col_dst,
-                                     t.coef_dst, t.selfc);
+          const int row = 16 * b + 4 * q + it;
           if (row < n) {
+            const float4 a = scale4(ag[it], disl[row]);
             const float4 y = make_float4(a.x + bias4.x, a.y + bias4.y, a.z + bias4.z, a.w + bias4.w);
             st4(Y + (int64_t)(base + row) * HID + 4 * j, y);
             s1[0] += y.x; s1[1] += y.y; s1[2] += y.z; s1[3] += y.w;
@@ -265,12 +315,8 @@ __global__ void __launch_bounds__(NTHR) k_gcn_fwd(
         continue;
       }
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int row = 16 * b + 4 * it + q;
-        const float4 a = agg_rows4(tile, base, row, row < n, j, t.rowptr_dst, t.col_dst,
-                                   t.coef_dst, t.selfc);
-        st4(stg + (4 * it + q) * SLD + 4 * j, a);
-      }
+      for (int it = 0; it < 4; ++it)
+        st4(stg + (4 * q + it) * SLD + 4 * j, scale4(ag[it], disl[16 * b + 4 * q + it]));
       __builtin_amdgcn_wave_barrier();
       // A fragments: lane (i=j, kk=q) holds P[row j][k = 16q + s], s = 0..15
       float af[16];
@@ -319,8 +365,10 @@ __global__ void __launch_bounds__(NTHR) k_gcn_bwd(
   __shared__ __attribute__((aligned(16))) float tile[MAXR * HID];
   __shared__ __attribute__((aligned(16))) float stg_all[NWAVE * STG_FLOATS];
   __shared__ __attribute__((aligned(16))) float Wl[FIRST ? 4 : HID * HID];
+  __shared__ float disl[MAXR];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, j = lane & 15;
   float* stg = stg_all + wave * STG_FLOATS;
+  const uint4* ent = static_cast<const uint4*>(t.ent_src);
 
   if (!FIRST) {
     for (int i = threadIdx.x; i < HID * HID / 4; i += NTHR) st4(Wl + 4 * i, ld4(W + 4 * i));
@@ -346,8 +394,17 @@ __global__ void __launch_bounds__(NTHR) k_gcn_bwd(
     const int base = t.tile_ptr[tid];
     const int n = t.tile_ptr[tid + 1] - base;
     const int nblk = (n + 15) >> 4;
+    const int gb0 = t.tile_blk[tid];
+    int off0 = 0, width = 0;
+    MetaRegs pre;
+    if (wave < nblk) {
+      off0 = cgnn_uniform(t.blk_off_src[gb0 + wave]);
+      width = (cgnn_uniform(t.blk_off_src[gb0 + wave + 1]) - off0) >> 4;
+      pre = meta_issue(ent + (off0 >> 1), width, lane);
+    }
 
-    // ------------------------------------------- phase A: dY = BatchNorm'(dZ) into the tile
+    // --------------------------- phase A: dis * dY, dY = BatchNorm'(dZ), into the tile
+    for (int r = threadIdx.x; r < nblk * 16; r += NTHR) disl[r] = r < n ? t.dis[base + r] : 0.f;
     for (int idx = threadIdx.x; idx < nblk * 256; idx += NTHR) {
       const int row = idx >> 4;
       float4 dy = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -359,6 +416,7 @@ __global__ void __launch_bounds__(NTHR) k_gcn_bwd(
         dy.z = ca.z * (dz.z - c1.z - (y.z - cmean.z) * cis.z * c2.z);
         dy.w = ca.w * (dz.w - c1.w - (y.w - cmean.w) * cis.w * c2.w);
         db[0] += dy.x; db[1] += dy.y; db[2] += dy.z; db[3] += dy.w;
+        dy = scale4(dy, t.dis[base + row]);
       }
       st4(tile + row * HID + 4 * j, dy);
     }
@@ -366,12 +424,23 @@ __global__ void __launch_bounds__(NTHR) k_gcn_bwd(
 
     // --------------------- phase B: dT = A_hat^T dY per block; dW += dT^T X; dZprev = ...
     for (int b = wave; b < nblk; b += NWAVE) {
+      {
+        uint4* mbuf = reinterpret_cast<uint4*>(stg);
+        meta_commit(mbuf, pre, lane);
+        int off1 = 0, width1 = 0;
+        if (b + NWAVE < nblk) {
+          off1 = cgnn_uniform(t.blk_off_src[gb0 + b + NWAVE]);
+          width1 = (cgnn_uniform(t.blk_off_src[gb0 + b + NWAVE + 1]) - off1) >> 4;
+        }
+        __builtin_amdgcn_wave_barrier();
+        float4 ag[4];
+        agg_block(tile, mbuf, ent + (off0 >> 1), width, q, j, ag);
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int row = 16 * b + 4 * it + q;
-        const float4 a = agg_rows4(tile, base, row, row < n, j, t.rowptr_src, t.col_src,
-                                   t.coef_src, t.selfc);
-        st4(stg + (4 * it + q) * SLD + 4 * j, a);
+        for (int it = 0; it < 4; ++it)
+          st4(stg + (4 * q + it) * SLD + 4 * j, scale4(ag[it], disl[16 * b + 4 * q + it]));
+        if (b + NWAVE < nblk) pre = meta_issue(ent + (off1 >> 1), width1, lane);
+        off0 = off1; width = width1;
       }
       __builtin_amdgcn_wave_barrier();
 
@@ -392,26 +461,28 @@ __global__ void __launch_bounds__(NTHR) k_gcn_bwd(
         continue;
       }
 
-      // previous layer's block: rows 4q+r, columns 4j..4j+3 -> X (B operand of dW) and the
-      // relu'/dropout' factor + xhat for the epilogue.
-      float4 xb[4], fac[4], xh[4];
+      // previous layer's block: rows 4q+r, columns 4j..4j+3.  Only the raw pre-BatchNorm values
+      // and the keep bits stay live; X (B operand of dW) and relu'/dropout'/xhat (epilogue) are
+      // re-derived from them where needed (register pressure: dW holds 64 accumulators).
+      float4 yp[4];
+      uint32_t keeps = 0u;                      // byte r: keep bits of row 4q+r (0 = no such row)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = 16 * b + 4 * q + r;
-        xb[r] = fac[r] = xh[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        yp[r] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row < n) {
-          const float4 y = ld4(Xprev + (int64_t)(base + row) * HID + 4 * j);
-          uint32_t keep = 0xFu;
-          if (use_drop) keep = mask_prev[(int64_t)(base + row) * 16 + j];
-          xb[r] = act4(y, pa, pb, keep, drop.scale, fac[r]);
-          xh[r] = make_float4((y.x - pmean.x) * pis.x, (y.y - pmean.y) * pis.y,
-                              (y.z - pmean.z) * pis.z, (y.w - pmean.w) * pis.w);
+          yp[r] = ld4(Xprev + (int64_t)(base + row) * HID + 4 * j);
+          uint32_t kb = 0xFu;
+          if (use_drop) kb = mask_prev[(int64_t)(base + row) * 16 + j];
+          keeps |= kb << (8 * r);
         }
       }
       // dW[o][col] += sum_m dT[m][o] X[m][col]; k <-> m = 4q + s
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const float bx[4] = {xb[s].x, xb[s].y, xb[s].z, xb[s].w};
+        float4 f;
+        const float4 x = act4(yp[s], pa, pb, (keeps >> (8 * s)) & 0xFu, drop.scale, f);
+        const float bx[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti) {
           const float av = stg[(4 * q + s) * SLD + 16 * ti + j];
@@ -441,12 +512,15 @@ __global__ void __launch_bounds__(NTHR) k_gcn_bwd(
       for (int r = 0; r < 4; ++r) {
         const int row = 16 * b + 4 * q + r;
         if (row < n) {
-          const float4 dzp = make_float4(dx[0][r] * fac[r].x, dx[1][r] * fac[r].y,
-                                         dx[2][r] * fac[r].z, dx[3][r] * fac[r].w);
+          float4 f;
+          act4(yp[r], pa, pb, (keeps >> (8 * r)) & 0xFu, drop.scale, f);
+          const float4 dzp = make_float4(dx[0][r] * f.x, dx[1][r] * f.y, dx[2][r] * f.z, dx[3][r] * f.w);
           st4(dZprev + (int64_t)(base + row) * HID + 4 * j, dzp);
           s1[0] += dzp.x; s1[1] += dzp.y; s1[2] += dzp.z; s1[3] += dzp.w;
-          s2[0] += (double)dzp.x * xh[r].x; s2[1] += (double)dzp.y * xh[r].y;
-          s2[2] += (double)dzp.z * xh[r].z; s2[3] += (double)dzp.w * xh[r].w;
+          s2[0] += (double)dzp.x * ((yp[r].x - pmean.x) * pis.x);
+          s2[1] += (double)dzp.y * ((yp[r].y - pmean.y) * pis.y);
+          s2[2] += (double)dzp.z * ((yp[r].z - pmean.z) * pis.z);
+          s2[3] += (double)dzp.w * ((yp[r].w - pmean.w) * pis.w);
         }
       }
     }
@@ -688,7 +762,8 @@ DropCfg make_drop(float p, uint64_t seed, int* use_drop) {
 
 bool tiles_ok(const cgnn_tiles* t) {
   return t && t->num_tiles >= 0 && t->num_nodes >= 0 && t->max_tile_rows <= CGNN_FUSED_MAX_ROWS &&
-         (t->num_tiles == 0 || (t->tile_ptr && t->rowptr_dst && t->rowptr_src && t->selfc));
+         (t->num_tiles == 0 || (t->tile_ptr && t->tile_blk && t->blk_off_dst && t->ent_dst &&
+                                t->blk_off_src && t->ent_src && t->dis));
 }
 
 }  // namespace

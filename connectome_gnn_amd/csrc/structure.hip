@@ -191,6 +191,78 @@ __global__ void k_sage_coef_bwd(const int64_t* __restrict__ dst, const float* __
   coef_src_bwd[s] = w[e] / den[dst[e]];
 }
 
+
+// ---------------------------------------------------------------- blocked-ELL (fused path)
+// One thread per 16-row block: width = max degree of its rows + 1 (the self-loop entry).
+__global__ void k_bell_width(const int32_t* __restrict__ tile_ptr,
+                             const int32_t* __restrict__ tile_blk, int num_tiles,
+                             const int32_t* __restrict__ rowptr, int32_t* __restrict__ counts) {
+  const int t = blockIdx.x;
+  if (t >= num_tiles) return;
+  const int base = tile_ptr[t], n = tile_ptr[t + 1] - base;
+  const int b0 = tile_blk[t], nb = tile_blk[t + 1] - b0;
+  for (int lb = threadIdx.x; lb < nb; lb += blockDim.x) {
+    int w = 0;
+    for (int i = 0; i < 16; ++i) {
+      const int r = 16 * lb + i;
+      if (r < n) w = max(w, rowptr[base + r + 1] - rowptr[base + r]);
+    }
+    counts[b0 + lb] = (w + 1) * 16;             // entries of this block
+  }
+}
+
+// One 16-lane group per block row-set: lane i of the group owns row i of the block and writes
+// entry (s, i) for every step s -> 128-byte coalesced lines per step.
+__global__ void __launch_bounds__(256) k_bell_fill(
+    const int32_t* __restrict__ tile_ptr, const int32_t* __restrict__ tile_blk, int num_tiles,
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+    const int32_t* __restrict__ eid, const float* __restrict__ w,
+    const int32_t* __restrict__ blk_off, uint2* __restrict__ ent) {
+  const int t = blockIdx.x;
+  if (t >= num_tiles) return;
+  const int base = tile_ptr[t], n = tile_ptr[t + 1] - base;
+  const int b0 = tile_blk[t], nb = tile_blk[t + 1] - b0;
+  const int i = threadIdx.x & 15;
+  for (int lb = threadIdx.x >> 4; lb < nb; lb += blockDim.x >> 4) {
+    const int off = blk_off[b0 + lb];
+    const int width = (blk_off[b0 + lb + 1] - off) >> 4;
+    const int r = 16 * lb + i;
+    int beg = 0, deg = -1;                      // deg = -1: row does not exist -> all padding
+    if (r < n) {
+      beg = rowptr[base + r];
+      deg = rowptr[base + r + 1] - beg;
+    }
+    for (int s = 0; s < width; ++s) {
+      uint2 e = make_uint2(0u, 0u);             // padding: row 0 of the tile, weight +0
+      if (s < deg) {
+        e.x = (uint32_t)(col[beg + s] - base) * 256u;
+        e.y = __float_as_uint(w[eid[beg + s]]);
+      } else if (s == deg) {
+        e.x = (uint32_t)r * 256u;               // the appended self-loop, weight 1, last
+        e.y = __float_as_uint(1.0f);
+      }
+      ent[(int64_t)off + 16 * s + i] = e;
+    }
+  }
+}
+
+__global__ void k_gather_f32(const float* __restrict__ src, const int32_t* __restrict__ idx,
+                             int64_t n, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = src[idx[i]];
+}
+
+// dis from edge weights already in src-CSR slot order (contiguous per row, COO order).
+__global__ void k_gcn_dis(const float* __restrict__ w_src, const int32_t* __restrict__ rowptr_src,
+                          int64_t nn, float* __restrict__ dis) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nn) return;
+  float deg = 0.f;
+  for (int s = rowptr_src[i]; s < rowptr_src[i + 1]; ++s) deg += w_src[s];
+  deg += 1.0f;
+  dis[i] = 1.0f / sqrtf(deg + 1e-8f);
+}
+
 inline unsigned blocks_for(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
 // in-place exclusive scan of counts[0..n) (n = Nn+1, counts[Nn] = 0) using tile_sums scratch
@@ -302,6 +374,50 @@ int cgnn_sage_norm(const int64_t* edge_index, const float* w, int64_t nn, int64_
                                                          coef_src_bwd);
     CGNN_CHECK_LAUNCH();
   }
+  return CGNN_OK;
+}
+
+int cgnn_bell_plan(const int32_t* tile_ptr, const int32_t* tile_blk, int32_t num_tiles,
+                   int32_t num_blocks, const int32_t* rowptr, int32_t* blk_off, int32_t* scratch,
+                   void* stream) {
+  if (num_tiles < 0 || num_blocks < 0 || !blk_off || !scratch) return CGNN_EINVAL;
+  if (num_tiles > 0 && (!tile_ptr || !tile_blk || !rowptr)) return CGNN_EINVAL;
+  hipStream_t st = cgnn_stream(stream);
+  k_zero_i32<<<blocks_for(num_blocks + 1, 256), 256, 0, st>>>(blk_off, num_blocks + 1);
+  if (num_tiles > 0) k_bell_width<<<num_tiles, 64, 0, st>>>(tile_ptr, tile_blk, num_tiles, rowptr, blk_off);
+  CGNN_CHECK_LAUNCH();
+  return scan_i32(blk_off, (int64_t)num_blocks + 1, scratch, st);
+}
+
+int cgnn_bell_fill(const int32_t* tile_ptr, const int32_t* tile_blk, int32_t num_tiles,
+                   const int32_t* rowptr, const int32_t* col, const int32_t* eid,
+                   const float* edge_weight, const int32_t* blk_off, void* entries, void* stream) {
+  if (num_tiles < 0) return CGNN_EINVAL;
+  if (num_tiles == 0) return CGNN_OK;
+  if (!tile_ptr || !tile_blk || !rowptr || !blk_off || !entries) return CGNN_EINVAL;
+  k_bell_fill<<<num_tiles, 256, 0, cgnn_stream(stream)>>>(tile_ptr, tile_blk, num_tiles, rowptr, col,
+                                                         eid, edge_weight, blk_off,
+                                                         static_cast<uint2*>(entries));
+  CGNN_CHECK_LAUNCH();
+  return CGNN_OK;
+}
+
+int cgnn_gather_f32(const float* src, const int32_t* idx, int64_t n, float* out, void* stream) {
+  if (n < 0) return CGNN_EINVAL;
+  if (n == 0) return CGNN_OK;
+  if (!src || !idx || !out) return CGNN_EINVAL;
+  k_gather_f32<<<blocks_for(n, 256), 256, 0, cgnn_stream(stream)>>>(src, idx, n, out);
+  CGNN_CHECK_LAUNCH();
+  return CGNN_OK;
+}
+
+int cgnn_gcn_dis(const float* w_src, const int32_t* rowptr_src, int64_t nn, float* dis,
+                 void* stream) {
+  if (nn < 0) return CGNN_EINVAL;
+  if (nn == 0) return CGNN_OK;
+  if (!rowptr_src || !dis) return CGNN_EINVAL;
+  k_gcn_dis<<<blocks_for(nn, 256), 256, 0, cgnn_stream(stream)>>>(w_src, rowptr_src, nn, dis);
+  CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }
 

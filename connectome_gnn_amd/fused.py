@@ -19,7 +19,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
-from .structure import BatchStructure, GcnNorm
+from .structure import BatchStructure
 
 HID = 64
 MAX_ROWS = 384
@@ -44,22 +44,21 @@ def eligible(model, batch, structure: BatchStructure) -> Optional[str]:
     return None
 
 
-def _tiles_struct(s: BatchStructure, norm: GcnNorm, grid: int):
-    tptr, rows = s.tile_ptr(MAX_ROWS, grid)
+def _tiles_struct(s: BatchStructure, meta, dis: torch.Tensor):
     t = _lib.CgnnTiles()
     t.num_nodes = s.num_nodes
-    t.num_tiles = int(tptr.numel()) - 1
-    t.max_tile_rows = rows
-    t.tile_ptr = tptr.data_ptr()
-    t.rowptr_dst, t.col_dst, t.coef_dst = s.rowptr_dst.data_ptr(), s.col_dst.data_ptr(), norm.coef_dst.data_ptr()
-    t.rowptr_src, t.col_src, t.coef_src = s.rowptr_src.data_ptr(), s.col_src.data_ptr(), norm.coef_src.data_ptr()
-    t.selfc = norm.selfc.data_ptr()
-    return t, tptr          # keep tptr alive with the struct
+    t.num_tiles = int(meta.tile_ptr.numel()) - 1
+    t.max_tile_rows = meta.max_tile_rows
+    t.tile_ptr, t.tile_blk = meta.tile_ptr.data_ptr(), meta.tile_blk.data_ptr()
+    t.blk_off_dst, t.ent_dst = meta.blk_off_dst.data_ptr(), meta.ent_dst.data_ptr()
+    t.blk_off_src, t.ent_src = meta.blk_off_src.data_ptr(), meta.ent_src.data_ptr()
+    t.dis = dis.data_ptr()
+    return t
 
 
 class _Ctx:
     """Everything of one forward pass that backward needs and autograd must not track."""
-    __slots__ = ("s", "norm", "tiles", "tptr", "grid", "ys", "bns", "masks", "p", "x0", "f0",
+    __slots__ = ("s", "meta", "dis", "tiles", "grid", "ys", "bns", "masks", "p", "x0", "f0",
                  "count", "sync_group", "num_layers", "training")
 
 
@@ -78,7 +77,6 @@ class FusedGCNEncode(torch.autograd.Function):
     def forward(ctx, x0, meta, *params):
         lib = _lib.load()
         s: BatchStructure = meta["structure"]
-        norm: GcnNorm = meta["norm"]
         bns_mod = meta["batch_norms"]
         training: bool = meta["training"]
         p: float = meta["dropout"] if training else 0.0
@@ -88,7 +86,9 @@ class FusedGCNEncode(torch.autograd.Function):
         x0 = x0.contiguous()
         nn_, B = s.num_nodes, s.num_graphs
         grid = lib.cgnn_fused_grid()
-        tiles, tptr = _tiles_struct(s, norm, grid)
+        fmeta = s.fused_meta(MAX_ROWS, grid)      # static per batch (cached on the structure)
+        dis = s.gcn_dis(fmeta)                    # the normalisation itself: every forward
+        tiles = _tiles_struct(s, fmeta, dis)
         tp = ctypes.byref(tiles)
         f32 = dict(dtype=torch.float32, device=dev)
         stat_slab = torch.empty(grid, 128, dtype=torch.float64, device=dev) if training else None
@@ -142,7 +142,7 @@ class FusedGCNEncode(torch.autograd.Function):
                 _lib.ptr(pooled), st()), "cgnn_gcn_fused_pool_fwd")
             masks.append(mask)
         c = _Ctx()
-        c.s, c.norm, c.tiles, c.tptr, c.grid = s, norm, tiles, tptr, grid
+        c.s, c.meta, c.dis, c.tiles, c.grid = s, fmeta, dis, tiles, grid
         c.ys, c.bns, c.masks, c.p, c.x0, c.f0 = ys, bns, masks, p, x0, x0.shape[1]
         c.count, c.sync_group, c.num_layers, c.training = count, sync_group, L, training
         ctx.c = c
@@ -222,7 +222,7 @@ class FusedGCNEncode(torch.autograd.Function):
         return (None, None, *grads)
 
 
-def encode(model, batch, structure: BatchStructure, norm: GcnNorm) -> torch.Tensor:
+def encode(model, batch, structure: BatchStructure) -> torch.Tensor:
     params = []
     for conv, bn in zip(model.convs, model.batch_norms):
         params += [conv.linear.weight, conv.bias, bn.weight, bn.bias]
@@ -231,6 +231,6 @@ def encode(model, batch, structure: BatchStructure, norm: GcnNorm) -> torch.Tens
         if isinstance(bn, torch.nn.SyncBatchNorm) and model.training and dist.is_initialized() \
                 and dist.get_world_size(bn.process_group) > 1:
             sync_group = bn.process_group if bn.process_group is not None else dist.group.WORLD
-    meta = {"structure": structure, "norm": norm, "batch_norms": list(model.batch_norms),
+    meta = {"structure": structure, "batch_norms": list(model.batch_norms),
             "training": model.training, "dropout": float(model.dropout), "sync_group": sync_group}
     return FusedGCNEncode.apply(batch.node_features, meta, *params)

@@ -123,12 +123,12 @@ class _ConnectomeModel(nn.Module):
         """Graph embeddings [B, hidden] (reference models.py:203-211 / 256-262)."""
         _require_device(batch.node_features, "batch.node_features")
         s = batch.structure()
-        norm = self._norm(s)                  # once per forward pass, shared by all layers
         if self._try_fused(batch, s):
             from . import fused
             self.impl_used = "fused"
-            return fused.encode(self, batch, s, norm)
+            return fused.encode(self, batch, s)
         self.impl_used = "layered"
+        norm = self._norm(s)                  # once per forward pass, shared by all layers
         x = batch.node_features
         for conv, bn in zip(self.convs, self.batch_norms):
             x = conv(x, batch.edge_index, batch.edge_weight, structure=s, norm=norm)

@@ -41,6 +41,20 @@ class SageNorm:
     coef_src_bwd: torch.Tensor   # [Ee]  w_e / den[dst_e] in src-CSR slot order
 
 
+@dataclass
+class FusedMeta:
+    """Static per-batch metadata of the fused per-tile kernels (see include/cgnn.h)."""
+    tile_ptr: torch.Tensor      # int32 [T+1]
+    tile_blk: torch.Tensor      # int32 [T+1] first 16-row block of each tile
+    max_tile_rows: int
+    num_blocks: int
+    blk_off_dst: torch.Tensor   # int32 [NB+1] (entries)
+    ent_dst: torch.Tensor       # uint8 [8 * entries]  blocked-ELL, rows = destinations
+    blk_off_src: torch.Tensor
+    ent_src: torch.Tensor       # blocked-ELL, rows = sources
+    w_src: torch.Tensor         # f32 [Ee] edge weights in src-CSR slot order (for dis)
+
+
 class BatchStructure:
     """dst-/src-sorted CSR (+ per-graph node ranges) of one batch, on its device."""
 
@@ -165,3 +179,55 @@ class BatchStructure:
             t = torch.from_numpy(cuts.astype(np.int32)).to(self.rowptr_dst.device)
             self._tiles[key] = (t, rows)
         return self._tiles[key]
+
+    def fused_meta(self, max_rows: int, num_workgroups: int) -> FusedMeta:
+        """Blocked-ELL metadata for the fused kernels, built once per batch by the HIP library
+        (cgnn_bell_plan / cgnn_bell_fill / cgnn_gather_f32)."""
+        key = ("meta", max_rows, num_workgroups)
+        if key in self._tiles:
+            return self._tiles[key]
+        lib = _lib.load()
+        dev = self.rowptr_dst.device
+        tptr, rows = self.tile_ptr(max_rows, num_workgroups)
+        cuts = tptr.cpu().numpy().astype(np.int64)
+        nblk = (np.diff(cuts) + 15) // 16
+        tile_blk_h = np.concatenate([[0], np.cumsum(nblk)]).astype(np.int32)
+        nb = int(tile_blk_h[-1])
+        nt = int(cuts.size) - 1
+        tile_blk = torch.from_numpy(tile_blk_h).to(dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        out = {}
+        with torch.cuda.device(dev):
+            for name, rowptr, col, eid in (("dst", self.rowptr_dst, self.col_dst, self.eid_dst),
+                                           ("src", self.rowptr_src, self.col_src, self.eid_src)):
+                blk_off = torch.empty(nb + 1, **i32)
+                scratch = torch.empty(nb // 2048 + 8, **i32)
+                _lib.check(lib.cgnn_bell_plan(_lib.ptr(tptr), _lib.ptr(tile_blk), nt, nb,
+                                              _lib.ptr(rowptr), _lib.ptr(blk_off), _lib.ptr(scratch),
+                                              _lib.stream_ptr()), "cgnn_bell_plan")
+                total = int(blk_off[-1])                 # sync: sizes the entry array
+                ent = torch.empty(max(total, 1) * 8, dtype=torch.uint8, device=dev)
+                _lib.check(lib.cgnn_bell_fill(_lib.ptr(tptr), _lib.ptr(tile_blk), nt,
+                                              _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(eid),
+                                              _lib.ptr(self._edge_weight), _lib.ptr(blk_off),
+                                              _lib.ptr(ent), _lib.stream_ptr()), "cgnn_bell_fill")
+                out[name] = (blk_off, ent)
+            w_src = torch.empty(self.num_edges, dtype=torch.float32, device=dev)
+            _lib.check(lib.cgnn_gather_f32(_lib.ptr(self._edge_weight), _lib.ptr(self.eid_src),
+                                           self.num_edges, _lib.ptr(w_src), _lib.stream_ptr()),
+                       "cgnn_gather_f32")
+        m = FusedMeta(tptr, tile_blk, rows, nb, out["dst"][0], out["dst"][1], out["src"][0],
+                      out["src"][1], w_src)
+        self._tiles[key] = m
+        return m
+
+    def gcn_dis(self, meta: FusedMeta) -> torch.Tensor:
+        """dis = (source-side degree + self-loop + 1e-8)^-1/2, models.py:97-105; every step."""
+        lib = _lib.load()
+        dev = self.rowptr_dst.device
+        dis = torch.empty(self.num_nodes, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.cgnn_gcn_dis(_lib.ptr(meta.w_src), _lib.ptr(self.rowptr_src),
+                                        self.num_nodes, _lib.ptr(dis), _lib.stream_ptr()),
+                       "cgnn_gcn_dis")
+        return dis

@@ -170,15 +170,45 @@ int cgnn_pool_mean_bwd_f32(const float* dP, const int32_t* gptr, float* dX, int6
 #define CGNN_FUSED_MAX_ROWS 384
 #define CGNN_FUSED_MAX_F0   16
 
+/* Blocked-ELL metadata of one edge ordering (rows = destinations for forward, rows = sources
+ * for the transposed passes).  Rows are grouped in 16-row blocks aligned to the start of each
+ * tile; block b stores width_b = max degree in the block + 1 steps of 16 entries each
+ * (entry (s, i) at blk_off[b] + 16*s + i), every entry 8 bytes:
+ *     uint32 lds_offset = 256 * (neighbour's row inside the tile)   float weight
+ * A row's real edges come first in COO order, then its self-loop (weight 1), then zero-weight
+ * padding, so the kernels' inner loop is branch-free and sums in the reference's order.
+ * Built once per batch (the weights are the raw edge weights; the symmetric normalisation is
+ * applied as  dis[d] * sum_e w_e * (dis[s_e] * x[s_e])  with `dis` recomputed every step). */
+
+/* Pass 1: widths + exclusive scan.  tile_ptr/tile_blk int32 [T+1] (tile_blk = prefix of
+ * ceil(rows/16), NB = num_blocks = tile_blk[T]), rowptr int32 [Nn+1] of the ordering.
+ * blk_off int32 [NB+1] out (in entries); scratch: int32 [NB/2048 + 8]. */
+int cgnn_bell_plan(const int32_t* tile_ptr, const int32_t* tile_blk, int32_t num_tiles,
+                   int32_t num_blocks, const int32_t* rowptr, int32_t* blk_off, int32_t* scratch,
+                   void* stream);
+/* Pass 2: fill entries (8 bytes each, blk_off[NB] of them). */
+int cgnn_bell_fill(const int32_t* tile_ptr, const int32_t* tile_blk, int32_t num_tiles,
+                   const int32_t* rowptr, const int32_t* col, const int32_t* eid,
+                   const float* edge_weight, const int32_t* blk_off, void* entries, void* stream);
+
+/* out[i] = src[idx[i]] (edge weights permuted to CSR slot order, once per batch). */
+int cgnn_gather_f32(const float* src, const int32_t* idx, int64_t n, float* out, void* stream);
+
+/* GCN degree normalisation, models.py:97-105, every step: dis[i] = (sum of row i of w_src
+ * (COO order) + 1 + 1e-8)^-1/2 with w_src the edge weights in src-CSR slot order. */
+int cgnn_gcn_dis(const float* w_src, const int32_t* rowptr_src, int64_t num_nodes, float* dis,
+                 void* stream);
+
 /* HOST-side parameter block (plain device pointers) describing the tiling of one batch. */
 typedef struct cgnn_tiles {
   int64_t num_nodes;
   int32_t num_tiles;
   int32_t max_tile_rows;        /* <= CGNN_FUSED_MAX_ROWS */
   const int32_t* tile_ptr;      /* [num_tiles+1] node offsets; tiles are unions of whole graphs */
-  const int32_t* rowptr_dst; const int32_t* col_dst; const float* coef_dst;
-  const int32_t* rowptr_src; const int32_t* col_src; const float* coef_src;
-  const float* selfc;           /* [num_nodes] dis^2 */
+  const int32_t* tile_blk;      /* [num_tiles+1] first 16-row block of each tile */
+  const int32_t* blk_off_dst; const void* ent_dst;   /* blocked-ELL, rows = destinations */
+  const int32_t* blk_off_src; const void* ent_src;   /* blocked-ELL, rows = sources */
+  const float* dis;             /* [num_nodes] */
 } cgnn_tiles;
 
 /* Number of persistent workgroups every fused kernel launches (= rows of every slab). */

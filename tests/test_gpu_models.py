@@ -258,8 +258,7 @@ def test_fused_dropout_contract():
     rel = (acc / 20 - ref).norm() / ref.norm()
     assert rel < 0.25, float(rel)
     # mask bytes: keep rate ~ 0.7
-    s = b.structure(); norm = s.gcn_norm()
-    out = fused.encode(m, b, s, norm)
+    out = fused.encode(m, b, b.structure())
     ctx = out.grad_fn.c if hasattr(out.grad_fn, "c") else None
     if ctx is not None:
         for mk in ctx.masks:
