@@ -13,7 +13,8 @@ import os
 from ctypes import c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcgnn_hip.so")
+# CGNN_LIB selects another build of the same ABI (diagnostic builds only, e.g. the stamped one)
+LIB_PATH = os.environ.get("CGNN_LIB") or os.path.join(_HERE, "libcgnn_hip.so")
 ABI_VERSION = 1
 
 CGNN_OK, CGNN_EINVAL, CGNN_ELAUNCH, CGNN_EUNSUPPORTED = 0, -1, -2, -3

@@ -13,12 +13,17 @@
 //   phase A  all 512 threads stream the tile from HBM with 16-byte loads, apply the fused
 //            elementwise prologue (BatchNorm-apply+ReLU+dropout, or BatchNorm-backward), and
 //            write it to LDS.
-//   phase B  each wave owns 16-row blocks.  Four rows at a time (16 lanes x float4 per row) it
-//            walks the rows' CSR slots -- 16 slots of (col, coef) are fetched with one coalesced
-//            load and broadcast inside the 16-lane row with DPP row_newbcast -- and accumulates
-//            neighbour rows straight out of the LDS tile with ds_read_b128.  The finished block
-//            goes through `stg` to v_mfma_f32_16x16x4_f32 (exact fp32) and the epilogue
-//            (bias / BatchNorm statistics / ReLU' * dropout') runs on the accumulators.
+//   phase B  each wave owns 16-row blocks.  Lane group q (16 lanes x float4 = one 64-wide row)
+//            owns rows 4q..4q+3 of the block.  The block's blocked-ELL entries (byte offset of
+//            the neighbour's row in the tile, raw edge weight; self-loop last; zero-weight
+//            padding up to the block's width) are fetched one block ahead with one coalesced
+//            32-byte load per lane, kept in registers and broadcast inside the 16-lane group
+//            with DPP row_newbcast; neighbour rows come straight out of the LDS tile with
+//            ds_read_b128.  The finished block goes through `stg` to v_mfma_f32_16x16x4_f32
+//            (exact fp32) and the epilogue (bias / BatchNorm statistics / ReLU' * dropout')
+//            runs on the accumulators.  The symmetric normalisation is applied as
+//            dis[d] * sum_e w_e * (dis[s_e] * x[s_e]): rows are scaled by dis when staged and
+//            again when they leave the aggregation, so the metadata is static per batch.
 //
 // The MFMA reduction index is permuted freely (lane group kk supplies k = 16*kk + s) so that
 // every operand fragment is a run of 16-byte LDS/register accesses; output tile tj holds the
@@ -26,6 +31,24 @@
 //
 // No atomics anywhere: per-workgroup partial sums go to slabs reduced in a fixed order.
 #include "common.h"
+
+// Diagnostic build only (-DCGNN_STAMPS, tools/stamp_probe.py): per-phase s_memtime shares.
+#ifdef CGNN_STAMPS
+__device__ unsigned long long g_stamps[1024 * 8 * 8];   // [wg][wave][slot]
+#define CGNN_STAMP_DECL unsigned long long stamp_t_ = 0; (void)stamp_t_;
+#define CGNN_STAMP_BEGIN() stamp_t_ = __builtin_amdgcn_s_memtime();
+#define CGNN_STAMP(slot)                                                               \
+  {                                                                                    \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();                      \
+    if ((threadIdx.x & 63) == 0)                                                       \
+      g_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (slot)] += now_ - stamp_t_; \
+    stamp_t_ = now_;                                                                   \
+  }
+#else
+#define CGNN_STAMP_DECL
+#define CGNN_STAMP_BEGIN()
+#define CGNN_STAMP(slot)
+#endif
 
 namespace {
 
@@ -94,52 +117,91 @@ __device__ __forceinline__ float4 ldsrow(const char* tb, uint32_t off) {
   return *reinterpret_cast<const float4*>(tb + off);
 }
 
-// Per-wave metadata pipeline: a block's entries (<= META_STEPS steps = 3 KB) are fetched with
-// three coalesced 1 KB wave loads issued one block ahead (in flight during the previous
-// block's MFMAs), committed to the wave's LDS buffer (the staging buffer, dead at that point)
-// and read from there by the aggregation loop.  Steps beyond META_STEPS (very high degree)
-// come straight from global memory.
-constexpr int META_STEPS = 24;
-struct MetaRegs { uint4 r0, r1, r2; };
+// Per-wave metadata pipeline.  Lane (q, j) keeps, in registers, the 4 entries (32 bytes) its
+// row group needs at step j (batch 0) and step 16+j (batch 1): one coalesced 2 KB wave load
+// per 16 steps, issued one block ahead (in flight during the previous block's MFMAs).  Inside
+// the loop an entry is broadcast to the 16 lanes of the group with DPP row_newbcast, so the
+// only LDS traffic is the neighbour rows themselves and every row-read address is available
+// without a memory round trip.  Steps >= 32 (very high degree) come from global memory.
+struct MetaRegs { uint4 a0, a1, b0, b1; };
 
-__device__ __forceinline__ MetaRegs meta_issue(const uint4* __restrict__ mp, int width, int lane) {
-  const int nq = min(width, META_STEPS) * 8;      // uint4 count
-  MetaRegs m;
+// AHEAD2: also prefetch batch 1 a block ahead (8 more live VGPRs); otherwise batch 1 is
+// requested at the start of its own block's aggregation and lands while batch 0 is processed.
+template <bool AHEAD2>
+__device__ __forceinline__ MetaRegs meta_issue(const uint4* __restrict__ mp, int width, int q, int j) {
   const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-  m.r0 = lane < nq ? mp[lane] : z;
-  m.r1 = lane + 64 < nq ? mp[lane + 64] : z;
-  m.r2 = lane + 128 < nq ? mp[lane + 128] : z;
+  MetaRegs m{z, z, z, z};
+  if (j < width) { m.a0 = mp[8 * j + 2 * q]; m.a1 = mp[8 * j + 2 * q + 1]; }
+  if (AHEAD2 && 16 + j < width) { m.b0 = mp[8 * (16 + j) + 2 * q]; m.b1 = mp[8 * (16 + j) + 2 * q + 1]; }
   return m;
 }
 
-__device__ __forceinline__ void meta_commit(uint4* mbuf, const MetaRegs& m, int lane) {
-  mbuf[lane] = m.r0;
-  mbuf[lane + 64] = m.r1;
-  mbuf[lane + 128] = m.r2;
-}
+#define CGNN_BC(v, S) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x150 + (S), 0xf, 0xf, false))
+// One step, unconditional: entries past the block's width are (offset 0, weight 0).
+#define CGNN_AGG_STEP(M0, M1, S)                                                            \
+  {                                                                                         \
+    const uint32_t o0 = CGNN_BC(M0.x, S), w0 = CGNN_BC(M0.y, S), o1 = CGNN_BC(M0.z, S),     \
+                   w1 = CGNN_BC(M0.w, S), o2 = CGNN_BC(M1.x, S), w2 = CGNN_BC(M1.y, S),     \
+                   o3 = CGNN_BC(M1.z, S), w3 = CGNN_BC(M1.w, S);                            \
+    fma4(acc[0], w0, ldsrow(tb, o0)); fma4(acc[1], w1, ldsrow(tb, o1));                     \
+    fma4(acc[2], w2, ldsrow(tb, o2)); fma4(acc[3], w3, ldsrow(tb, o3));                     \
+  }
+// G steps = 4G independent 16-byte LDS reads in flight (16G VGPRs), then 16G FMAs; the
+// sched_barrier stops the scheduler from hoisting every read of the block (256 VGPRs -> spills).
+#define CGNN_AGG_2(M0, M1, S)                                                               \
+  CGNN_AGG_STEP(M0, M1, S) CGNN_AGG_STEP(M0, M1, (S) + 1) __builtin_amdgcn_sched_barrier(0);
+#define CGNN_AGG_4W(M0, M1, S)                                                              \
+  CGNN_AGG_STEP(M0, M1, S) CGNN_AGG_STEP(M0, M1, (S) + 1) CGNN_AGG_STEP(M0, M1, (S) + 2)    \
+  CGNN_AGG_STEP(M0, M1, (S) + 3) __builtin_amdgcn_sched_barrier(0);
+#define CGNN_AGG_4(M0, M1, S)                                                               \
+  if (G >= 4) { CGNN_AGG_4W(M0, M1, S) } else { CGNN_AGG_2(M0, M1, S) CGNN_AGG_2(M0, M1, (S) + 2) }
 
-__device__ __forceinline__ void agg_block(const float* __restrict__ tile, const uint4* mbuf,
+// `width` must be wave-uniform.  Steps run in straight-line groups (no per-step branch: a
+// branch per step would fence the scheduler and expose the LDS latency of every step).
+// G = steps whose row reads may be in flight together (register budget of the caller).
+#define CGNN_AGG_STEP_IF(M0, M1, S, W) if ((S) < (W)) CGNN_AGG_STEP(M0, M1, S)
+#define CGNN_AGG_16_IF(M0, M1, W)                                                             \
+  CGNN_AGG_STEP_IF(M0, M1, 0, W) CGNN_AGG_STEP_IF(M0, M1, 1, W) CGNN_AGG_STEP_IF(M0, M1, 2, W)     \
+  CGNN_AGG_STEP_IF(M0, M1, 3, W) CGNN_AGG_STEP_IF(M0, M1, 4, W) CGNN_AGG_STEP_IF(M0, M1, 5, W)     \
+  CGNN_AGG_STEP_IF(M0, M1, 6, W) CGNN_AGG_STEP_IF(M0, M1, 7, W) CGNN_AGG_STEP_IF(M0, M1, 8, W)     \
+  CGNN_AGG_STEP_IF(M0, M1, 9, W) CGNN_AGG_STEP_IF(M0, M1, 10, W) CGNN_AGG_STEP_IF(M0, M1, 11, W)   \
+  CGNN_AGG_STEP_IF(M0, M1, 12, W) CGNN_AGG_STEP_IF(M0, M1, 13, W) CGNN_AGG_STEP_IF(M0, M1, 14, W)  \
+  CGNN_AGG_STEP_IF(M0, M1, 15, W)
+
+template <int G, bool AHEAD2>
+__device__ __forceinline__ void agg_block(const float* __restrict__ tile, MetaRegs m,
                                           const uint4* __restrict__ mp, int width, int q, int j,
                                           float4 (&acc)[4]) {
   const char* tb = reinterpret_cast<const char*>(tile) + 16 * j;
+  if (!AHEAD2 && 16 + j < width) { m.b0 = mp[8 * (16 + j) + 2 * q]; m.b1 = mp[8 * (16 + j) + 2 * q + 1]; }
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  const uint4* p = mbuf + 2 * q;
-  const int wl = min(width, META_STEPS);
-  uint4 a0 = p[0], a1 = p[1];
-#pragma unroll 2
-  for (int s = 1; s < wl; ++s) {
-    const uint4 n0 = p[8 * s], n1 = p[8 * s + 1];
-    fma4(acc[0], a0.y, ldsrow(tb, a0.x)); fma4(acc[1], a0.w, ldsrow(tb, a0.z));
-    fma4(acc[2], a1.y, ldsrow(tb, a1.x)); fma4(acc[3], a1.w, ldsrow(tb, a1.z));
-    a0 = n0; a1 = n1;
+  if (G == 1) {
+    // lowest register pressure: one scalar-branched basic block per step (the generic backward
+    // kernel holds 64 dW accumulators and cannot afford more rows in flight)
+    CGNN_AGG_16_IF(m.a0, m.a1, width)
+    if (width > 16) {
+      const int w1 = width - 16;
+      CGNN_AGG_16_IF(m.b0, m.b1, w1)
+    }
+  } else {
+    if (width >= 13) {
+      CGNN_AGG_4(m.a0, m.a1, 0) CGNN_AGG_4(m.a0, m.a1, 4) CGNN_AGG_4(m.a0, m.a1, 8) CGNN_AGG_4(m.a0, m.a1, 12)
+    } else {
+      CGNN_AGG_4(m.a0, m.a1, 0)
+      if (width > 4) { CGNN_AGG_4(m.a0, m.a1, 4) }
+      if (width > 8) { CGNN_AGG_4(m.a0, m.a1, 8) }
+    }
+    if (width > 16) {
+      CGNN_AGG_4(m.b0, m.b1, 0)
+      if (width > 20) { CGNN_AGG_4(m.b0, m.b1, 4) }
+      if (width > 24) { CGNN_AGG_4(m.b0, m.b1, 8) CGNN_AGG_4(m.b0, m.b1, 12) }
+    }
   }
-  fma4(acc[0], a0.y, ldsrow(tb, a0.x)); fma4(acc[1], a0.w, ldsrow(tb, a0.z));
-  fma4(acc[2], a1.y, ldsrow(tb, a1.x)); fma4(acc[3], a1.w, ldsrow(tb, a1.z));
-  for (int s = wl; s < width; ++s) {              // overflow steps: from global
-    a0 = mp[8 * s + 2 * q]; a1 = mp[8 * s + 2 * q + 1];
-    fma4(acc[0], a0.y, ldsrow(tb, a0.x)); fma4(acc[1], a0.w, ldsrow(tb, a0.z));
-    fma4(acc[2], a1.y, ldsrow(tb, a1.x)); fma4(acc[3], a1.w, ldsrow(tb, a1.z));
+  for (int s = 32; s < width; ++s) {              // overflow steps: from global
+    const uint4 e0 = mp[8 * s + 2 * q], e1 = mp[8 * s + 2 * q + 1];
+    fma4(acc[0], e0.y, ldsrow(tb, e0.x)); fma4(acc[1], e0.w, ldsrow(tb, e0.z));
+    fma4(acc[2], e1.y, ldsrow(tb, e1.x)); fma4(acc[3], e1.w, ldsrow(tb, e1.z));
   }
 }
 
@@ -219,84 +281,107 @@ __global__ void __launch_bounds__(NTHR) k_gcn_fwd(
     pb = ld4(bn_prev + HID + 4 * j);
   }
   double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  CGNN_STAMP_DECL
 
   for (int tid = blockIdx.x; tid < t.num_tiles; tid += gridDim.x) {
+    CGNN_STAMP_BEGIN()
     const int base = t.tile_ptr[tid];
     const int n = t.tile_ptr[tid + 1] - base;
     const int nblk = (n + 15) >> 4;
     const int gb0 = t.tile_blk[tid];
     // metadata of this wave's first block: in flight during phase A
-    int off0 = 0, width = 0;
-    MetaRegs pre;
-    if (wave < nblk) {
-      off0 = cgnn_uniform(t.blk_off_dst[gb0 + wave]);
-      width = (cgnn_uniform(t.blk_off_dst[gb0 + wave + 1]) - off0) >> 4;
-      pre = meta_issue(ent + (off0 >> 1), width, lane);
+    // entry offsets / widths of all of this wave's blocks (<= 3): scalar loads, once per tile
+    int boff[3] = {0, 0, 0}, bwid[3] = {0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int bb = cgnn_uniform(wave) + NWAVE * k;
+      if (bb < nblk) {
+        boff[k] = t.blk_off_dst[gb0 + bb];
+        bwid[k] = (t.blk_off_dst[gb0 + bb + 1] - boff[k]) >> 4;
+      }
     }
+    int off0 = boff[0], width = bwid[0], bk = 0;
+    MetaRegs pre;
+    if (wave < nblk) pre = meta_issue<true>(ent + (off0 >> 1), width, q, j);
 
     // ---------------------------------------------------------------- phase A: fill the tile
     // (rows are pre-scaled by dis[row]: A_hat X = dis * (A_w + I)(dis * X))
-    for (int r = threadIdx.x; r < nblk * 16; r += NTHR) disl[r] = r < n ? t.dis[base + r] : 0.f;
     if (FIRST) {
-      // T = X0 W0^T on the matrix core, written straight into the tile.
+      // T = X0 W0^T on the matrix core, written straight into the tile (all loads first).
+      for (int r = threadIdx.x; r < nblk * 16; r += NTHR) disl[r] = r < n ? t.dis[base + r] : 0.f;
       for (int b = wave; b < nblk; b += NWAVE) {
         const int arow = 16 * b + j;                    // A operand: row i = j, k-slot kk = q
         f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+        float av[4], dv[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const int k = 4 * s + q;
-          float av = 0.f;
+          av[s] = (arow < n && k < F0) ? Xin[(int64_t)(base + arow) * F0 + k] : 0.f;
+          const int row = 16 * b + 4 * q + s;
+          dv[s] = row < n ? t.dis[base + row] : 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
           if (4 * s < F0) {
-            if (arow < n && k < F0) av = Xin[(int64_t)(base + arow) * F0 + k];
 #pragma unroll
             for (int tj = 0; tj < 4; ++tj)
-              acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wreg[tj][s], acc[tj], 0, 0, 0);
+              acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], wreg[tj][s], acc[tj], 0, 0, 0);
+          }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          st4(tile + (16 * b + 4 * q + r) * HID + 4 * j,
+              make_float4(acc[0][r] * dv[r], acc[1][r] * dv[r], acc[2][r] * dv[r], acc[3][r] * dv[r]));
+      }
+    } else {
+      // UNR rows per thread in flight at once (512 thr x 6 x 16 B = 48 KB per CU outstanding)
+      constexpr int UNR = 6;
+      for (int r0 = threadIdx.x >> 4; r0 < nblk * 16; r0 += 32 * UNR) {
+        float4 yb[UNR];
+        float dv[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int row = r0 + 32 * u;
+          yb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          dv[u] = 0.f;
+          if (row < n) {
+            yb[u] = ld4(Xin + (int64_t)(base + row) * HID + 4 * j);
+            dv[u] = t.dis[base + row];
           }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * b + 4 * q + r;
-          const float dv = row < n ? t.dis[base + row] : 0.f;
-          st4(tile + row * HID + 4 * j,
-              make_float4(acc[0][r] * dv, acc[1][r] * dv, acc[2][r] * dv, acc[3][r] * dv));
-        }
-      }
-    } else {
-      for (int idx = threadIdx.x; idx < nblk * 256; idx += NTHR) {
-        const int row = idx >> 4;                        // chunk == j (NTHR % 16 == 0)
-        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < n) {
-          const float4 y = ld4(Xin + (int64_t)(base + row) * HID + 4 * j);
-          uint32_t keep = 0xFu;
-          if (use_drop) {
-            keep = drop_bits(drop, (uint32_t)(base + row), (uint32_t)j);
-            if (mask_out) mask_out[(int64_t)(base + row) * 16 + j] = (uint8_t)keep;
+        for (int u = 0; u < UNR; ++u) {
+          const int row = r0 + 32 * u;
+          if (row < nblk * 16) {
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < n) {
+              uint32_t keep = 0xFu;
+              if (use_drop) {
+                keep = drop_bits(drop, (uint32_t)(base + row), (uint32_t)j);
+                if (mask_out) mask_out[(int64_t)(base + row) * 16 + j] = (uint8_t)keep;
+              }
+              float4 f;
+              x = scale4(act4(yb[u], pa, pb, keep, drop.scale, f), dv[u]);
+            }
+            st4(tile + row * HID + 4 * j, x);
+            if (j == 0) disl[row] = dv[u];
           }
-          float4 f;
-          x = scale4(act4(y, pa, pb, keep, drop.scale, f), t.dis[base + row]);
         }
-        st4(tile + row * HID + 4 * j, x);
       }
     }
+    CGNN_STAMP(0)      // phase A issue+compute
     __syncthreads();
+    CGNN_STAMP(1)      // phase A barrier wait
 
     // ------------------------------------------------- phase B: aggregate (+ project) blocks
     for (int b = wave; b < nblk; b += NWAVE) {
       f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-      uint4* mbuf = reinterpret_cast<uint4*>(stg);
-      meta_commit(mbuf, pre, lane);
-      int off1 = 0, width1 = 0;
-      if (b + NWAVE < nblk) {
-        off1 = cgnn_uniform(t.blk_off_dst[gb0 + b + NWAVE]);
-        width1 = (cgnn_uniform(t.blk_off_dst[gb0 + b + NWAVE + 1]) - off1) >> 4;
-      }
-      __builtin_amdgcn_wave_barrier();
+      ++bk;
+      const int off1 = bk == 1 ? boff[1] : boff[2], width1 = bk == 1 ? bwid[1] : bwid[2];
+      CGNN_STAMP(2)
       float4 ag[4];
-      agg_block(tile, mbuf, ent + (off0 >> 1), width, q, j, ag);
-      __builtin_amdgcn_wave_barrier();
-      if (b + NWAVE < nblk) pre = meta_issue(ent + (off1 >> 1), width1, lane);
-      const int cur_off = off0;
-      (void)cur_off;
+      agg_block<4, true>(tile, pre, ent + (off0 >> 1), width, q, j, ag);
+      CGNN_STAMP(3)    // aggregation
+      if (b + NWAVE < nblk) pre = meta_issue<true>(ent + (off1 >> 1), width1, q, j);
       off0 = off1; width = width1;
       if (FIRST) {
         // tile already holds dis*T: Y = dis * (A_w + I)(dis*T) + b, straight from registers.
@@ -312,6 +397,7 @@ __global__ void __launch_bounds__(NTHR) k_gcn_fwd(
             s2[2] += (double)y.z * y.z; s2[3] += (double)y.w * y.w;
           }
         }
+        CGNN_STAMP(4)  // epilogue (first layer)
         continue;
       }
 #pragma unroll
@@ -325,12 +411,17 @@ __global__ void __launch_bounds__(NTHR) k_gcn_fwd(
         const float4 v = ld4(stg + j * SLD + 16 * q + 4 * u);
         af[4 * u + 0] = v.x; af[4 * u + 1] = v.y; af[4 * u + 2] = v.z; af[4 * u + 3] = v.w;
       }
+      CGNN_STAMP(4)    // staging write + A-fragment read (+ next metadata issue)
 #pragma unroll
       for (int s = 0; s < 16; ++s)
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj)
           acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], wreg[tj][s], acc[tj], 0, 0, 0);
       __builtin_amdgcn_wave_barrier();
+#ifdef CGNN_STAMPS
+      asm volatile("" ::"v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]));
+#endif
+      CGNN_STAMP(5)    // 64 MFMAs
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = 16 * b + 4 * q + r;
@@ -343,8 +434,10 @@ __global__ void __launch_bounds__(NTHR) k_gcn_fwd(
           s2[2] += (double)y.z * y.z; s2[3] += (double)y.w * y.w;
         }
       }
+      CGNN_STAMP(7)    // epilogue: bias, store, fp64 statistics
     }
     __syncthreads();
+    CGNN_STAMP(6)      // end-of-tile barrier wait
   }
   if (stat_slab)
     reduce_stats(s1, s2, reinterpret_cast<double*>(tile), stat_slab + (int64_t)blockIdx.x * 128);
@@ -373,13 +466,10 @@ __global__ void __launch_bounds__(NTHR) k_gcn_bwd(
   if (!FIRST) {
     for (int i = threadIdx.x; i < HID * HID / 4; i += NTHR) st4(Wl + 4 * i, ld4(W + 4 * i));
   }
-  // phase-A constants for this thread's 4 columns
-  const float4 ca = ld4(bn + 4 * j), cmean = ld4(bn + 2 * HID + 4 * j), cis = ld4(bn + 3 * HID + 4 * j);
-  const float4 c1 = ld4(bwc + 4 * j), c2 = ld4(bwc + HID + 4 * j);
-  float4 pa = make_float4(0, 0, 0, 0), pb = pa, pmean = pa, pis = pa;
+  // previous layer's BatchNorm block (a | b | mean | invstd) lives in LDS, not in 16 registers
+  __shared__ __attribute__((aligned(16))) float bnl[FIRST ? 4 : 4 * HID];
   if (!FIRST) {
-    pa = ld4(bn_prev + 4 * j); pb = ld4(bn_prev + HID + 4 * j);
-    pmean = ld4(bn_prev + 2 * HID + 4 * j); pis = ld4(bn_prev + 3 * HID + 4 * j);
+    for (int i = threadIdx.x; i < 4 * HID; i += NTHR) bnl[i] = bn_prev[i];
   }
   // dW accumulators: FIRST: dw[ti][0] only (16 input columns); else dw[ti][tj].
   f32x4 dw[4][FIRST ? 1 : 4];
@@ -387,97 +477,134 @@ __global__ void __launch_bounds__(NTHR) k_gcn_bwd(
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b2 = 0; b2 < (FIRST ? 1 : 4); ++b2) dw[a][b2] = f32x4{0, 0, 0, 0};
+  // per-thread partial sums: fp32 within a tile (a few dozen terms), folded into fp64 per tile
   double db[4] = {0, 0, 0, 0};
   double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  CGNN_STAMP_DECL
 
   for (int tid = blockIdx.x; tid < t.num_tiles; tid += gridDim.x) {
+    CGNN_STAMP_BEGIN()
     const int base = t.tile_ptr[tid];
     const int n = t.tile_ptr[tid + 1] - base;
     const int nblk = (n + 15) >> 4;
     const int gb0 = t.tile_blk[tid];
-    int off0 = 0, width = 0;
-    MetaRegs pre;
-    if (wave < nblk) {
-      off0 = cgnn_uniform(t.blk_off_src[gb0 + wave]);
-      width = (cgnn_uniform(t.blk_off_src[gb0 + wave + 1]) - off0) >> 4;
-      pre = meta_issue(ent + (off0 >> 1), width, lane);
+    int boff[3] = {0, 0, 0}, bwid[3] = {0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int bb = cgnn_uniform(wave) + NWAVE * k;
+      if (bb < nblk) {
+        boff[k] = t.blk_off_src[gb0 + bb];
+        bwid[k] = (t.blk_off_src[gb0 + bb + 1] - boff[k]) >> 4;
+      }
     }
+    int off0 = boff[0], width = bwid[0], bk = 0;
+    MetaRegs pre;
+    if (wave < nblk) pre = meta_issue<FIRST>(ent + (off0 >> 1), width, q, j);
 
     // --------------------------- phase A: dis * dY, dY = BatchNorm'(dZ), into the tile
-    for (int r = threadIdx.x; r < nblk * 16; r += NTHR) disl[r] = r < n ? t.dis[base + r] : 0.f;
-    for (int idx = threadIdx.x; idx < nblk * 256; idx += NTHR) {
-      const int row = idx >> 4;
-      float4 dy = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < n) {
-        const float4 dz = ld4(dZ + (int64_t)(base + row) * HID + 4 * j);
-        const float4 y = ld4(Y + (int64_t)(base + row) * HID + 4 * j);
-        dy.x = ca.x * (dz.x - c1.x - (y.x - cmean.x) * cis.x * c2.x);
-        dy.y = ca.y * (dz.y - c1.y - (y.y - cmean.y) * cis.y * c2.y);
-        dy.z = ca.z * (dz.z - c1.z - (y.z - cmean.z) * cis.z * c2.z);
-        dy.w = ca.w * (dz.w - c1.w - (y.w - cmean.w) * cis.w * c2.w);
-        db[0] += dy.x; db[1] += dy.y; db[2] += dy.z; db[3] += dy.w;
-        dy = scale4(dy, t.dis[base + row]);
+    {
+      // phase-A constants of this thread's 4 columns: re-read per tile (L1/L2 hits) instead of
+      // held in 20 registers across phase B, where dW's 64 accumulators need the room.
+      const float4 ca = ld4(bn + 4 * j), cmean = ld4(bn + 2 * HID + 4 * j), cis = ld4(bn + 3 * HID + 4 * j);
+      const float4 c1 = ld4(bwc + 4 * j), c2 = ld4(bwc + HID + 4 * j);
+      constexpr int UNR = 6;
+      for (int r0 = threadIdx.x >> 4; r0 < nblk * 16; r0 += 32 * UNR) {
+        float4 zb[UNR], yb[UNR];
+        float dv[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int row = r0 + 32 * u;
+          zb[u] = yb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          dv[u] = 0.f;
+          if (row < n) {
+            zb[u] = ld4(dZ + (int64_t)(base + row) * HID + 4 * j);
+            yb[u] = ld4(Y + (int64_t)(base + row) * HID + 4 * j);
+            dv[u] = t.dis[base + row];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int row = r0 + 32 * u;
+          if (row < nblk * 16) {
+            float4 dy = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < n) {
+              const float4 dz = zb[u], y = yb[u];
+              dy.x = ca.x * (dz.x - c1.x - (y.x - cmean.x) * cis.x * c2.x);
+              dy.y = ca.y * (dz.y - c1.y - (y.y - cmean.y) * cis.y * c2.y);
+              dy.z = ca.z * (dz.z - c1.z - (y.z - cmean.z) * cis.z * c2.z);
+              dy.w = ca.w * (dz.w - c1.w - (y.w - cmean.w) * cis.w * c2.w);
+              db[0] += dy.x; db[1] += dy.y; db[2] += dy.z; db[3] += dy.w;
+              dy = scale4(dy, dv[u]);
+            }
+            st4(tile + row * HID + 4 * j, dy);
+            if (j == 0) disl[row] = dv[u];
+          }
+        }
       }
-      st4(tile + row * HID + 4 * j, dy);
     }
+    CGNN_STAMP(0)
     __syncthreads();
+    CGNN_STAMP(1)
 
     // --------------------- phase B: dT = A_hat^T dY per block; dW += dT^T X; dZprev = ...
     for (int b = wave; b < nblk; b += NWAVE) {
+      float4 yp[4];
+      uint32_t keeps = 0u;                      // byte r: keep bits of row 4q+r (0 = no such row)
       {
-        uint4* mbuf = reinterpret_cast<uint4*>(stg);
-        meta_commit(mbuf, pre, lane);
-        int off1 = 0, width1 = 0;
-        if (b + NWAVE < nblk) {
-          off1 = cgnn_uniform(t.blk_off_src[gb0 + b + NWAVE]);
-          width1 = (cgnn_uniform(t.blk_off_src[gb0 + b + NWAVE + 1]) - off1) >> 4;
+        ++bk;
+        const int off1 = bk == 1 ? boff[1] : boff[2], width1 = bk == 1 ? bwid[1] : bwid[2];
+        CGNN_STAMP(2)
+        // previous layer's block (rows 4q+r, columns 4j..4j+3): requested AFTER the metadata
+        // commit (so the commit does not wait on it) and BEFORE the aggregation (which hides
+        // its HBM latency).  Only the raw pre-BatchNorm values and the keep bits stay live; X
+        // (B operand of dW) and relu'/dropout'/xhat (epilogue) are re-derived where needed.
+        if (!FIRST) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * b + 4 * q + r;
+            yp[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < n) {
+                yp[r] = ld4(Xprev + (int64_t)(base + row) * HID + 4 * j);
+                uint32_t kb = 0xFu;
+                if (use_drop) kb = mask_prev[(int64_t)(base + row) * 16 + j];
+                keeps |= kb << (8 * r);
+            }
+          }
         }
-        __builtin_amdgcn_wave_barrier();
         float4 ag[4];
-        agg_block(tile, mbuf, ent + (off0 >> 1), width, q, j, ag);
-        __builtin_amdgcn_wave_barrier();
+        agg_block<FIRST ? 4 : 1, FIRST>(tile, pre, ent + (off0 >> 1), width, q, j, ag);
+        CGNN_STAMP(3)
 #pragma unroll
         for (int it = 0; it < 4; ++it)
           st4(stg + (4 * q + it) * SLD + 4 * j, scale4(ag[it], disl[16 * b + 4 * q + it]));
-        if (b + NWAVE < nblk) pre = meta_issue(ent + (off1 >> 1), width1, lane);
+        if (b + NWAVE < nblk) pre = meta_issue<FIRST>(ent + (off1 >> 1), width1, q, j);
         off0 = off1; width = width1;
       }
       __builtin_amdgcn_wave_barrier();
 
       if (FIRST) {
         // B operand: X0[row 4q+s][col j] (zero beyond F0); dW0[o][jcol] tile ti: o = 16ti+4q+r
+        float xv[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const int row = 16 * b + 4 * q + s;
-          float xv = 0.f;
-          if (row < n && j < F0) xv = Xprev[(int64_t)(base + row) * F0 + j];
+          xv[s] = (row < n && j < F0) ? Xprev[(int64_t)(base + row) * F0 + j] : 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
 #pragma unroll
           for (int ti = 0; ti < 4; ++ti) {
             const float av = stg[(4 * q + s) * SLD + 16 * ti + j];
-            dw[ti][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xv, dw[ti][0], 0, 0, 0);
+            dw[ti][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xv[s], dw[ti][0], 0, 0, 0);
           }
         }
         __builtin_amdgcn_wave_barrier();
+        CGNN_STAMP(4)
         continue;
       }
 
-      // previous layer's block: rows 4q+r, columns 4j..4j+3.  Only the raw pre-BatchNorm values
-      // and the keep bits stay live; X (B operand of dW) and relu'/dropout'/xhat (epilogue) are
-      // re-derived from them where needed (register pressure: dW holds 64 accumulators).
-      float4 yp[4];
-      uint32_t keeps = 0u;                      // byte r: keep bits of row 4q+r (0 = no such row)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * b + 4 * q + r;
-        yp[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < n) {
-          yp[r] = ld4(Xprev + (int64_t)(base + row) * HID + 4 * j);
-          uint32_t kb = 0xFu;
-          if (use_drop) kb = mask_prev[(int64_t)(base + row) * 16 + j];
-          keeps |= kb << (8 * r);
-        }
-      }
       // dW[o][col] += sum_m dT[m][o] X[m][col]; k <-> m = 4q + s
+      const float4 pa = ld4(bnl + 4 * j), pb = ld4(bnl + HID + 4 * j);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         float4 f;
@@ -508,12 +635,14 @@ __global__ void __launch_bounds__(NTHR) k_gcn_bwd(
         dx[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], w4.w, dx[3], 0, 0, 0);
       }
       __builtin_amdgcn_wave_barrier();
+      const float4 pa2 = ld4(bnl + 4 * j), pb2 = ld4(bnl + HID + 4 * j);
+      const float4 pmean = ld4(bnl + 2 * HID + 4 * j), pis = ld4(bnl + 3 * HID + 4 * j);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = 16 * b + 4 * q + r;
         if (row < n) {
           float4 f;
-          act4(yp[r], pa, pb, (keeps >> (8 * r)) & 0xFu, drop.scale, f);
+          act4(yp[r], pa2, pb2, (keeps >> (8 * r)) & 0xFu, drop.scale, f);
           const float4 dzp = make_float4(dx[0][r] * f.x, dx[1][r] * f.y, dx[2][r] * f.z, dx[3][r] * f.w);
           st4(dZprev + (int64_t)(base + row) * HID + 4 * j, dzp);
           s1[0] += dzp.x; s1[1] += dzp.y; s1[2] += dzp.z; s1[3] += dzp.w;
@@ -523,8 +652,11 @@ __global__ void __launch_bounds__(NTHR) k_gcn_bwd(
           s2[3] += (double)dzp.w * ((yp[r].w - pmean.w) * pis.w);
         }
       }
+      CGNN_STAMP(4)
     }
+    CGNN_STAMP(5)
     __syncthreads();
+    CGNN_STAMP(6)
   }
 
   // ---------------------------------------------------------------- workgroup reductions
@@ -769,6 +901,17 @@ bool tiles_ok(const cgnn_tiles* t) {
 }  // namespace
 
 extern "C" {
+
+#ifdef CGNN_STAMPS
+// diagnostic build only: copy the stamp accumulators to the host and clear them
+int cgnn_debug_stamps(unsigned long long* out_host) {
+  if (hipDeviceSynchronize() != hipSuccess) return CGNN_ELAUNCH;
+  if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) != hipSuccess) return CGNN_ELAUNCH;
+  static unsigned long long zeros[1024 * 8 * 8];
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zeros, sizeof(zeros)) != hipSuccess) return CGNN_ELAUNCH;
+  return CGNN_OK;
+}
+#endif
 
 int cgnn_fused_grid(void) { return fused_grid(); }
 

@@ -151,6 +151,8 @@ class ConnectomeDataLoader:
         for lo in range(0, n, self.batch_size):
             chunk = order[lo:lo + self.batch_size]
             if self.world_size > 1:
+                if len(chunk) < self.world_size:
+                    continue          # a tail smaller than the world: dropped on every rank
                 chunk = shard_slice(chunk, self.rank, self.world_size)
             yield collate_graphs([self.dataset[i] for i in chunk])
 

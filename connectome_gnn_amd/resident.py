@@ -51,6 +51,8 @@ class ResidentDataLoader:
         for lo in range(0, n, self.batch_size):
             chunk = order[lo:lo + self.batch_size]
             if self.world_size > 1:
+                if chunk.numel() < self.world_size:
+                    continue          # a tail smaller than the world: dropped on every rank
                 chunk = torch.tensor(shard_slice(chunk.tolist(), self.rank, self.world_size),
                                      dtype=torch.long)
             yield assemble_batch(self.dataset, chunk)

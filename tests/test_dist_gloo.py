@@ -1,0 +1,106 @@
+"""world_size-2 tests of the data-parallel host path over gloo (CPU tensors): the flat-buffer
+gradient all-reduce, parameter broadcast, sharded loaders and the sync-BN sum exchange used by
+the fused encoder.  The HIP kernels are not involved (no GPU here); what is checked is that
+mean-of-shard-gradients equals the global-batch gradient, using the oracle as the local model."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import connectome_gnn_amd as C
+    from connectome_gnn_amd import dist as cdist
+    from connectome_gnn_amd.fused import _sync_sums
+    from connectome_gnn_amd.graph import shard_slice
+    from oracle import reference_path as O
+    try:
+        r, w, _ = cdist.init_from_env(backend="gloo")
+        assert (r, w) == (rank, world)
+        torch.set_num_threads(1)
+        graphs = C.generate_dataset(8, 20, 4, seed=3)
+        # --- parameters: different per rank, then broadcast from rank 0
+        torch.manual_seed(100 + rank)
+        lin = torch.nn.Linear(5, 3)
+        cdist.broadcast_parameters(lin)
+        ref = [p.detach().clone() for p in lin.parameters()]
+        gathered = [torch.zeros_like(ref[0]) for _ in range(world)]
+        dist.all_gather(gathered, ref[0])
+        assert all(torch.equal(g, gathered[0]) for g in gathered)
+        # --- gradient sync: oracle model with local (per-shard) BN replaced by eval-mode BN so
+        # that shard gradients average exactly to the global-batch gradient
+        torch.manual_seed(7)
+        st = O.require_grad(O.init_gcn_state(5, 16))
+        params = [st[k] for k in O.param_keys(st)]
+        sync = cdist.GradSync(params)
+
+        def grads_on(gs):
+            for p in params:
+                p.grad = None
+            b = O.collate([g.node_features for g in gs], [g.edge_index for g in gs],
+                          [g.edge_weight for g in gs], [g.label for g in gs])
+            loss = torch.nn.functional.cross_entropy(O.gcn_forward(st, b, 0.0, False), b.labels)
+            loss.backward()
+            return [p.grad.clone() for p in params]
+
+        full = grads_on(graphs)
+        mine = shard_slice(list(range(8)), rank, world)
+        grads_on([graphs[i] for i in mine])
+        sync()                                                  # equal shards: plain mean
+        for p, g in zip(params, full):
+            torch.testing.assert_close(p.grad, g, rtol=1e-5, atol=1e-7)
+        # unequal shards (5 + 3): weight by share of the global batch
+        cut = [graphs[:5], graphs[5:]][rank]
+        grads_on(cut)
+        sync(local_graphs=len(cut), global_graphs=8)
+        for p, g in zip(params, full):
+            torch.testing.assert_close(p.grad, g, rtol=1e-5, atol=1e-7)
+        # --- sync-BN sum exchange of the fused encoder: [sum | sumsq] + row count
+        sums = torch.arange(128, dtype=torch.float64) * (rank + 1)
+        cnt = _sync_sums(sums, 10.0 * (rank + 1), None)
+        assert cnt == 30.0 and torch.equal(sums, torch.arange(128, dtype=torch.float64) * 3)
+        # --- sharded loader: same global order on all ranks, disjoint contiguous shards
+        torch.manual_seed(11)
+        ld = C.ConnectomeDataLoader(graphs, batch_size=4, shuffle=True, rank=rank, world_size=world)
+        first = [b.node_features.clone() for b in ld]
+        sizes = torch.tensor([b.shape[0] for b in first])
+        allsz = [torch.zeros_like(sizes) for _ in range(world)]
+        dist.all_gather(allsz, sizes)
+        assert int(sum(a.sum() for a in allsz)) == 8 * 20
+        dist.barrier()
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_data_parallel_host_path_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=150) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
