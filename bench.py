@@ -180,6 +180,14 @@ def main() -> None:
         dom_bytes = dom_bytes_fn(nn_, ee)
         avg_ms = sum(kms) / max(len(kms), 1)
         achieved = dom_bytes / (avg_ms * 1e-3) / 1e9 if kms else 0.0
+        # HBM bytes per launch of that kernel from the PMC passes kept under profiles/ (collected
+        # offline with rocprofv3 --pmc on this same command; null for other workloads)
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_fused_pmc_traffic.json")
+        if impl_used == "fused" and os.path.exists(pmc) and bsz == 4096:
+            doc = json.load(open(pmc))
+            if doc.get("workload") == args.workload:
+                traffic = doc["kernels"].get("k_gcn_bwd<384, false>", {}).get("hbm_bytes_per_launch")
         out = {
             "metric": "training graphs/sec, 3-layer GCN, batch=4096x360-ROI connectomes"
             if args.workload.startswith("cfg4") else f"training graphs/sec, {args.workload}",
@@ -198,7 +206,8 @@ def main() -> None:
                                  "frac_of_hbm_peak": bpg * graphs_per_s / world / (HBM_PEAK_GBS * 1e9)},
             "roofline": {"bound": "hbm", "kernel": dom, "launches_timed": len(kms),
                          "avg_ms": avg_ms, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None},
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": dom_bytes},
             "final_loss": final_loss,
         }
         if not args.no_cpu_baseline and world == 1:
