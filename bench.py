@@ -91,6 +91,9 @@ def main() -> None:
     ap.add_argument("--nbuf", type=int, default=2, help="distinct resident batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-bn", action="store_true", help="full-batch BN statistics across ranks")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
+    ap.add_argument("--one-device", action="store_true",
+                    help="rehearsal only: every rank on cuda:0 (use with --backend gloo)")
     args = ap.parse_args()
 
     import connectome_gnn_amd as C
@@ -98,7 +101,9 @@ def main() -> None:
     from connectome_gnn_amd.resident import assemble_batch
     from connectome_gnn_amd.synthetic import generate_packed
 
-    rank, world, local = cdist.init_from_env()
+    if args.one_device:
+        os.environ["LOCAL_RANK"] = "0"
+    rank, world, local = cdist.init_from_env(args.backend)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
