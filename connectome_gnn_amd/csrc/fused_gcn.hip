@@ -446,9 +446,19 @@ __global__ void __launch_bounds__(NTHR) k_gcn_fwd(
 // ==========================================================================================
 // backward
 // ==========================================================================================
-template <int MAXR, bool FIRST>
+// POOLIN: this is the last layer and its incoming gradient is the readout's: dZ is not read
+// from HBM but rebuilt per row as dP[graph]/(n_g+1e-8) * relu' * dropout' (models.py:57-59,
+// 209-211 backward) -- saves writing and re-reading one [Nn,64] array per step.
+struct PoolIn {
+  const float* dP;               // [B,64]
+  const int32_t* node_graph;     // [Nn]
+  const int32_t* gptr;           // [B+1]
+  const uint8_t* mask_cur;       // keep bits of THIS layer's activation (or NULL)
+};
+
+template <int MAXR, bool FIRST, bool POOLIN>
 __global__ void __launch_bounds__(NTHR) k_gcn_bwd(
-    cgnn_tiles t, const float* __restrict__ dZ, const float* __restrict__ Y,
+    cgnn_tiles t, PoolIn pin, const float* __restrict__ dZ, const float* __restrict__ Y,
     const float* __restrict__ bn, const float* __restrict__ bwc,
     const float* __restrict__ Xprev /* Yprev [Nn,64] or X0 [Nn,F0] */, int F0,
     const float* __restrict__ bn_prev, DropCfg drop, int use_drop,
@@ -507,19 +517,39 @@ __global__ void __launch_bounds__(NTHR) k_gcn_bwd(
       // held in 20 registers across phase B, where dW's 64 accumulators need the room.
       const float4 ca = ld4(bn + 4 * j), cmean = ld4(bn + 2 * HID + 4 * j), cis = ld4(bn + 3 * HID + 4 * j);
       const float4 c1 = ld4(bwc + 4 * j), c2 = ld4(bwc + HID + 4 * j);
+      const float4 cb = POOLIN ? ld4(bn + HID + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
       constexpr int UNR = 6;
       for (int r0 = threadIdx.x >> 4; r0 < nblk * 16; r0 += 32 * UNR) {
         float4 zb[UNR], yb[UNR];
         float dv[UNR];
+        int gid[UNR];
+        uint32_t kb[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
           const int row = r0 + 32 * u;
           zb[u] = yb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
           dv[u] = 0.f;
+          gid[u] = 0;
+          kb[u] = 0xFu;
           if (row < n) {
-            zb[u] = ld4(dZ + (int64_t)(base + row) * HID + 4 * j);
+            if (POOLIN) {
+              gid[u] = pin.node_graph[base + row];
+              if (use_drop) kb[u] = pin.mask_cur[(int64_t)(base + row) * 16 + j];
+            } else {
+              zb[u] = ld4(dZ + (int64_t)(base + row) * HID + 4 * j);
+            }
             yb[u] = ld4(Y + (int64_t)(base + row) * HID + 4 * j);
             dv[u] = t.dis[base + row];
+          }
+        }
+        if (POOLIN) {
+#pragma unroll
+          for (int u = 0; u < UNR; ++u) {
+            const int row = r0 + 32 * u;
+            if (row < n) {
+              const float inv = 1.0f / ((float)(pin.gptr[gid[u] + 1] - pin.gptr[gid[u]]) + 1e-8f);
+              zb[u] = scale4(ld4(pin.dP + (int64_t)gid[u] * HID + 4 * j), inv);
+            }
           }
         }
 #pragma unroll
@@ -528,7 +558,13 @@ __global__ void __launch_bounds__(NTHR) k_gcn_bwd(
           if (row < nblk * 16) {
             float4 dy = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row < n) {
-              const float4 dz = zb[u], y = yb[u];
+              float4 dz = zb[u];
+              const float4 y = yb[u];
+              if (POOLIN) {
+                float4 f;
+                act4(y, ca, cb, kb[u], drop.scale, f);
+                dz = make_float4(dz.x * f.x, dz.y * f.y, dz.z * f.z, dz.w * f.w);
+              }
               dy.x = ca.x * (dz.x - c1.x - (y.x - cmean.x) * cis.x * c2.x);
               dy.y = ca.y * (dz.y - c1.y - (y.y - cmean.y) * cis.y * c2.y);
               dy.z = ca.z * (dz.z - c1.z - (y.z - cmean.z) * cis.z * c2.z);
@@ -784,7 +820,7 @@ __global__ void __launch_bounds__(PTHR) k_pool_bwd(const float* __restrict__ dP,
       float4 f;
       act4(y, a, b, keep, drop.scale, f);
       const float4 dz = make_float4(gp.x * f.x, gp.y * f.y, gp.z * f.z, gp.w * f.w);
-      st4(dZ + (int64_t)row * HID + 4 * j, dz);
+      if (dZ) st4(dZ + (int64_t)row * HID + 4 * j, dz);
       s1[0] += dz.x; s1[1] += dz.y; s1[2] += dz.z; s1[3] += dz.w;
       s2[0] += (double)dz.x * ((y.x - mean.x) * is.x); s2[1] += (double)dz.y * ((y.y - mean.y) * is.y);
       s2[2] += (double)dz.z * ((y.z - mean.z) * is.z); s2[3] += (double)dz.w * ((y.w - mean.w) * is.w);
@@ -976,7 +1012,7 @@ int cgnn_gcn_fused_pool_bwd(const float* dP, const float* Y, const float* bn, fl
                             const uint8_t* mask, const int32_t* gptr, int32_t num_graphs,
                             float* dZ, double* s_slab, void* stream) {
   if (num_graphs < 0 || p_drop < 0.f || p_drop >= 1.f) return CGNN_EINVAL;
-  if (!dP || !Y || !bn || !gptr || !dZ || !s_slab) return CGNN_EINVAL;
+  if (!dP || !Y || !bn || !gptr || !s_slab) return CGNN_EINVAL;   /* dZ may be NULL: sums only */
   if (p_drop > 0.f && !mask) return CGNN_EINVAL;
   int use_drop;
   DropCfg d = make_drop(p_drop, 0, &use_drop);
@@ -998,30 +1034,49 @@ int cgnn_bn_bwd_finalize(const double* sums, double count, float* dgamma, float*
 int cgnn_gcn_fused_bwd(const cgnn_tiles* t, const float* dZ, const float* Y, const float* bn,
                        const float* bwc, const float* Yprev, const float* bn_prev, float p_drop,
                        const uint8_t* mask_prev, const float* W, float* dZprev,
-                       double* s_slab_prev, float* dW_slab, double* db_slab, void* stream) {
+                       double* s_slab_prev, float* dW_slab, double* db_slab, const float* dP,
+                       const int32_t* node_graph, const int32_t* gptr, const uint8_t* mask_cur,
+                       void* stream) {
   if (!tiles_ok(t)) return t && t->max_tile_rows > CGNN_FUSED_MAX_ROWS ? CGNN_EUNSUPPORTED : CGNN_EINVAL;
-  if (!dZ || !Y || !bn || !bwc || !Yprev || !bn_prev || !W || !dZprev || !s_slab_prev || !dW_slab ||
+  if (!Y || !bn || !bwc || !Yprev || !bn_prev || !W || !dZprev || !s_slab_prev || !dW_slab ||
       !db_slab || p_drop < 0.f || p_drop >= 1.f)
     return CGNN_EINVAL;
   if (p_drop > 0.f && !mask_prev) return CGNN_EINVAL;
+  if (dP ? (!node_graph || !gptr || (p_drop > 0.f && !mask_cur)) : !dZ) return CGNN_EINVAL;
   int use_drop;
   DropCfg d = make_drop(p_drop, 0, &use_drop);
-  k_gcn_bwd<CGNN_FUSED_MAX_ROWS, false><<<fused_grid(), NTHR, 0, cgnn_stream(stream)>>>(
-      *t, dZ, Y, bn, bwc, Yprev, 0, bn_prev, d, use_drop, mask_prev, W, dZprev, s_slab_prev,
-      dW_slab, db_slab);
+  PoolIn pin{dP, node_graph, gptr, mask_cur};
+  if (dP)
+    k_gcn_bwd<CGNN_FUSED_MAX_ROWS, false, true><<<fused_grid(), NTHR, 0, cgnn_stream(stream)>>>(
+        *t, pin, dZ, Y, bn, bwc, Yprev, 0, bn_prev, d, use_drop, mask_prev, W, dZprev, s_slab_prev,
+        dW_slab, db_slab);
+  else
+    k_gcn_bwd<CGNN_FUSED_MAX_ROWS, false, false><<<fused_grid(), NTHR, 0, cgnn_stream(stream)>>>(
+        *t, pin, dZ, Y, bn, bwc, Yprev, 0, bn_prev, d, use_drop, mask_prev, W, dZprev, s_slab_prev,
+        dW_slab, db_slab);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }
 
 int cgnn_gcn_fused_bwd_first(const cgnn_tiles* t, const float* dZ, const float* Y, const float* bn,
                              const float* bwc, const float* X0, int32_t F0, float* dW_slab,
-                             double* db_slab, void* stream) {
+                             double* db_slab, float p_drop, const float* dP,
+                             const int32_t* node_graph, const int32_t* gptr,
+                             const uint8_t* mask_cur, void* stream) {
   if (!tiles_ok(t) || F0 <= 0 || F0 > CGNN_FUSED_MAX_F0) return t && t->max_tile_rows > CGNN_FUSED_MAX_ROWS ? CGNN_EUNSUPPORTED : CGNN_EINVAL;
-  if (!dZ || !Y || !bn || !bwc || !X0 || !dW_slab || !db_slab) return CGNN_EINVAL;
-  DropCfg d{};
-  k_gcn_bwd<CGNN_FUSED_MAX_ROWS, true><<<fused_grid(), NTHR, 0, cgnn_stream(stream)>>>(
-      *t, dZ, Y, bn, bwc, X0, F0, nullptr, d, 0, nullptr, nullptr, nullptr, nullptr, dW_slab,
-      db_slab);
+  if (!Y || !bn || !bwc || !X0 || !dW_slab || !db_slab || p_drop < 0.f || p_drop >= 1.f) return CGNN_EINVAL;
+  if (dP ? (!node_graph || !gptr || (p_drop > 0.f && !mask_cur)) : !dZ) return CGNN_EINVAL;
+  int use_drop;
+  DropCfg d = make_drop(dP ? p_drop : 0.f, 0, &use_drop);
+  PoolIn pin{dP, node_graph, gptr, mask_cur};
+  if (dP)
+    k_gcn_bwd<CGNN_FUSED_MAX_ROWS, true, true><<<fused_grid(), NTHR, 0, cgnn_stream(stream)>>>(
+        *t, pin, dZ, Y, bn, bwc, X0, F0, nullptr, d, use_drop, nullptr, nullptr, nullptr, nullptr,
+        dW_slab, db_slab);
+  else
+    k_gcn_bwd<CGNN_FUSED_MAX_ROWS, true, false><<<fused_grid(), NTHR, 0, cgnn_stream(stream)>>>(
+        *t, pin, dZ, Y, bn, bwc, X0, F0, nullptr, d, use_drop, nullptr, nullptr, nullptr, nullptr,
+        dW_slab, db_slab);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }

@@ -185,20 +185,25 @@ class FusedGCNEncode(torch.autograd.Function):
                 bwc.zero_()      # eval-mode BatchNorm is a fixed affine map: dY = a * dZ
             return bwc
 
+        # the last layer rebuilds its incoming gradient from dP (POOLIN); the readout backward
+        # only supplies the BatchNorm-backward sums (dZ = NULL)
+        pool_args = (_lib.ptr(d_pooled), _lib.ptr(s.node_graph), _lib.ptr(s.gptr), _lib.ptr(c.masks[-1]))
+        none_args = (None, None, None, None)
         with torch.cuda.device(dev):
             _lib.check(lib.cgnn_gcn_fused_pool_bwd(
                 _lib.ptr(d_pooled), _lib.ptr(c.ys[-1]), _lib.ptr(c.bns[-1]), c.p,
-                _lib.ptr(c.masks[-1]), _lib.ptr(s.gptr), B, _lib.ptr(dz), _lib.ptr(s_slab), st()),
+                _lib.ptr(c.masks[-1]), _lib.ptr(s.gptr), B, None, _lib.ptr(s_slab), st()),
                 "cgnn_gcn_fused_pool_bwd")
             bwc = bn_backward(L - 1)
             for l in range(L - 1, 0, -1):
                 w = params[4 * l].contiguous()
+                extra = pool_args if l == L - 1 else none_args
                 with _lib.timed("cgnn_gcn_fused_bwd"):
                     _lib.check(lib.cgnn_gcn_fused_bwd(
                         tp, _lib.ptr(dz), _lib.ptr(c.ys[l]), _lib.ptr(c.bns[l]), _lib.ptr(bwc),
                         _lib.ptr(c.ys[l - 1]), _lib.ptr(c.bns[l - 1]), c.p, _lib.ptr(c.masks[l - 1]),
                         _lib.ptr(w), _lib.ptr(dz_prev), _lib.ptr(s_slab), _lib.ptr(dw_slab),
-                        _lib.ptr(db_slab), st()), "cgnn_gcn_fused_bwd")
+                        _lib.ptr(db_slab), *extra, st()), "cgnn_gcn_fused_bwd")
                 dw, db = torch.empty(HID, HID, **f32), torch.empty(HID, **f32)
                 _lib.check(lib.cgnn_slab_reduce_f32(_lib.ptr(dw_slab), grid, HID, HID, HID,
                                                     _lib.ptr(dw), HID, st()), "cgnn_slab_reduce_f32")
@@ -207,10 +212,11 @@ class FusedGCNEncode(torch.autograd.Function):
                 grads[4 * l], grads[4 * l + 1] = dw, db
                 bwc = bn_backward(l - 1)
                 dz, dz_prev = dz_prev, dz
+            extra = pool_args if L == 1 else none_args
             with _lib.timed("cgnn_gcn_fused_bwd_first"):
                 _lib.check(lib.cgnn_gcn_fused_bwd_first(
                     tp, _lib.ptr(dz), _lib.ptr(c.ys[0]), _lib.ptr(c.bns[0]), _lib.ptr(bwc),
-                    _lib.ptr(c.x0), c.f0, _lib.ptr(dw_slab), _lib.ptr(db_slab), st()),
+                    _lib.ptr(c.x0), c.f0, _lib.ptr(dw_slab), _lib.ptr(db_slab), c.p, *extra, st()),
                     "cgnn_gcn_fused_bwd_first")
             dw0, db0 = torch.empty(HID, c.f0, **f32), torch.empty(HID, **f32)
             _lib.check(lib.cgnn_slab_reduce_f32(_lib.ptr(dw_slab), grid, HID, 16, c.f0,

@@ -67,6 +67,7 @@ class BatchStructure:
         self.max_out_degree = 0
         self.block_diagonal = True
         self.gptr: Optional[torch.Tensor] = None         # int32 [B+1]
+        self.node_graph: Optional[torch.Tensor] = None   # int32 [Nn]
         self.rowptr_dst = self.eid_dst = self.col_dst = None
         self.rowptr_src = self.eid_src = self.col_src = None
         self._edge_index = None
@@ -106,6 +107,8 @@ class BatchStructure:
                 _lib.ptr(s.rowptr_src), _lib.ptr(s.eid_src), _lib.ptr(s.col_src),
                 _lib.ptr(flags), _lib.ptr(ws), _lib.stream_ptr()), "cgnn_csr_build")
             s.gptr = batch.ptr.to(device=dev, dtype=torch.int32)
+            s.node_graph = (node_graph.to(torch.int32) if node_graph is not None
+                            else torch.zeros(nn_, dtype=torch.int32, device=dev))
             f = flags.tolist()                      # one sync per batch, at build time only
             s._ptr_host = batch.ptr.detach().cpu().numpy().astype(np.int64)
             sizes = np.diff(s._ptr_host)

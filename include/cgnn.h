@@ -241,7 +241,8 @@ int cgnn_gcn_fused_pool_fwd(const float* Y, const float* bn, float p_drop, uint6
                             void* stream);
 
 /* Backward of the readout through dropout/ReLU: dZ = dP[g]/(n_g+1e-8) * drop' * relu';
- * also the BatchNorm-backward sums of the last layer: s_slab [grid][128] = sum dZ | sum dZ*xhat. */
+ * also the BatchNorm-backward sums of the last layer: s_slab [grid][128] = sum dZ | sum dZ*xhat.
+ * dZ may be NULL (sums only) when the last layer's backward rebuilds dZ itself (dP != NULL there). */
 int cgnn_gcn_fused_pool_bwd(const float* dP, const float* Y, const float* bn, float p_drop,
                             const uint8_t* mask, const int32_t* gptr, int32_t num_graphs,
                             float* dZ, double* s_slab, void* stream);
@@ -253,15 +254,22 @@ int cgnn_bn_bwd_finalize(const double* sums, double count, float* dgamma, float*
 /* Layer l>0 backward.  Inputs: dZ (grad wrt BN output of layer l), Y (its pre-BN output), bn,
  * bwc; previous layer's Yprev/bn_prev/mask_prev (to rebuild X_l and apply relu'/drop').
  * Outputs: dZprev [Nn,64]; s_slab_prev [grid][128]; dW_slab [grid][64*64]; db_slab [grid][64]. */
+/* Last layer only: pass dP != NULL (then dZ is ignored and may be NULL) together with
+ * node_graph int32 [Nn], gptr int32 [B+1] and mask_cur (this layer's keep bits): the incoming
+ * gradient is rebuilt per row as dP[g]/(n_g+1e-8) * relu' * dropout'.  Otherwise dP = NULL. */
 int cgnn_gcn_fused_bwd(const cgnn_tiles* t, const float* dZ, const float* Y, const float* bn,
                        const float* bwc, const float* Yprev, const float* bn_prev, float p_drop,
                        const uint8_t* mask_prev, const float* W, float* dZprev,
-                       double* s_slab_prev, float* dW_slab, double* db_slab, void* stream);
+                       double* s_slab_prev, float* dW_slab, double* db_slab, const float* dP,
+                       const int32_t* node_graph, const int32_t* gptr, const uint8_t* mask_cur,
+                       void* stream);
 
 /* Layer 0 backward: dW0 = dT^T X0 only.  dW_slab [grid][64*16] (columns >= F0 are zero). */
 int cgnn_gcn_fused_bwd_first(const cgnn_tiles* t, const float* dZ, const float* Y,
                              const float* bn, const float* bwc, const float* X0, int32_t F0,
-                             float* dW_slab, double* db_slab, void* stream);
+                             float* dW_slab, double* db_slab, float p_drop, const float* dP,
+                             const int32_t* node_graph, const int32_t* gptr,
+                             const uint8_t* mask_cur, void* stream);
 
 /* Fixed-order combination of per-workgroup partials (fp64 accumulate):
  * f32 slab [rows][width] -> out[r*ld_out + c] for width = out_rows*out_cols (take the first

@@ -49,7 +49,8 @@ def main():
     ds = generate_packed(min(nb, 512), 360, 14, seed=1).to("cuda")
     b = assemble_batch(ds, torch.arange(nb) % min(nb, 512))
     torch.manual_seed(0)
-    m = C.GCNConnectome(5, 64, impl="fused").to("cuda").train()
+    m = C.GCNConnectome(5, 64, dropout=float(os.environ.get("PROBE_DROPOUT", "0.3")),
+                        impl="fused").to("cuda").train()
     for _ in range(2):
         m(b).sum().backward()
     read(lib)
