@@ -252,10 +252,12 @@ __global__ void __launch_bounds__(NTHR) k_gcn_fwd(
   float* stg = stg_all + wave * STG_FLOATS;
   const uint4* ent = static_cast<const uint4*>(t.ent_dst);
 
-  // B-operand fragments of the projection, resident in registers for the whole kernel.
-  //   generic: B[k][col] = W[col][k], lane (kk=q, jj=j), tile tj <-> col 4j+tj, k = 16q + s
-  //   first  : same with k = 4s + q < F0 (F0 <= 16 -> 4 k-steps)
-  float wreg[4][16];
+  // B operand of the projection: B[k][col] = W[col][k], lane (kk=q, jj=j), tile tj <-> col 4j+tj.
+  //   first  : k = 4s + q < F0 (F0 <= 16 -> 4 k-steps), 16 registers
+  //   generic: k = 16q + s; W^T lives in LDS (one conflict-free ds_read_b128 per k-step) so that
+  //            the registers can hold the NEXT tile's rows while this tile is being processed
+  __shared__ __attribute__((aligned(16))) float Wt[FIRST ? 4 : HID * HID];
+  float wreg[4][4];
   if (FIRST) {
 #pragma unroll
     for (int tj = 0; tj < 4; ++tj)
@@ -265,14 +267,7 @@ __global__ void __launch_bounds__(NTHR) k_gcn_fwd(
         wreg[tj][s] = k < F0 ? W[(4 * j + tj) * F0 + k] : 0.f;
       }
   } else {
-#pragma unroll
-    for (int tj = 0; tj < 4; ++tj)
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float4 v = ld4(W + (4 * j + tj) * HID + 16 * q + 4 * u);
-        wreg[tj][4 * u + 0] = v.x; wreg[tj][4 * u + 1] = v.y;
-        wreg[tj][4 * u + 2] = v.z; wreg[tj][4 * u + 3] = v.w;
-      }
+    for (int i = threadIdx.x; i < HID * HID; i += NTHR) Wt[(i & 63) * HID + (i >> 6)] = W[i];
   }
   const float4 bias4 = ld4(bias + 4 * j);
   float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa;
@@ -282,6 +277,23 @@ __global__ void __launch_bounds__(NTHR) k_gcn_fwd(
   }
   double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
   CGNN_STAMP_DECL
+  // cross-tile prefetch registers: row (tid>>4) + 32u, columns 4j..4j+3 of the next tile
+  constexpr int PF = FIRST ? 1 : MAXR / 32;
+  float4 pfy[PF];
+  float pfd[PF];
+  if (!FIRST && (int)blockIdx.x < t.num_tiles) {
+    const int nb2 = t.tile_ptr[blockIdx.x], nn2 = t.tile_ptr[blockIdx.x + 1] - nb2;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int row = (threadIdx.x >> 4) + 32 * u;
+      pfy[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      pfd[u] = 0.f;
+      if (row < nn2) {
+        pfy[u] = ld4(Xin + (int64_t)(nb2 + row) * HID + 4 * j);
+        pfd[u] = t.dis[nb2 + row];
+      }
+    }
+  }
 
   for (int tid = blockIdx.x; tid < t.num_tiles; tid += gridDim.x) {
     CGNN_STAMP_BEGIN()
@@ -333,44 +345,45 @@ __global__ void __launch_bounds__(NTHR) k_gcn_fwd(
               make_float4(acc[0][r] * dv[r], acc[1][r] * dv[r], acc[2][r] * dv[r], acc[3][r] * dv[r]));
       }
     } else {
-      // UNR rows per thread in flight at once (512 thr x 6 x 16 B = 48 KB per CU outstanding)
-      constexpr int UNR = 6;
-      for (int r0 = threadIdx.x >> 4; r0 < nblk * 16; r0 += 32 * UNR) {
-        float4 yb[UNR];
-        float dv[UNR];
+      // the tile's rows were requested a whole phase B ago (cross-tile register prefetch)
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-          const int row = r0 + 32 * u;
-          yb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-          dv[u] = 0.f;
+      for (int u = 0; u < PF; ++u) {
+        const int row = (threadIdx.x >> 4) + 32 * u;
+        if (row < nblk * 16) {
+          float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
           if (row < n) {
-            yb[u] = ld4(Xin + (int64_t)(base + row) * HID + 4 * j);
-            dv[u] = t.dis[base + row];
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-          const int row = r0 + 32 * u;
-          if (row < nblk * 16) {
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < n) {
-              uint32_t keep = 0xFu;
-              if (use_drop) {
-                keep = drop_bits(drop, (uint32_t)(base + row), (uint32_t)j);
-                if (mask_out) mask_out[(int64_t)(base + row) * 16 + j] = (uint8_t)keep;
-              }
-              float4 f;
-              x = scale4(act4(yb[u], pa, pb, keep, drop.scale, f), dv[u]);
+            uint32_t keep = 0xFu;
+            if (use_drop) {
+              keep = drop_bits(drop, (uint32_t)(base + row), (uint32_t)j);
+              if (mask_out) mask_out[(int64_t)(base + row) * 16 + j] = (uint8_t)keep;
             }
-            st4(tile + row * HID + 4 * j, x);
-            if (j == 0) disl[row] = dv[u];
+            float4 f;
+            x = scale4(act4(pfy[u], pa, pb, keep, drop.scale, f), pfd[u]);
+          }
+          st4(tile + row * HID + 4 * j, x);
+          if (j == 0) disl[row] = pfd[u];
+        }
+      }
+    }
+    __syncthreads();
+    if (!FIRST) {
+      // request the NEXT tile's rows now; they land while this tile is aggregated/projected
+      const int nxt = tid + gridDim.x;
+      if (nxt < t.num_tiles) {
+        const int nb2 = t.tile_ptr[nxt], nn2 = t.tile_ptr[nxt + 1] - nb2;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+          const int row = (threadIdx.x >> 4) + 32 * u;
+          pfy[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          pfd[u] = 0.f;
+          if (row < nn2) {
+            pfy[u] = ld4(Xin + (int64_t)(nb2 + row) * HID + 4 * j);
+            pfd[u] = t.dis[nb2 + row];
           }
         }
       }
     }
-    CGNN_STAMP(0)      // phase A issue+compute
-    __syncthreads();
-    CGNN_STAMP(1)      // phase A barrier wait
+    CGNN_STAMP(1)      // phase A + barrier
 
     // ------------------------------------------------- phase B: aggregate (+ project) blocks
     for (int b = wave; b < nblk; b += NWAVE) {
@@ -413,10 +426,13 @@ __global__ void __launch_bounds__(NTHR) k_gcn_fwd(
       }
       CGNN_STAMP(4)    // staging write + A-fragment read (+ next metadata issue)
 #pragma unroll
-      for (int s = 0; s < 16; ++s)
-#pragma unroll
-        for (int tj = 0; tj < 4; ++tj)
-          acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], wreg[tj][s], acc[tj], 0, 0, 0);
+      for (int s = 0; s < 16; ++s) {
+        const float4 w4 = ld4(Wt + (16 * q + s) * HID + 4 * j);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], w4.x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], w4.y, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], w4.z, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], w4.w, acc[3], 0, 0, 0);
+      }
       __builtin_amdgcn_wave_barrier();
 #ifdef CGNN_STAMPS
       asm volatile("" ::"v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]));
@@ -796,14 +812,16 @@ __global__ void __launch_bounds__(PTHR) k_pool_fwd(const float* __restrict__ Y,
   }
 }
 
-__global__ void __launch_bounds__(PTHR) k_pool_bwd(const float* __restrict__ dP,
+constexpr int PBTHR = 1024;  // readout backward: 64 row-lanes x 16 chunks (16 waves per CU)
+
+__global__ void __launch_bounds__(PBTHR) k_pool_bwd(const float* __restrict__ dP,
                                                    const float* __restrict__ Y,
                                                    const float* __restrict__ bn, DropCfg drop,
                                                    int use_drop, const uint8_t* __restrict__ mask,
                                                    const int32_t* __restrict__ gptr, int B,
                                                    float* __restrict__ dZ,
                                                    double* __restrict__ s_slab) {
-  __shared__ double red[16 * 128];
+  __shared__ double red[(PBTHR / 16) * 128];
   const int j = threadIdx.x & 15, rr = threadIdx.x >> 4;
   const float4 a = ld4(bn + 4 * j), b = ld4(bn + HID + 4 * j);
   const float4 mean = ld4(bn + 2 * HID + 4 * j), is = ld4(bn + 3 * HID + 4 * j);
@@ -813,17 +831,35 @@ __global__ void __launch_bounds__(PTHR) k_pool_bwd(const float* __restrict__ dP,
     const float inv = 1.0f / ((float)(rend - rbeg) + 1e-8f);
     float4 gp = ld4(dP + (int64_t)g * HID + 4 * j);
     gp.x *= inv; gp.y *= inv; gp.z *= inv; gp.w *= inv;
-    for (int row = rbeg + rr; row < rend; row += 16) {
-      const float4 y = ld4(Y + (int64_t)row * HID + 4 * j);
-      uint32_t keep = 0xFu;
-      if (use_drop) keep = mask[(int64_t)row * 16 + j];
-      float4 f;
-      act4(y, a, b, keep, drop.scale, f);
-      const float4 dz = make_float4(gp.x * f.x, gp.y * f.y, gp.z * f.z, gp.w * f.w);
-      if (dZ) st4(dZ + (int64_t)row * HID + 4 * j, dz);
-      s1[0] += dz.x; s1[1] += dz.y; s1[2] += dz.z; s1[3] += dz.w;
-      s2[0] += (double)dz.x * ((y.x - mean.x) * is.x); s2[1] += (double)dz.y * ((y.y - mean.y) * is.y);
-      s2[2] += (double)dz.z * ((y.z - mean.z) * is.z); s2[3] += (double)dz.w * ((y.w - mean.w) * is.w);
+    constexpr int U = 3;                       // rows in flight per thread
+    constexpr int RS = PBTHR / 16;             // row stride
+    for (int row0 = rbeg + rr; row0 < rend; row0 += RS * U) {
+      float4 yb[U];
+      uint32_t kb[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int row = row0 + RS * u;
+        yb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        kb[u] = 0u;
+        if (row < rend) {
+          yb[u] = ld4(Y + (int64_t)row * HID + 4 * j);
+          kb[u] = use_drop ? mask[(int64_t)row * 16 + j] : 0xFu;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int row = row0 + RS * u;
+        if (row < rend) {
+          const float4 y = yb[u];
+          float4 f;
+          act4(y, a, b, kb[u], drop.scale, f);
+          const float4 dz = make_float4(gp.x * f.x, gp.y * f.y, gp.z * f.z, gp.w * f.w);
+          if (dZ) st4(dZ + (int64_t)row * HID + 4 * j, dz);
+          s1[0] += dz.x; s1[1] += dz.y; s1[2] += dz.z; s1[3] += dz.w;
+          s2[0] += (double)dz.x * ((y.x - mean.x) * is.x); s2[1] += (double)dz.y * ((y.y - mean.y) * is.y);
+          s2[2] += (double)dz.z * ((y.z - mean.z) * is.z); s2[3] += (double)dz.w * ((y.w - mean.w) * is.w);
+        }
+      }
     }
   }
 #pragma unroll
@@ -834,8 +870,7 @@ __global__ void __launch_bounds__(PTHR) k_pool_bwd(const float* __restrict__ dP,
   __syncthreads();
   if (threadIdx.x < 128) {
     double tot = 0.0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) tot += red[k * 128 + threadIdx.x];
+    for (int k = 0; k < PBTHR / 16; ++k) tot += red[k * 128 + threadIdx.x];
     s_slab[(int64_t)blockIdx.x * 128 + threadIdx.x] = tot;
   }
 }
@@ -1017,7 +1052,7 @@ int cgnn_gcn_fused_pool_bwd(const float* dP, const float* Y, const float* bn, fl
   int use_drop;
   DropCfg d = make_drop(p_drop, 0, &use_drop);
   // exactly cgnn_fused_grid() workgroups so that the slab has the documented row count
-  k_pool_bwd<<<fused_grid(), PTHR, 0, cgnn_stream(stream)>>>(dP, Y, bn, d, use_drop, mask, gptr,
+  k_pool_bwd<<<fused_grid(), PBTHR, 0, cgnn_stream(stream)>>>(dP, Y, bn, d, use_drop, mask, gptr,
                                                              num_graphs, dZ, s_slab);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
