@@ -136,7 +136,7 @@ __device__ __forceinline__ MetaRegs meta_issue(const uint4* __restrict__ mp, int
   return m;
 }
 
-#define CGNN_BC(v, S) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x150 + (S), 0xf, 0xf, false))
+#define CGNN_BC(v, S) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x150 + (S), 0xf, 0xf, true))
 // One step, unconditional: entries past the block's width are (offset 0, weight 0).
 #define CGNN_AGG_STEP(M0, M1, S)                                                            \
   {                                                                                         \

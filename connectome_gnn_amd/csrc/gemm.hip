@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(256) k_linear_bwd_input(
 // partial[chunk][n][k] = sum_{m in chunk} dY[m][n] * X[m][k]
 // Block: 4 waves, output tile 64(n) x 64(k); wave w owns the 32x32 tile (w>>1, w&1).
 constexpr int MT = 32;           // rows of M staged per step
-constexpr int WCHUNK = 2048;     // rows of M per block
+constexpr int WCHUNK = 512;      // rows of M per block (many blocks: M is the only big dim)
 constexpr int LDM = 64 + 4;      // row stride of the staged [MT][64] tiles (16-B aligned rows)
 
 __global__ void __launch_bounds__(256) k_linear_bwd_weight(
@@ -213,18 +213,31 @@ __global__ void __launch_bounds__(256) k_linear_bwd_weight(
   }
 }
 
-__global__ void k_reduce_slab(const float* __restrict__ slab, int64_t nchunks, int64_t elems,
-                              float* __restrict__ dW, int ldw, int kcol0, int K) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= elems) return;
+// 16 threads per output element walk the chunk dimension (fixed assignment -> deterministic),
+// then a fixed-order shuffle tree; coalesced across elements.
+__global__ void __launch_bounds__(256) k_reduce_slab(const float* __restrict__ slab,
+                                                     int64_t nchunks, int64_t elems,
+                                                     float* __restrict__ dW, int ldw, int kcol0,
+                                                     int K) {
+  const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x & 15);
+  const int part = threadIdx.x >> 4;           // 0..15
   double s = 0.0;
-  for (int64_t c = 0; c < nchunks; ++c) s += (double)slab[c * elems + i];
-  const int64_t n = i / K, k = i % K;
-  dW[n * ldw + kcol0 + k] = (float)s;
+  if (i < elems)
+    for (int64_t c = part; c < nchunks; c += 16) s += (double)slab[c * elems + i];
+  __shared__ double red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (part == 0 && i < elems) {
+    double t = 0.0;
+#pragma unroll
+    for (int p2 = 0; p2 < 16; ++p2) t += red[p2 * 16 + (threadIdx.x & 15)];
+    const int64_t n = i / K, k = i % K;
+    dW[n * ldw + kcol0 + k] = (float)t;
+  }
 }
 
 // ------------------------------------------------------------------------------- column sums
-constexpr int CS_ROWS = 4096;    // rows per block
+constexpr int CS_ROWS = 512;     // rows per block
 
 __global__ void __launch_bounds__(256) k_colsum_partial(const float* __restrict__ A, int64_t lda,
                                                         int64_t M, int N,
@@ -236,10 +249,17 @@ __global__ void __launch_bounds__(256) k_colsum_partial(const float* __restrict_
     const int nc = min(256, N - c0);
     const int rpi = 256 / nc;                 // rows handled per iteration
     const int c = threadIdx.x % nc, rr = threadIdx.x / nc;
-    double s = 0.0;
-    if (rr < rpi)
-      for (int64_t r = rbeg + rr; r < rend; r += rpi) s += (double)A[r * lda + c0 + c];
-    red[threadIdx.x] = s;
+    float sf = 0.f;                            // <= CS_ROWS/rpi terms per thread
+    if (rr < rpi) {
+      int64_t r = rbeg + rr;
+      for (; r + 3 * rpi < rend; r += 4 * rpi) {   // 4 independent loads in flight
+        const float v0 = A[r * lda + c0 + c], v1 = A[(r + rpi) * lda + c0 + c];
+        const float v2 = A[(r + 2 * rpi) * lda + c0 + c], v3 = A[(r + 3 * rpi) * lda + c0 + c];
+        sf += (v0 + v1) + (v2 + v3);
+      }
+      for (; r < rend; r += rpi) sf += A[r * lda + c0 + c];
+    }
+    red[threadIdx.x] = (double)sf;
     __syncthreads();
     if (threadIdx.x < nc) {
       double t = 0.0;
@@ -250,13 +270,23 @@ __global__ void __launch_bounds__(256) k_colsum_partial(const float* __restrict_
   }
 }
 
-__global__ void k_colsum_final(const double* __restrict__ slab, int64_t nblocks, int N,
-                               float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= N) return;
+__global__ void __launch_bounds__(256) k_colsum_final(const double* __restrict__ slab,
+                                                      int64_t nblocks, int N,
+                                                      float* __restrict__ out) {
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+  const int part = threadIdx.x >> 4;
   double s = 0.0;
-  for (int64_t b = 0; b < nblocks; ++b) s += slab[b * N + c];
-  out[c] = (float)s;
+  if (c < N)
+    for (int64_t b = part; b < nblocks; b += 16) s += slab[b * N + c];
+  __shared__ double red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (part == 0 && c < N) {
+    double t = 0.0;
+#pragma unroll
+    for (int p2 = 0; p2 < 16; ++p2) t += red[p2 * 16 + (threadIdx.x & 15)];
+    out[c] = (float)t;
+  }
 }
 
 }  // namespace
@@ -314,7 +344,7 @@ int cgnn_linear_bwd_weight_f32(const float* dY, int64_t lddy, const float* X, in
     CGNN_CHECK_LAUNCH();
   }
   const int64_t elems = (int64_t)N * K;
-  k_reduce_slab<<<(unsigned)((elems + 255) / 256), 256, 0, st>>>(static_cast<float*>(slab), nchunks,
+  k_reduce_slab<<<(unsigned)((elems + 15) / 16), 256, 0, st>>>(static_cast<float*>(slab), nchunks,
                                                                  elems, dW, ldw, k0, K);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
@@ -337,7 +367,7 @@ int cgnn_colsum_f32(const float* A, int64_t lda, float* out, int64_t M, int32_t 
     k_colsum_partial<<<(unsigned)nb, 256, 0, st>>>(A, lda, M, N, static_cast<double*>(slab));
     CGNN_CHECK_LAUNCH();
   }
-  k_colsum_final<<<(N + 255) / 256, 256, 0, st>>>(static_cast<double*>(slab), nb, N, out);
+  k_colsum_final<<<(N + 15) / 16, 256, 0, st>>>(static_cast<double*>(slab), nb, N, out);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }
