@@ -1,0 +1,240 @@
+// fused_gcn_l0.hip -- layer 0 of the fused GCN path, specialised for narrow input features.
+//
+// The reference evaluates every layer as  A_hat (X W^T) + b  (models.py:111-114).  For layer 0
+// the input has F0 = 5 columns, so by associativity
+//       Y0  = (A_hat X0) W0^T + b            dW0 = dY0^T (A_hat X0)
+// only the NARROW aggregate P0 = A_hat X0 ([Nn, F0], 8x less LDS traffic than a 64-wide one) is
+// ever needed; it is computed once in forward and kept (32 bytes per node).  The layer-0
+// backward then needs no aggregation at all: it is a streaming reduction over (dY0, P0).
+//
+//   k_l0_fwd : per tile, X0*dis -> LDS [rows][8]; one thread per destination row walks its
+//              blocked-ELL entries; P0 -> LDS + HBM; Y0 = P0 W0^T + b on the vector ALUs
+//              (5 FMAs per output) with float4 stores; BatchNorm sums in the epilogue.
+//              25 KB of LDS per workgroup -> 6 workgroups per CU hide the gather latency.
+//   k_l0_bwd : dY0 = BatchNorm'(dZ0); dW0 += dY0^T P0; db0 += dY0  (no LDS tile, no metadata).
+#include "common.h"
+
+namespace {
+
+constexpr int HID = CGNN_FUSED_HIDDEN;
+constexpr int FP = 8;                 // padded feature count (F0 <= 8)
+constexpr int MAXR = CGNN_FUSED_MAX_ROWS;
+constexpr int L0THR = 384;            // forward: one thread per row of a <=384-row tile
+constexpr int L0BTHR = 256;           // backward (streaming)
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+
+__global__ void __launch_bounds__(L0THR, 5) k_l0_fwd(cgnn_tiles t, const float* __restrict__ X0, int F0,
+                                                  const float* __restrict__ W0,
+                                                  const float* __restrict__ bias,
+                                                  float* __restrict__ P0, float* __restrict__ Y,
+                                                  double* __restrict__ stat_slab) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * MAXR * FP];   // 24 KB -> 6 WGs per CU
+  float* xs = smem;
+  float* ps = smem + MAXR * FP;
+  double* red = reinterpret_cast<double*>(smem);                      // reused after the loop
+  const int j = threadIdx.x & 15, rr = threadIdx.x >> 4;       // rr in [0, 24)
+  const uint2* ent = static_cast<const uint2*>(t.ent_dst);
+  // W0^T in LDS: wl[k][col] = W0[col][k] (zero for k >= F0); occupancy matters more here than
+  // 32 registers of weights (the row gather is hidden by many resident waves, not by ILP)
+  __shared__ __attribute__((aligned(16))) float wl[FP * HID];
+  for (int i = threadIdx.x; i < FP * HID; i += L0THR) {
+    const int k = i >> 6, c = i & 63;
+    wl[i] = k < F0 ? W0[c * F0 + k] : 0.f;
+  }
+  const float4 b4 = ld4(bias + 4 * j);
+  // per-thread partial sums stay fp32 (a thread sees <= ~16 rows per tile, a few tiles); the
+  // cross-thread / cross-workgroup combination is fp64
+  float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+
+  for (int tid = blockIdx.x; tid < t.num_tiles; tid += gridDim.x) {
+    const int base = t.tile_ptr[tid];
+    const int n = t.tile_ptr[tid + 1] - base;
+    const int gb0 = t.tile_blk[tid];
+    // 1. dis * X0 -> LDS (zero-padded to 8 columns)
+    {
+      constexpr int NI = MAXR * FP / L0THR;            // 8 elements per thread, all loads first
+      float xv[NI], dvv[NI];
+#pragma unroll
+      for (int u = 0; u < NI; ++u) {
+        const int idx = threadIdx.x + L0THR * u, r = idx >> 3, k = idx & 7;
+        xv[u] = dvv[u] = 0.f;
+        if (r < n && k < F0) {
+          xv[u] = X0[(int64_t)(base + r) * F0 + k];
+          dvv[u] = t.dis[base + r];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NI; ++u) xs[threadIdx.x + L0THR * u] = xv[u] * dvv[u];
+    }
+    __syncthreads();
+    // 2. narrow aggregate, one thread per destination row (entries of 16 rows are contiguous)
+    for (int r = threadIdx.x; r < n; r += L0THR) {
+      const int b = r >> 4, i = r & 15;
+      const int off0 = t.blk_off_dst[gb0 + b];
+      const int width = (t.blk_off_dst[gb0 + b + 1] - off0) >> 4;
+      float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+      const uint2* e = ent + off0 + i;
+      // entries stream from HBM: fetch EB steps at a time (independent loads), then consume
+      constexpr int EB = 6;
+      for (int s0 = 0; s0 < width; s0 += EB) {
+        uint2 eb[EB];
+#pragma unroll
+        for (int u = 0; u < EB; ++u) eb[u] = s0 + u < width ? e[16 * (s0 + u)] : make_uint2(0u, 0u);
+#pragma unroll
+        for (int u = 0; u < EB; ++u) {
+          const float w = __uint_as_float(eb[u].y);          // padding: weight 0, row 0
+          const float* src = xs + (eb[u].x >> 8) * FP;       // entry offset = 256 * local row
+          const float4 v0 = ld4(src), v1 = ld4(src + 4);
+          a0.x = fmaf(w, v0.x, a0.x); a0.y = fmaf(w, v0.y, a0.y); a0.z = fmaf(w, v0.z, a0.z); a0.w = fmaf(w, v0.w, a0.w);
+          a1.x = fmaf(w, v1.x, a1.x); a1.y = fmaf(w, v1.y, a1.y); a1.z = fmaf(w, v1.z, a1.z); a1.w = fmaf(w, v1.w, a1.w);
+        }
+      }
+      const float dv = t.dis[base + r];
+      a0 = make_float4(a0.x * dv, a0.y * dv, a0.z * dv, a0.w * dv);
+      a1 = make_float4(a1.x * dv, a1.y * dv, a1.z * dv, a1.w * dv);
+      st4(ps + r * FP, a0); st4(ps + r * FP + 4, a1);
+      st4(P0 + (int64_t)(base + r) * FP, a0); st4(P0 + (int64_t)(base + r) * FP + 4, a1);
+    }
+    __syncthreads();
+    // 3. Y0 = P0 W0^T + b: thread (row rr + 16*it, columns 4j..4j+3)
+    for (int r = rr; r < n; r += L0THR / 16) {
+      const float4 p0 = ld4(ps + r * FP), p1 = ld4(ps + r * FP + 4);
+      const float pv[FP] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+      float4 y = b4;
+#pragma unroll
+      for (int k = 0; k < FP; ++k) {
+        const float4 wk = ld4(wl + k * HID + 4 * j);
+        y.x = fmaf(pv[k], wk.x, y.x); y.y = fmaf(pv[k], wk.y, y.y);
+        y.z = fmaf(pv[k], wk.z, y.z); y.w = fmaf(pv[k], wk.w, y.w);
+      }
+      st4(Y + (int64_t)(base + r) * HID + 4 * j, y);
+      s1[0] += y.x; s1[1] += y.y; s1[2] += y.z; s1[3] += y.w;
+      s2[0] = fmaf(y.x, y.x, s2[0]); s2[1] = fmaf(y.y, y.y, s2[1]);
+      s2[2] = fmaf(y.z, y.z, s2[2]); s2[3] = fmaf(y.w, y.w, s2[3]);
+    }
+    __syncthreads();
+  }
+  if (stat_slab) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      red[rr * 128 + 4 * j + i] = (double)s1[i];
+      red[rr * 128 + 64 + 4 * j + i] = (double)s2[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      double tot = 0.0;
+#pragma unroll
+      for (int k = 0; k < L0THR / 16; ++k) tot += red[k * 128 + threadIdx.x];
+      stat_slab[(int64_t)blockIdx.x * 128 + threadIdx.x] = tot;
+    }
+  }
+}
+
+// dW0[o][k] = sum_rows dY0[row][o] * P0[row][k];  db0[o] = sum_rows dY0[row][o]
+__global__ void __launch_bounds__(L0BTHR) k_l0_bwd(const float* __restrict__ dZ,
+                                                  const float* __restrict__ Y,
+                                                  const float* __restrict__ bn,
+                                                  const float* __restrict__ bwc,
+                                                  const float* __restrict__ P0, int64_t nn,
+                                                  float* __restrict__ dW_slab,
+                                                  double* __restrict__ db_slab) {
+  __shared__ float redw[16 * HID * FP];          // 32 KB
+  __shared__ double redb[16 * HID];
+  const int j = threadIdx.x & 15, rr = threadIdx.x >> 4;
+  const float4 ca = ld4(bn + 4 * j), cmean = ld4(bn + 2 * HID + 4 * j), cis = ld4(bn + 3 * HID + 4 * j);
+  const float4 c1 = ld4(bwc + 4 * j), c2 = ld4(bwc + HID + 4 * j);
+  float dw[4][FP];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int k = 0; k < FP; ++k) dw[c][k] = 0.f;
+  float db[4] = {0.f, 0.f, 0.f, 0.f};
+  constexpr int U = 4;                           // rows in flight per thread
+  const int64_t stride = (int64_t)gridDim.x * 16;
+  for (int64_t row0 = (int64_t)blockIdx.x * 16 + rr; row0 < nn; row0 += stride * U) {
+    float4 zb[U], yb[U], pa[U], pb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = row0 + stride * u;
+      zb[u] = yb[u] = pa[u] = pb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < nn) {
+        zb[u] = ld4(dZ + row * HID + 4 * j);
+        yb[u] = ld4(Y + row * HID + 4 * j);
+        pa[u] = ld4(P0 + row * FP);
+        pb[u] = ld4(P0 + row * FP + 4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = row0 + stride * u;
+      if (row < nn) {
+        const float4 dz = zb[u], y = yb[u];
+        const float dy[4] = {ca.x * (dz.x - c1.x - (y.x - cmean.x) * cis.x * c2.x),
+                             ca.y * (dz.y - c1.y - (y.y - cmean.y) * cis.y * c2.y),
+                             ca.z * (dz.z - c1.z - (y.z - cmean.z) * cis.z * c2.z),
+                             ca.w * (dz.w - c1.w - (y.w - cmean.w) * cis.w * c2.w)};
+        const float pv[FP] = {pa[u].x, pa[u].y, pa[u].z, pa[u].w, pb[u].x, pb[u].y, pb[u].z, pb[u].w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          db[c] += dy[c];
+#pragma unroll
+          for (int k = 0; k < FP; ++k) dw[c][k] = fmaf(dy[c], pv[k], dw[c][k]);
+        }
+      }
+    }
+  }
+  // reduce over the 16 row-lanes that share a column chunk (fixed order)
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    redb[rr * HID + 4 * j + c] = (double)db[c];
+#pragma unroll
+    for (int k = 0; k < FP; ++k) redw[(rr * HID + 4 * j + c) * FP + k] = dw[c][k];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < HID * FP; e += L0BTHR) {
+    double tot = 0.0;
+#pragma unroll
+    for (int r2 = 0; r2 < 16; ++r2) tot += (double)redw[r2 * HID * FP + e];
+    dW_slab[(int64_t)blockIdx.x * HID * FP + e] = (float)tot;
+  }
+  if (threadIdx.x < HID) {
+    double tot = 0.0;
+#pragma unroll
+    for (int r2 = 0; r2 < 16; ++r2) tot += redb[r2 * HID + threadIdx.x];
+    db_slab[(int64_t)blockIdx.x * HID + threadIdx.x] = tot;
+  }
+}
+
+int l0_grid() { return 8 * cgnn_fused_grid(); }     // workgroups (= slab rows) of both kernels
+
+}  // namespace
+
+extern "C" {
+
+int cgnn_l0_grid(void) { return l0_grid(); }
+
+int cgnn_gcn_l0_fwd(const cgnn_tiles* t, const float* X0, int32_t F0, const float* W0,
+                    const float* bias, float* P0, float* Y, double* stat_slab, void* stream) {
+  if (!t || F0 <= 0 || F0 > FP || t->max_tile_rows > CGNN_FUSED_MAX_ROWS) return t && F0 > FP ? CGNN_EUNSUPPORTED : CGNN_EINVAL;
+  if (t->num_tiles == 0) return CGNN_OK;
+  if (!X0 || !W0 || !bias || !P0 || !Y || !t->tile_ptr || !t->tile_blk || !t->blk_off_dst ||
+      !t->ent_dst || !t->dis)
+    return CGNN_EINVAL;
+  k_l0_fwd<<<l0_grid(), L0THR, 0, cgnn_stream(stream)>>>(*t, X0, F0, W0, bias, P0, Y, stat_slab);
+  CGNN_CHECK_LAUNCH();
+  return CGNN_OK;
+}
+
+int cgnn_gcn_l0_bwd(const float* dZ, const float* Y, const float* bn, const float* bwc,
+                    const float* P0, int64_t num_nodes, float* dW_slab, double* db_slab,
+                    void* stream) {
+  if (num_nodes < 0 || !dZ || !Y || !bn || !bwc || !P0 || !dW_slab || !db_slab) return CGNN_EINVAL;
+  k_l0_bwd<<<l0_grid(), L0BTHR, 0, cgnn_stream(stream)>>>(dZ, Y, bn, bwc, P0, num_nodes, dW_slab, db_slab);
+  CGNN_CHECK_LAUNCH();
+  return CGNN_OK;
+}
+
+}  // extern "C"

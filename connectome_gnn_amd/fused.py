@@ -58,7 +58,7 @@ def _tiles_struct(s: BatchStructure, meta, dis: torch.Tensor):
 
 class _Ctx:
     """Everything of one forward pass that backward needs and autograd must not track."""
-    __slots__ = ("s", "meta", "dis", "tiles", "grid", "ys", "bns", "masks", "p", "x0", "f0",
+    __slots__ = ("s", "meta", "dis", "tiles", "grid", "ys", "bns", "masks", "p", "x0", "f0", "p0",
                  "count", "sync_group", "num_layers", "training")
 
 
@@ -97,12 +97,24 @@ class FusedGCNEncode(torch.autograd.Function):
         bns: List[torch.Tensor] = []
         masks: List[Optional[torch.Tensor]] = []
         local_count = count = float(nn_)
+        narrow0 = L >= 2 and x0.shape[1] <= 8      # layer-0 narrow form (fused_gcn_l0.hip)
+        p0 = None
         st = _lib.stream_ptr
         with torch.cuda.device(dev):
             for l in range(L):
                 w, b, gamma, beta = (t.contiguous() for t in params[4 * l:4 * l + 4])
                 y = torch.empty(nn_, HID, **f32)
-                if l == 0:
+                slab, slab_rows = stat_slab, grid
+                if l == 0 and narrow0:
+                    # layer 0, narrow form: Y0 = (A_hat X0) W0^T + b, P0 = A_hat X0 kept
+                    p0 = torch.empty(nn_, 8, **f32)
+                    slab_rows = lib.cgnn_l0_grid()
+                    slab = torch.empty(slab_rows, 128, dtype=torch.float64, device=dev) if training else None
+                    with _lib.timed("cgnn_gcn_l0_fwd"):
+                        _lib.check(lib.cgnn_gcn_l0_fwd(
+                            tp, _lib.ptr(x0), x0.shape[1], _lib.ptr(w), _lib.ptr(b), _lib.ptr(p0),
+                            _lib.ptr(y), _lib.ptr(slab), st()), "cgnn_gcn_l0_fwd")
+                elif l == 0:
                     with _lib.timed("cgnn_gcn_fused_fwd_first"):
                         _lib.check(lib.cgnn_gcn_fused_fwd_first(
                             tp, _lib.ptr(x0), x0.shape[1], _lib.ptr(w), _lib.ptr(b), _lib.ptr(y),
@@ -120,7 +132,7 @@ class FusedGCNEncode(torch.autograd.Function):
                 bn = torch.empty(4 * HID, **f32)
                 cnt = count
                 if training:
-                    _lib.check(lib.cgnn_bn_reduce(_lib.ptr(stat_slab), grid, 128, _lib.ptr(sums), st()),
+                    _lib.check(lib.cgnn_bn_reduce(_lib.ptr(slab), slab_rows, 128, _lib.ptr(sums), st()),
                                "cgnn_bn_reduce")
                     if sync_group is not None:
                         cnt = _sync_sums(sums, local_count, sync_group)
@@ -143,7 +155,7 @@ class FusedGCNEncode(torch.autograd.Function):
             masks.append(mask)
         c = _Ctx()
         c.s, c.meta, c.dis, c.tiles, c.grid = s, fmeta, dis, tiles, grid
-        c.ys, c.bns, c.masks, c.p, c.x0, c.f0 = ys, bns, masks, p, x0, x0.shape[1]
+        c.ys, c.bns, c.masks, c.p, c.x0, c.f0, c.p0 = ys, bns, masks, p, x0, x0.shape[1], p0
         c.count, c.sync_group, c.num_layers, c.training = count, sync_group, L, training
         ctx.c = c
         ctx.save_for_backward(*params)
@@ -212,17 +224,32 @@ class FusedGCNEncode(torch.autograd.Function):
                 grads[4 * l], grads[4 * l + 1] = dw, db
                 bwc = bn_backward(l - 1)
                 dz, dz_prev = dz_prev, dz
-            extra = pool_args if L == 1 else none_args
-            with _lib.timed("cgnn_gcn_fused_bwd_first"):
-                _lib.check(lib.cgnn_gcn_fused_bwd_first(
-                    tp, _lib.ptr(dz), _lib.ptr(c.ys[0]), _lib.ptr(c.bns[0]), _lib.ptr(bwc),
-                    _lib.ptr(c.x0), c.f0, _lib.ptr(dw_slab), _lib.ptr(db_slab), c.p, *extra, st()),
-                    "cgnn_gcn_fused_bwd_first")
             dw0, db0 = torch.empty(HID, c.f0, **f32), torch.empty(HID, **f32)
-            _lib.check(lib.cgnn_slab_reduce_f32(_lib.ptr(dw_slab), grid, HID, 16, c.f0,
-                                                _lib.ptr(dw0), c.f0, st()), "cgnn_slab_reduce_f32")
-            _lib.check(lib.cgnn_slab_reduce_f64(_lib.ptr(db_slab), grid, HID, _lib.ptr(db0), st()),
-                       "cgnn_slab_reduce_f64")
+            if c.p0 is not None:
+                # dW0 = dY0^T P0, db0 = sum dY0: streaming, no aggregation (fused_gcn_l0.hip)
+                g0 = lib.cgnn_l0_grid()
+                dw_slab0 = torch.empty(g0, HID * 8, **f32)
+                db_slab0 = torch.empty(g0, HID, **f64)
+                with _lib.timed("cgnn_gcn_l0_bwd"):
+                    _lib.check(lib.cgnn_gcn_l0_bwd(
+                        _lib.ptr(dz), _lib.ptr(c.ys[0]), _lib.ptr(c.bns[0]), _lib.ptr(bwc),
+                        _lib.ptr(c.p0), nn_, _lib.ptr(dw_slab0), _lib.ptr(db_slab0), st()),
+                        "cgnn_gcn_l0_bwd")
+                _lib.check(lib.cgnn_slab_reduce_f32(_lib.ptr(dw_slab0), g0, HID, 8, c.f0,
+                                                    _lib.ptr(dw0), c.f0, st()), "cgnn_slab_reduce_f32")
+                _lib.check(lib.cgnn_slab_reduce_f64(_lib.ptr(db_slab0), g0, HID, _lib.ptr(db0), st()),
+                           "cgnn_slab_reduce_f64")
+            else:
+                extra = pool_args if L == 1 else none_args
+                with _lib.timed("cgnn_gcn_fused_bwd_first"):
+                    _lib.check(lib.cgnn_gcn_fused_bwd_first(
+                        tp, _lib.ptr(dz), _lib.ptr(c.ys[0]), _lib.ptr(c.bns[0]), _lib.ptr(bwc),
+                        _lib.ptr(c.x0), c.f0, _lib.ptr(dw_slab), _lib.ptr(db_slab), c.p, *extra, st()),
+                        "cgnn_gcn_fused_bwd_first")
+                _lib.check(lib.cgnn_slab_reduce_f32(_lib.ptr(dw_slab), grid, HID, 16, c.f0,
+                                                    _lib.ptr(dw0), c.f0, st()), "cgnn_slab_reduce_f32")
+                _lib.check(lib.cgnn_slab_reduce_f64(_lib.ptr(db_slab), grid, HID, _lib.ptr(db0), st()),
+                           "cgnn_slab_reduce_f64")
             grads[0], grads[1] = dw0, db0
         ctx.c = None
         return (None, None, *grads)

@@ -271,6 +271,18 @@ int cgnn_gcn_fused_bwd_first(const cgnn_tiles* t, const float* dZ, const float* 
                              const int32_t* node_graph, const int32_t* gptr,
                              const uint8_t* mask_cur, void* stream);
 
+/* Layer 0, narrow form (F0 <= 8): Y0 = (A_hat X0) W0^T + b with P0 = A_hat X0 kept for backward
+ * ([Nn,8] fp32, columns >= F0 zero); dW0 = dY0^T P0, db0 = sum dY0 need no aggregation.
+ * Slabs have cgnn_l0_grid() rows: stat_slab [..][128] fp64, dW_slab [..][64*8] f32,
+ * db_slab [..][64] fp64.  (cgnn_gcn_fused_fwd_first/bwd_first remain for 8 < F0 <= 16 and for
+ * one-layer models.) */
+int cgnn_l0_grid(void);
+int cgnn_gcn_l0_fwd(const cgnn_tiles* t, const float* X0, int32_t F0, const float* W0,
+                    const float* bias, float* P0, float* Y, double* stat_slab, void* stream);
+int cgnn_gcn_l0_bwd(const float* dZ, const float* Y, const float* bn, const float* bwc,
+                    const float* P0, int64_t num_nodes, float* dW_slab, double* db_slab,
+                    void* stream);
+
 /* Fixed-order combination of per-workgroup partials (fp64 accumulate):
  * f32 slab [rows][width] -> out[r*ld_out + c] for width = out_rows*out_cols (take the first
  * `take_cols` of every `out_cols` columns); f64 slab [rows][width] -> f32 out [width]. */
