@@ -67,6 +67,9 @@ PROTOTYPES = {
     "cgnn_bn_bwd_finalize": (c_int, [P, F64, P, P, P, P]),
     "cgnn_gcn_fused_bwd": (c_int, [TP, P, P, P, P, P, P, F32, P, P, P, P, P, P, P, P, P, P, P]),
     "cgnn_gcn_fused_bwd_first": (c_int, [TP, P, P, P, P, P, I32, P, P, F32, P, P, P, P, P]),
+    "cgnn_bn_stats_finalize": (c_int, [P, I32, F64, P, P, P, P, F32, F32, P, P, P]),
+    "cgnn_bn_bwd_stats_finalize": (c_int, [P, I32, F64, I32, P, P, P, P]),
+    "cgnn_dw_db_reduce": (c_int, [P, P, I32, I32, I32, P, I32, P, P]),
     "cgnn_l0_grid": (c_int, []),
     "cgnn_gcn_l0_fwd": (c_int, [TP, P, I32, P, P, P, P, P, P]),
     "cgnn_gcn_l0_bwd": (c_int, [P, P, P, P, P, I64, P, P, P]),

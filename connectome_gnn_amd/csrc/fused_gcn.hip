@@ -938,6 +938,97 @@ __global__ void k_bn_bwd_finalize(const double* __restrict__ sums, double count,
   bwc[HID + c] = (float)(sums[HID + c] / count);
 }
 
+// ---- merged "reduce the per-workgroup partials + finalise" kernels (single-GPU fast path) ----
+// Block-wide fixed-order sum of v over 256 threads (4 waves).
+__device__ __forceinline__ double block_sum256(double v, double* sh) {
+  v = cgnn_wave_sum(v);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const double t = sh[0] + sh[1] + sh[2] + sh[3];
+  __syncthreads();
+  return t;
+}
+
+// one block per channel c: S1 = sum_r slab[r][c], S2 = sum_r slab[r][64+c], then finalise
+__global__ void __launch_bounds__(256) k_bn_fwd_stats(
+    const double* __restrict__ slab, int rows, double count, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+    float momentum, float eps, long long* __restrict__ tracked, float* __restrict__ bn_out) {
+  __shared__ double sh[4];
+  const int c = blockIdx.x;
+  double a1 = 0.0, a2 = 0.0;
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    a1 += slab[(int64_t)r * 128 + c];
+    a2 += slab[(int64_t)r * 128 + HID + c];
+  }
+  const double S1 = block_sum256(a1, sh), S2 = block_sum256(a2, sh);
+  if (threadIdx.x == 0) {
+    const double m = S1 / count;
+    double v = S2 / count - m * m;
+    if (v < 0.0) v = 0.0;
+    const float mean = (float)m, var = (float)v;
+    const double unbiased = count > 1.0 ? v * count / (count - 1.0) : v;
+    rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean;
+    rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (float)unbiased;
+    const float invstd = 1.0f / sqrtf(var + eps);
+    const float a = gamma[c] * invstd;
+    bn_out[c] = a;
+    bn_out[HID + c] = beta[c] - mean * a;
+    bn_out[2 * HID + c] = mean;
+    bn_out[3 * HID + c] = invstd;
+    if (c == 0 && tracked) *tracked += 1;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_bn_bwd_stats(const double* __restrict__ slab, int rows,
+                                                      double count, int zero_coef,
+                                                      float* __restrict__ dgamma,
+                                                      float* __restrict__ dbeta,
+                                                      float* __restrict__ bwc) {
+  __shared__ double sh[4];
+  const int c = blockIdx.x;
+  double a1 = 0.0, a2 = 0.0;
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    a1 += slab[(int64_t)r * 128 + c];
+    a2 += slab[(int64_t)r * 128 + HID + c];
+  }
+  const double S1 = block_sum256(a1, sh), S2 = block_sum256(a2, sh);
+  if (threadIdx.x == 0) {
+    dbeta[c] = (float)S1;
+    dgamma[c] = (float)S2;
+    bwc[c] = zero_coef ? 0.f : (float)(S1 / count);
+    bwc[HID + c] = zero_coef ? 0.f : (float)(S2 / count);
+  }
+}
+
+// dW (f32 slab [rows][64*out_cols]) and db (f64 slab [rows][64]) in one launch:
+// one wave per output element, 4 elements per block.
+__global__ void __launch_bounds__(256) k_dw_db_reduce(const float* __restrict__ dw_slab,
+                                                      const double* __restrict__ db_slab, int rows,
+                                                      int out_cols, int take_cols,
+                                                      float* __restrict__ dW, int ldw,
+                                                      float* __restrict__ db) {
+  const int nw = HID * out_cols;
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (e >= nw + HID) return;
+  double s = 0.0;
+  if (e < nw) {
+    for (int r = lane; r < rows; r += 64) s += (double)dw_slab[(int64_t)r * nw + e];
+  } else {
+    for (int r = lane; r < rows; r += 64) s += db_slab[(int64_t)r * HID + (e - nw)];
+  }
+  s = cgnn_wave_sum(s);
+  if (lane == 0) {
+    if (e < nw) {
+      const int o = e / out_cols, cc = e % out_cols;
+      if (cc < take_cols) dW[(int64_t)o * ldw + cc] = (float)s;
+    } else {
+      db[e - nw] = (float)s;
+    }
+  }
+}
+
 int g_grid_cache = 0;
 
 int fused_grid() {
@@ -1112,6 +1203,39 @@ int cgnn_gcn_fused_bwd_first(const cgnn_tiles* t, const float* dZ, const float* 
     k_gcn_bwd<CGNN_FUSED_MAX_ROWS, true, false><<<fused_grid(), NTHR, 0, cgnn_stream(stream)>>>(
         *t, pin, dZ, Y, bn, bwc, X0, F0, nullptr, d, use_drop, nullptr, nullptr, nullptr, nullptr,
         dW_slab, db_slab);
+  CGNN_CHECK_LAUNCH();
+  return CGNN_OK;
+}
+
+int cgnn_bn_stats_finalize(const double* slab, int32_t rows, double count, const float* gamma,
+                           const float* beta, float* running_mean, float* running_var,
+                           float momentum, float eps, int64_t* num_batches_tracked, float* bn_out,
+                           void* stream) {
+  if (!slab || rows <= 0 || count <= 0.0 || !gamma || !beta || !running_mean || !running_var || !bn_out)
+    return CGNN_EINVAL;
+  k_bn_fwd_stats<<<HID, 256, 0, cgnn_stream(stream)>>>(
+      slab, rows, count, gamma, beta, running_mean, running_var, momentum, eps,
+      reinterpret_cast<long long*>(num_batches_tracked), bn_out);
+  CGNN_CHECK_LAUNCH();
+  return CGNN_OK;
+}
+
+int cgnn_bn_bwd_stats_finalize(const double* slab, int32_t rows, double count, int32_t zero_coef,
+                               float* dgamma, float* dbeta, float* bwc, void* stream) {
+  if (!slab || rows <= 0 || count <= 0.0 || !dgamma || !dbeta || !bwc) return CGNN_EINVAL;
+  k_bn_bwd_stats<<<HID, 256, 0, cgnn_stream(stream)>>>(slab, rows, count, zero_coef, dgamma, dbeta, bwc);
+  CGNN_CHECK_LAUNCH();
+  return CGNN_OK;
+}
+
+int cgnn_dw_db_reduce(const float* dw_slab, const double* db_slab, int32_t rows, int32_t out_cols,
+                      int32_t take_cols, float* dW, int32_t ld_dw, float* db, void* stream) {
+  if (!dw_slab || !db_slab || !dW || !db || rows <= 0 || out_cols <= 0 || take_cols <= 0 ||
+      take_cols > out_cols || ld_dw < take_cols)
+    return CGNN_EINVAL;
+  const int total = HID * out_cols + HID;
+  k_dw_db_reduce<<<(total + 3) / 4, 256, 0, cgnn_stream(stream)>>>(dw_slab, db_slab, rows, out_cols,
+                                                                 take_cols, dW, ld_dw, db);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }

@@ -131,17 +131,25 @@ class FusedGCNEncode(torch.autograd.Function):
                 bn_mod = bns_mod[l]
                 bn = torch.empty(4 * HID, **f32)
                 cnt = count
-                if training:
-                    _lib.check(lib.cgnn_bn_reduce(_lib.ptr(slab), slab_rows, 128, _lib.ptr(sums), st()),
-                               "cgnn_bn_reduce")
-                    if sync_group is not None:
+                if training and sync_group is None:
+                    # one launch: reduce partials, finalise, update running stats and the counter
+                    _lib.check(lib.cgnn_bn_stats_finalize(
+                        _lib.ptr(slab), slab_rows, cnt, _lib.ptr(gamma), _lib.ptr(beta),
+                        _lib.ptr(bn_mod.running_mean), _lib.ptr(bn_mod.running_var),
+                        float(bn_mod.momentum), float(bn_mod.eps),
+                        _lib.ptr(bn_mod.num_batches_tracked), _lib.ptr(bn), st()),
+                        "cgnn_bn_stats_finalize")
+                else:
+                    if training:
+                        _lib.check(lib.cgnn_bn_reduce(_lib.ptr(slab), slab_rows, 128, _lib.ptr(sums), st()),
+                                   "cgnn_bn_reduce")
                         cnt = _sync_sums(sums, local_count, sync_group)
-                    bn_mod.num_batches_tracked.add_(1)
-                _lib.check(lib.cgnn_bn_finalize(
-                    _lib.ptr(sums), cnt, _lib.ptr(gamma), _lib.ptr(beta),
-                    _lib.ptr(bn_mod.running_mean), _lib.ptr(bn_mod.running_var),
-                    float(bn_mod.momentum), float(bn_mod.eps), int(training), _lib.ptr(bn), st()),
-                    "cgnn_bn_finalize")
+                        bn_mod.num_batches_tracked.add_(1)
+                    _lib.check(lib.cgnn_bn_finalize(
+                        _lib.ptr(sums), cnt, _lib.ptr(gamma), _lib.ptr(beta),
+                        _lib.ptr(bn_mod.running_mean), _lib.ptr(bn_mod.running_var),
+                        float(bn_mod.momentum), float(bn_mod.eps), int(training), _lib.ptr(bn), st()),
+                        "cgnn_bn_finalize")
                 if l == 0:
                     count = cnt
                 ys.append(y)
@@ -184,17 +192,21 @@ class FusedGCNEncode(torch.autograd.Function):
 
         def bn_backward(l: int) -> torch.Tensor:
             """sums of layer l (in s_slab) -> dgamma/dbeta of layer l and its c1|c2 block."""
-            _lib.check(lib.cgnn_bn_reduce(_lib.ptr(s_slab), grid, 128, _lib.ptr(sums), st()),
-                       "cgnn_bn_reduce")
-            if c.sync_group is not None:
-                dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=c.sync_group)
             dgamma, dbeta, bwc = torch.empty(HID, **f32), torch.empty(HID, **f32), torch.empty(2 * HID, **f32)
-            _lib.check(lib.cgnn_bn_bwd_finalize(_lib.ptr(sums), c.count, _lib.ptr(dgamma),
-                                                _lib.ptr(dbeta), _lib.ptr(bwc), st()),
-                       "cgnn_bn_bwd_finalize")
+            if c.sync_group is None:
+                _lib.check(lib.cgnn_bn_bwd_stats_finalize(
+                    _lib.ptr(s_slab), grid, c.count, int(not c.training), _lib.ptr(dgamma),
+                    _lib.ptr(dbeta), _lib.ptr(bwc), st()), "cgnn_bn_bwd_stats_finalize")
+            else:
+                _lib.check(lib.cgnn_bn_reduce(_lib.ptr(s_slab), grid, 128, _lib.ptr(sums), st()),
+                           "cgnn_bn_reduce")
+                dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=c.sync_group)
+                _lib.check(lib.cgnn_bn_bwd_finalize(_lib.ptr(sums), c.count, _lib.ptr(dgamma),
+                                                    _lib.ptr(dbeta), _lib.ptr(bwc), st()),
+                           "cgnn_bn_bwd_finalize")
+                if not c.training:
+                    bwc.zero_()      # eval-mode BatchNorm is a fixed affine map: dY = a * dZ
             grads[4 * l + 2], grads[4 * l + 3] = dgamma, dbeta
-            if not c.training:
-                bwc.zero_()      # eval-mode BatchNorm is a fixed affine map: dY = a * dZ
             return bwc
 
         # the last layer rebuilds its incoming gradient from dP (POOLIN); the readout backward
@@ -217,10 +229,9 @@ class FusedGCNEncode(torch.autograd.Function):
                         _lib.ptr(w), _lib.ptr(dz_prev), _lib.ptr(s_slab), _lib.ptr(dw_slab),
                         _lib.ptr(db_slab), *extra, st()), "cgnn_gcn_fused_bwd")
                 dw, db = torch.empty(HID, HID, **f32), torch.empty(HID, **f32)
-                _lib.check(lib.cgnn_slab_reduce_f32(_lib.ptr(dw_slab), grid, HID, HID, HID,
-                                                    _lib.ptr(dw), HID, st()), "cgnn_slab_reduce_f32")
-                _lib.check(lib.cgnn_slab_reduce_f64(_lib.ptr(db_slab), grid, HID, _lib.ptr(db), st()),
-                           "cgnn_slab_reduce_f64")
+                _lib.check(lib.cgnn_dw_db_reduce(_lib.ptr(dw_slab), _lib.ptr(db_slab), grid, HID, HID,
+                                                 _lib.ptr(dw), HID, _lib.ptr(db), st()),
+                           "cgnn_dw_db_reduce")
                 grads[4 * l], grads[4 * l + 1] = dw, db
                 bwc = bn_backward(l - 1)
                 dz, dz_prev = dz_prev, dz
@@ -235,10 +246,9 @@ class FusedGCNEncode(torch.autograd.Function):
                         _lib.ptr(dz), _lib.ptr(c.ys[0]), _lib.ptr(c.bns[0]), _lib.ptr(bwc),
                         _lib.ptr(c.p0), nn_, _lib.ptr(dw_slab0), _lib.ptr(db_slab0), st()),
                         "cgnn_gcn_l0_bwd")
-                _lib.check(lib.cgnn_slab_reduce_f32(_lib.ptr(dw_slab0), g0, HID, 8, c.f0,
-                                                    _lib.ptr(dw0), c.f0, st()), "cgnn_slab_reduce_f32")
-                _lib.check(lib.cgnn_slab_reduce_f64(_lib.ptr(db_slab0), g0, HID, _lib.ptr(db0), st()),
-                           "cgnn_slab_reduce_f64")
+                _lib.check(lib.cgnn_dw_db_reduce(_lib.ptr(dw_slab0), _lib.ptr(db_slab0), g0, 8, c.f0,
+                                                 _lib.ptr(dw0), c.f0, _lib.ptr(db0), st()),
+                           "cgnn_dw_db_reduce")
             else:
                 extra = pool_args if L == 1 else none_args
                 with _lib.timed("cgnn_gcn_fused_bwd_first"):
@@ -246,10 +256,9 @@ class FusedGCNEncode(torch.autograd.Function):
                         tp, _lib.ptr(dz), _lib.ptr(c.ys[0]), _lib.ptr(c.bns[0]), _lib.ptr(bwc),
                         _lib.ptr(c.x0), c.f0, _lib.ptr(dw_slab), _lib.ptr(db_slab), c.p, *extra, st()),
                         "cgnn_gcn_fused_bwd_first")
-                _lib.check(lib.cgnn_slab_reduce_f32(_lib.ptr(dw_slab), grid, HID, 16, c.f0,
-                                                    _lib.ptr(dw0), c.f0, st()), "cgnn_slab_reduce_f32")
-                _lib.check(lib.cgnn_slab_reduce_f64(_lib.ptr(db_slab), grid, HID, _lib.ptr(db0), st()),
-                           "cgnn_slab_reduce_f64")
+                _lib.check(lib.cgnn_dw_db_reduce(_lib.ptr(dw_slab), _lib.ptr(db_slab), grid, 16, c.f0,
+                                                 _lib.ptr(dw0), c.f0, _lib.ptr(db0), st()),
+                           "cgnn_dw_db_reduce")
             grads[0], grads[1] = dw0, db0
         ctx.c = None
         return (None, None, *grads)

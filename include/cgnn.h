@@ -283,6 +283,19 @@ int cgnn_gcn_l0_bwd(const float* dZ, const float* Y, const float* bn, const floa
                     const float* P0, int64_t num_nodes, float* dW_slab, double* db_slab,
                     void* stream);
 
+/* Single-launch forms of (cgnn_bn_reduce + cgnn_bn_finalize [+ num_batches_tracked += 1]),
+ * (cgnn_bn_reduce + cgnn_bn_bwd_finalize) and (cgnn_slab_reduce_f32 + cgnn_slab_reduce_f64):
+ * used when no cross-rank exchange sits between the reduction and the finalisation.
+ * zero_coef != 0 writes c1 = c2 = 0 (eval-mode BatchNorm backward is a fixed affine map). */
+int cgnn_bn_stats_finalize(const double* slab, int32_t rows, double count, const float* gamma,
+                           const float* beta, float* running_mean, float* running_var,
+                           float momentum, float eps, int64_t* num_batches_tracked, float* bn_out,
+                           void* stream);
+int cgnn_bn_bwd_stats_finalize(const double* slab, int32_t rows, double count, int32_t zero_coef,
+                               float* dgamma, float* dbeta, float* bwc, void* stream);
+int cgnn_dw_db_reduce(const float* dw_slab, const double* db_slab, int32_t rows, int32_t out_cols,
+                      int32_t take_cols, float* dW, int32_t ld_dw, float* db, void* stream);
+
 /* Fixed-order combination of per-workgroup partials (fp64 accumulate):
  * f32 slab [rows][width] -> out[r*ld_out + c] for width = out_rows*out_cols (take the first
  * `take_cols` of every `out_cols` columns); f64 slab [rows][width] -> f32 out [width]. */
