@@ -159,7 +159,11 @@ __device__ __forceinline__ MetaRegs meta_issue(const uint4* __restrict__ mp, int
 // `width` must be wave-uniform.  Steps run in straight-line groups (no per-step branch: a
 // branch per step would fence the scheduler and expose the LDS latency of every step).
 // G = steps whose row reads may be in flight together (register budget of the caller).
+// scalar-branched forms: one basic block per step (or per pair of steps; the second step of a
+// pair may be padding, which is harmless: weight 0, row 0)
 #define CGNN_AGG_STEP_IF(M0, M1, S, W) if ((S) < (W)) CGNN_AGG_STEP(M0, M1, S)
+#define CGNN_AGG_PAIR_IF(M0, M1, S, W) \
+  if ((S) < (W)) { CGNN_AGG_STEP(M0, M1, S) CGNN_AGG_STEP(M0, M1, (S) + 1) }
 #define CGNN_AGG_16_IF(M0, M1, W)                                                             \
   CGNN_AGG_STEP_IF(M0, M1, 0, W) CGNN_AGG_STEP_IF(M0, M1, 1, W) CGNN_AGG_STEP_IF(M0, M1, 2, W)     \
   CGNN_AGG_STEP_IF(M0, M1, 3, W) CGNN_AGG_STEP_IF(M0, M1, 4, W) CGNN_AGG_STEP_IF(M0, M1, 5, W)     \
@@ -167,6 +171,10 @@ __device__ __forceinline__ MetaRegs meta_issue(const uint4* __restrict__ mp, int
   CGNN_AGG_STEP_IF(M0, M1, 9, W) CGNN_AGG_STEP_IF(M0, M1, 10, W) CGNN_AGG_STEP_IF(M0, M1, 11, W)   \
   CGNN_AGG_STEP_IF(M0, M1, 12, W) CGNN_AGG_STEP_IF(M0, M1, 13, W) CGNN_AGG_STEP_IF(M0, M1, 14, W)  \
   CGNN_AGG_STEP_IF(M0, M1, 15, W)
+#define CGNN_AGG_16_PAIRS(M0, M1, W)                                                          \
+  CGNN_AGG_PAIR_IF(M0, M1, 0, W) CGNN_AGG_PAIR_IF(M0, M1, 2, W) CGNN_AGG_PAIR_IF(M0, M1, 4, W)     \
+  CGNN_AGG_PAIR_IF(M0, M1, 6, W) CGNN_AGG_PAIR_IF(M0, M1, 8, W) CGNN_AGG_PAIR_IF(M0, M1, 10, W)    \
+  CGNN_AGG_PAIR_IF(M0, M1, 12, W) CGNN_AGG_PAIR_IF(M0, M1, 14, W)
 
 template <int G, bool AHEAD2>
 __device__ __forceinline__ void agg_block(const float* __restrict__ tile, MetaRegs m,
@@ -183,6 +191,13 @@ __device__ __forceinline__ void agg_block(const float* __restrict__ tile, MetaRe
     if (width > 16) {
       const int w1 = width - 16;
       CGNN_AGG_16_IF(m.b0, m.b1, w1)
+    }
+  } else if (G == 2) {
+    // scalar-branched pairs: 8 row reads in flight per basic block
+    CGNN_AGG_16_PAIRS(m.a0, m.a1, width)
+    if (width > 16) {
+      const int w1 = width - 16;
+      CGNN_AGG_16_PAIRS(m.b0, m.b1, w1)
     }
   } else {
     if (width >= 13) {
@@ -211,7 +226,8 @@ __device__ __forceinline__ float4 scale4(const float4& v, float s) {
 
 // Reduce per-lane fp64 column partials (lane (q,j): columns 4j..4j+3) over the workgroup and
 // write slab_row[0..63] (= s1) and slab_row[64..127] (= s2).  `red` >= 8*128 doubles of LDS.
-__device__ __forceinline__ void reduce_stats(double (&s1)[4], double (&s2)[4], double* red,
+template <typename T>
+__device__ __forceinline__ void reduce_stats(T (&s1)[4], T (&s2)[4], double* red,
                                              double* __restrict__ slab_row) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, j = lane & 15;
 #pragma unroll
@@ -223,8 +239,8 @@ __device__ __forceinline__ void reduce_stats(double (&s1)[4], double (&s2)[4], d
   if (q == 0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      red[wave * 128 + 4 * j + i] = s1[i];
-      red[wave * 128 + 64 + 4 * j + i] = s2[i];
+      red[wave * 128 + 4 * j + i] = (double)s1[i];
+      red[wave * 128 + 64 + 4 * j + i] = (double)s2[i];
     }
   }
   __syncthreads();
@@ -472,6 +488,11 @@ struct PoolIn {
   const uint8_t* mask_cur;       // keep bits of THIS layer's activation (or NULL)
 };
 
+#ifndef CGNN_BWD_G
+#define CGNN_BWD_G 2
+#endif
+constexpr int BWD_G = CGNN_BWD_G;
+
 template <int MAXR, bool FIRST, bool POOLIN>
 __global__ void __launch_bounds__(NTHR) k_gcn_bwd(
     cgnn_tiles t, PoolIn pin, const float* __restrict__ dZ, const float* __restrict__ Y,
@@ -503,9 +524,11 @@ __global__ void __launch_bounds__(NTHR) k_gcn_bwd(
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b2 = 0; b2 < (FIRST ? 1 : 4); ++b2) dw[a][b2] = f32x4{0, 0, 0, 0};
-  // per-thread partial sums: fp32 within a tile (a few dozen terms), folded into fp64 per tile
-  double db[4] = {0, 0, 0, 0};
-  double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  // per-thread partial sums stay fp32 (a thread adds a few hundred terms over its tiles: error
+  // ~1e-6 relative, far inside the 1e-5 bar); everything across threads/workgroups is fp64.
+  // (64 dW accumulators leave no room for 28 registers of fp64 partials.)
+  float db[4] = {0, 0, 0, 0};
+  float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
   CGNN_STAMP_DECL
 
   for (int tid = blockIdx.x; tid < t.num_tiles; tid += gridDim.x) {
@@ -624,7 +647,7 @@ __global__ void __launch_bounds__(NTHR) k_gcn_bwd(
           }
         }
         float4 ag[4];
-        agg_block<FIRST ? 4 : 1, FIRST>(tile, pre, ent + (off0 >> 1), width, q, j, ag);
+        agg_block<FIRST ? 4 : BWD_G, FIRST>(tile, pre, ent + (off0 >> 1), width, q, j, ag);
         CGNN_STAMP(3)
 #pragma unroll
         for (int it = 0; it < 4; ++it)
@@ -698,10 +721,10 @@ __global__ void __launch_bounds__(NTHR) k_gcn_bwd(
           const float4 dzp = make_float4(dx[0][r] * f.x, dx[1][r] * f.y, dx[2][r] * f.z, dx[3][r] * f.w);
           st4(dZprev + (int64_t)(base + row) * HID + 4 * j, dzp);
           s1[0] += dzp.x; s1[1] += dzp.y; s1[2] += dzp.z; s1[3] += dzp.w;
-          s2[0] += (double)dzp.x * ((yp[r].x - pmean.x) * pis.x);
-          s2[1] += (double)dzp.y * ((yp[r].y - pmean.y) * pis.y);
-          s2[2] += (double)dzp.z * ((yp[r].z - pmean.z) * pis.z);
-          s2[3] += (double)dzp.w * ((yp[r].w - pmean.w) * pis.w);
+          s2[0] = fmaf(dzp.x, (yp[r].x - pmean.x) * pis.x, s2[0]);
+          s2[1] = fmaf(dzp.y, (yp[r].y - pmean.y) * pis.y, s2[1]);
+          s2[2] = fmaf(dzp.z, (yp[r].z - pmean.z) * pis.z, s2[2]);
+          s2[3] = fmaf(dzp.w, (yp[r].w - pmean.w) * pis.w, s2[3]);
         }
       }
       CGNN_STAMP(4)
@@ -718,7 +741,7 @@ __global__ void __launch_bounds__(NTHR) k_gcn_bwd(
     __syncthreads();
     const int g = threadIdx.x >> 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) red[g * 64 + 4 * j + i] = db[i];
+    for (int i = 0; i < 4; ++i) red[g * 64 + 4 * j + i] = (double)db[i];
     __syncthreads();
     if (threadIdx.x < 64) {
       double s = 0.0;
