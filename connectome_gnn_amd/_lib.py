@@ -52,6 +52,15 @@ PROTOTYPES = {
     "cgnn_colsum_f32": (c_int, [P, I64, P, I64, I32, P, P]),
     "cgnn_pool_mean_fwd_f32": (c_int, [P, I64, P, P, I32, I32, P]),
     "cgnn_pool_mean_bwd_f32": (c_int, [P, P, P, I64, I32, I32, P]),
+    # BatchNorm + activation + dropout (layered path)
+    "cgnn_bn_act_width_ok": (c_int, [I32]),
+    "cgnn_bn_act_slab_rows": (I64, [I64]),
+    "cgnn_bn_act_fwd_stats": (c_int, [P, I64, I32, P, P]),
+    "cgnn_bn_act_finalize": (c_int, [P, I32, I32, F64, I32, P, P, P, P, F32, F32, P, P, P]),
+    "cgnn_bn_act_fwd_apply": (c_int, [P, P, I32, F32, U64, P, P, I64, I32, P]),
+    "cgnn_bn_act_bwd_stats": (c_int, [P, P, P, P, I32, F32, I64, I32, P, P]),
+    "cgnn_bn_act_bwd_finalize": (c_int, [P, I32, I32, F64, I32, P, P, P, P]),
+    "cgnn_bn_act_bwd_apply": (c_int, [P, P, P, P, P, I32, F32, P, I64, I32, P]),
     # fused per-tile GCN path
     "cgnn_bell_plan": (c_int, [P, P, I32, I32, P, P, P, P]),
     "cgnn_bell_fill": (c_int, [P, P, I32, P, P, P, P, P, P, P]),

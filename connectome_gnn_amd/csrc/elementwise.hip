@@ -1,0 +1,312 @@
+// elementwise.hip -- BatchNorm1d (+ReLU) + dropout for the layered path, any power-of-two width.
+//
+// Replaces, per layer, torch's batch_norm (3 forward + 3 backward kernels), relu, dropout and
+// their mask bookkeeping (models.py:208-210 / :260-261) by two streaming passes forward
+// (column statistics; normalise+activate+drop) and two backward (BatchNorm-backward sums;
+// apply).  Statistics are accumulated in fp64 across threads/blocks exactly like the fused
+// path; dropout keep-bits are one byte per 4-column chunk.
+//
+//   X' = drop( act( a*Y + b ) ),  a = gamma*invstd, b = beta - mean*a,  act = ReLU or identity
+//   dY = a * ( dZ - c1 - xhat*c2 ),  dZ = dX' * drop' * act'
+#include "common.h"
+
+namespace {
+
+struct DropCfg {
+  uint32_t thr16;
+  float scale;
+  uint32_t key0, key1;
+};
+
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+
+__device__ __forceinline__ uint32_t drop_bits(const DropCfg& d, uint32_t chunk_index) {
+  const uint32_t e = chunk_index * 2u;
+  const uint32_t h0 = mix32(mix32(e ^ d.key0) + d.key1);
+  const uint32_t h1 = mix32(mix32((e + 1u) ^ d.key0) + d.key1);
+  uint32_t b = 0;
+  b |= ((h0 & 0xFFFFu) >= d.thr16) ? 1u : 0u;
+  b |= ((h0 >> 16) >= d.thr16) ? 2u : 0u;
+  b |= ((h1 & 0xFFFFu) >= d.thr16) ? 4u : 0u;
+  b |= ((h1 >> 16) >= d.thr16) ? 8u : 0u;
+  return b;
+}
+
+DropCfg make_drop(float p, uint64_t seed, int* use_drop) {
+  DropCfg d;
+  *use_drop = (p > 0.f) ? 1 : 0;
+  double thr = (double)p * 65536.0 + 0.5;
+  if (thr > 65535.0) thr = 65535.0;
+  d.thr16 = (uint32_t)thr;
+  d.scale = p > 0.f ? (float)(1.0 / (1.0 - (double)d.thr16 / 65536.0)) : 1.0f;
+  d.key0 = (uint32_t)(seed & 0xFFFFFFFFu) * 0x9E3779B9u + 0x85EBCA6Bu;
+  d.key1 = (uint32_t)(seed >> 32) ^ 0xC2B2AE35u;
+  return d;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+
+constexpr int ROWS = 256;     // rows per block of the reduction kernels
+constexpr int THR = 256;
+
+// per-thread fp32 partials over <= ROWS*nch/THR rows, fp64 across threads -> slab[block][2N]
+template <bool BWD>
+__global__ void __launch_bounds__(THR) k_colstats(
+    const float* __restrict__ A /* Y (fwd) or dX' (bwd) */, const float* __restrict__ Y,
+    const uint8_t* __restrict__ mask, const float* __restrict__ coef, int relu, DropCfg drop,
+    int use_drop, int64_t M, int N, double* __restrict__ slab) {
+  extern __shared__ double red[];                    // [rpp][2N]
+  const int nch = N >> 2;
+  const int c = threadIdx.x % nch, rr = threadIdx.x / nch, rpp = THR / nch;
+  const int64_t rbeg = (int64_t)blockIdx.x * ROWS, rend = min(M, rbeg + ROWS);
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  float4 ca = s1, cb = s1, cm = s1, ci = s1;
+  if (BWD) {
+    ca = ld4(coef + 4 * c); cb = ld4(coef + N + 4 * c);
+    cm = ld4(coef + 2 * N + 4 * c); ci = ld4(coef + 3 * N + 4 * c);
+  }
+  if (rr < rpp) {
+    for (int64_t r = rbeg + rr; r < rend; r += rpp) {
+      const float4 a = ld4(A + r * N + 4 * c);
+      if (!BWD) {
+        s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
+        s2.x = fmaf(a.x, a.x, s2.x); s2.y = fmaf(a.y, a.y, s2.y);
+        s2.z = fmaf(a.z, a.z, s2.z); s2.w = fmaf(a.w, a.w, s2.w);
+      } else {
+        const float4 y = ld4(Y + r * N + 4 * c);
+        const uint32_t kb = use_drop ? mask[r * nch + c] : 0xFu;
+        const float zx = fmaf(ca.x, y.x, cb.x), zy = fmaf(ca.y, y.y, cb.y);
+        const float zz = fmaf(ca.z, y.z, cb.z), zw = fmaf(ca.w, y.w, cb.w);
+        const float fx = ((!relu || zx > 0.f) && (kb & 1u)) ? drop.scale : 0.f;
+        const float fy = ((!relu || zy > 0.f) && (kb & 2u)) ? drop.scale : 0.f;
+        const float fz = ((!relu || zz > 0.f) && (kb & 4u)) ? drop.scale : 0.f;
+        const float fw = ((!relu || zw > 0.f) && (kb & 8u)) ? drop.scale : 0.f;
+        const float dx = a.x * fx, dy = a.y * fy, dz = a.z * fz, dw = a.w * fw;
+        s1.x += dx; s1.y += dy; s1.z += dz; s1.w += dw;
+        s2.x = fmaf(dx, (y.x - cm.x) * ci.x, s2.x); s2.y = fmaf(dy, (y.y - cm.y) * ci.y, s2.y);
+        s2.z = fmaf(dz, (y.z - cm.z) * ci.z, s2.z); s2.w = fmaf(dw, (y.w - cm.w) * ci.w, s2.w);
+      }
+    }
+  }
+  if (rr < rpp) {
+    double* p = red + (int64_t)rr * 2 * N;
+    p[4 * c + 0] = s1.x; p[4 * c + 1] = s1.y; p[4 * c + 2] = s1.z; p[4 * c + 3] = s1.w;
+    p[N + 4 * c + 0] = s2.x; p[N + 4 * c + 1] = s2.y; p[N + 4 * c + 2] = s2.z; p[N + 4 * c + 3] = s2.w;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 2 * N; e += THR) {
+    double t = 0.0;
+    for (int q = 0; q < rpp; ++q) t += red[(int64_t)q * 2 * N + e];
+    slab[(int64_t)blockIdx.x * 2 * N + e] = t;
+  }
+}
+
+__device__ __forceinline__ double block_sum256(double v, double* sh) {
+  v = cgnn_wave_sum(v);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const double t = sh[0] + sh[1] + sh[2] + sh[3];
+  __syncthreads();
+  return t;
+}
+
+// one block per channel
+__global__ void __launch_bounds__(256) k_bn_fwd_finalize_n(
+    const double* __restrict__ slab, int rows, int N, double count, int training,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean,
+    float* __restrict__ rvar, float momentum, float eps, long long* __restrict__ tracked,
+    float* __restrict__ coef) {
+  __shared__ double sh[4];
+  const int c = blockIdx.x;
+  float mean, var;
+  if (training) {
+    double a1 = 0.0, a2 = 0.0;
+    for (int r = threadIdx.x; r < rows; r += 256) {
+      a1 += slab[(int64_t)r * 2 * N + c];
+      a2 += slab[(int64_t)r * 2 * N + N + c];
+    }
+    const double S1 = block_sum256(a1, sh), S2 = block_sum256(a2, sh);
+    const double m = S1 / count;
+    double v = S2 / count - m * m;
+    if (v < 0.0) v = 0.0;
+    mean = (float)m;
+    var = (float)v;
+    if (threadIdx.x == 0) {
+      const double unbiased = count > 1.0 ? v * count / (count - 1.0) : v;
+      rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean;
+      rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (float)unbiased;
+      if (c == 0 && tracked) *tracked += 1;
+    }
+  } else {
+    mean = rmean[c];
+    var = rvar[c];
+  }
+  if (threadIdx.x == 0) {
+    const float invstd = 1.0f / sqrtf(var + eps);
+    const float a = gamma[c] * invstd;
+    coef[c] = a;
+    coef[N + c] = beta[c] - mean * a;
+    coef[2 * N + c] = mean;
+    coef[3 * N + c] = invstd;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_bn_bwd_finalize_n(const double* __restrict__ slab, int rows,
+                                                           int N, double count, int zero_coef,
+                                                           float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta,
+                                                           float* __restrict__ bwc) {
+  __shared__ double sh[4];
+  const int c = blockIdx.x;
+  double a1 = 0.0, a2 = 0.0;
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    a1 += slab[(int64_t)r * 2 * N + c];
+    a2 += slab[(int64_t)r * 2 * N + N + c];
+  }
+  const double S1 = block_sum256(a1, sh), S2 = block_sum256(a2, sh);
+  if (threadIdx.x == 0) {
+    dbeta[c] = (float)S1;
+    dgamma[c] = (float)S2;
+    bwc[c] = zero_coef ? 0.f : (float)(S1 / count);
+    bwc[N + c] = zero_coef ? 0.f : (float)(S2 / count);
+  }
+}
+
+// forward apply (BWD=false): X' = drop(act(a*Y+b)), keep bytes out
+// backward apply (BWD=true): dY = a*(dZ - c1 - xhat*c2), dZ = dX'*drop'*act'
+template <bool BWD>
+__global__ void __launch_bounds__(256) k_bn_act_apply(
+    const float* __restrict__ Y, const float* __restrict__ dXp, const float* __restrict__ coef,
+    const float* __restrict__ bwc, int relu, DropCfg drop, int use_drop,
+    uint8_t* __restrict__ mask_out, const uint8_t* __restrict__ mask_in, float* __restrict__ out,
+    int64_t M, int N) {
+  const int nch = N >> 2;
+  const int64_t total = M * nch;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % nch);
+    const float4 y = ld4(Y + 4 * i);
+    const float4 ca = ld4(coef + 4 * c), cb = ld4(coef + N + 4 * c);
+    const float zx = fmaf(ca.x, y.x, cb.x), zy = fmaf(ca.y, y.y, cb.y);
+    const float zz = fmaf(ca.z, y.z, cb.z), zw = fmaf(ca.w, y.w, cb.w);
+    uint32_t kb = 0xFu;
+    if (use_drop) {
+      if (BWD) kb = mask_in[i];
+      else {
+        kb = drop_bits(drop, (uint32_t)i);
+        if (mask_out) mask_out[i] = (uint8_t)kb;
+      }
+    }
+    const float fx = ((!relu || zx > 0.f) && (kb & 1u)) ? drop.scale : 0.f;
+    const float fy = ((!relu || zy > 0.f) && (kb & 2u)) ? drop.scale : 0.f;
+    const float fz = ((!relu || zz > 0.f) && (kb & 4u)) ? drop.scale : 0.f;
+    const float fw = ((!relu || zw > 0.f) && (kb & 8u)) ? drop.scale : 0.f;
+    if (!BWD) {
+      st4(out + 4 * i, make_float4(zx * fx, zy * fy, zz * fz, zw * fw));
+    } else {
+      const float4 g = ld4(dXp + 4 * i);
+      const float4 cm = ld4(coef + 2 * N + 4 * c), ci = ld4(coef + 3 * N + 4 * c);
+      const float4 c1 = ld4(bwc + 4 * c), c2 = ld4(bwc + N + 4 * c);
+      st4(out + 4 * i, make_float4(ca.x * (g.x * fx - c1.x - (y.x - cm.x) * ci.x * c2.x),
+                                   ca.y * (g.y * fy - c1.y - (y.y - cm.y) * ci.y * c2.y),
+                                   ca.z * (g.z * fz - c1.z - (y.z - cm.z) * ci.z * c2.z),
+                                   ca.w * (g.w * fw - c1.w - (y.w - cm.w) * ci.w * c2.w)));
+    }
+  }
+}
+
+bool width_ok(int N) { return N >= 4 && N <= 1024 && (N & (N - 1)) == 0; }
+int stat_blocks(int64_t M) { return (int)((M + ROWS - 1) / ROWS); }
+
+}  // namespace
+
+extern "C" {
+
+int cgnn_bn_act_width_ok(int32_t N) { return width_ok(N) ? 1 : 0; }
+int64_t cgnn_bn_act_slab_rows(int64_t M) { return M < 0 ? CGNN_EINVAL : (M == 0 ? 1 : stat_blocks(M)); }
+
+int cgnn_bn_act_fwd_stats(const float* Y, int64_t M, int32_t N, double* slab, void* stream) {
+  if (M < 0 || !width_ok(N) || !slab) return width_ok(N) ? CGNN_EINVAL : CGNN_EUNSUPPORTED;
+  if (M == 0) return CGNN_OK;
+  if (!Y) return CGNN_EINVAL;
+  DropCfg d{};
+  const int rpp = THR / (N >> 2);
+  k_colstats<false><<<stat_blocks(M), THR, (size_t)rpp * 2 * N * sizeof(double), cgnn_stream(stream)>>>(
+      Y, nullptr, nullptr, nullptr, 0, d, 0, M, N, slab);
+  CGNN_CHECK_LAUNCH();
+  return CGNN_OK;
+}
+
+int cgnn_bn_act_finalize(const double* slab, int32_t rows, int32_t N, double count, int32_t training,
+                         const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, float momentum, float eps,
+                         int64_t* num_batches_tracked, float* coef, void* stream) {
+  if (!width_ok(N) || !gamma || !beta || !running_mean || !running_var || !coef) return CGNN_EINVAL;
+  if (training && (!slab || rows <= 0 || count <= 0.0)) return CGNN_EINVAL;
+  k_bn_fwd_finalize_n<<<N, 256, 0, cgnn_stream(stream)>>>(
+      slab, rows, N, count, training, gamma, beta, running_mean, running_var, momentum, eps,
+      reinterpret_cast<long long*>(num_batches_tracked), coef);
+  CGNN_CHECK_LAUNCH();
+  return CGNN_OK;
+}
+
+int cgnn_bn_act_fwd_apply(const float* Y, const float* coef, int32_t relu, float p_drop, uint64_t seed,
+                          uint8_t* mask_out, float* X, int64_t M, int32_t N, void* stream) {
+  if (M < 0 || !width_ok(N) || p_drop < 0.f || p_drop >= 1.f) return CGNN_EINVAL;
+  if (M == 0) return CGNN_OK;
+  if (!Y || !coef || !X) return CGNN_EINVAL;
+  int use_drop;
+  DropCfg d = make_drop(p_drop, seed, &use_drop);
+  const int64_t total = M * (N >> 2);
+  unsigned grid = (unsigned)((total + 255) / 256);
+  if (grid > 256u * 32u) grid = 256u * 32u;
+  k_bn_act_apply<false><<<grid, 256, 0, cgnn_stream(stream)>>>(Y, nullptr, coef, nullptr, relu, d, use_drop,
+                                                              mask_out, nullptr, X, M, N);
+  CGNN_CHECK_LAUNCH();
+  return CGNN_OK;
+}
+
+int cgnn_bn_act_bwd_stats(const float* dX, const float* Y, const uint8_t* mask, const float* coef,
+                          int32_t relu, float p_drop, int64_t M, int32_t N, double* slab, void* stream) {
+  if (M < 0 || !width_ok(N) || !slab || p_drop < 0.f || p_drop >= 1.f) return CGNN_EINVAL;
+  if (M == 0) return CGNN_OK;
+  if (!dX || !Y || !coef || (p_drop > 0.f && !mask)) return CGNN_EINVAL;
+  int use_drop;
+  DropCfg d = make_drop(p_drop, 0, &use_drop);
+  const int rpp = THR / (N >> 2);
+  k_colstats<true><<<stat_blocks(M), THR, (size_t)rpp * 2 * N * sizeof(double), cgnn_stream(stream)>>>(
+      dX, Y, mask, coef, relu, d, use_drop, M, N, slab);
+  CGNN_CHECK_LAUNCH();
+  return CGNN_OK;
+}
+
+int cgnn_bn_act_bwd_finalize(const double* slab, int32_t rows, int32_t N, double count,
+                             int32_t zero_coef, float* dgamma, float* dbeta, float* bwc, void* stream) {
+  if (!width_ok(N) || !slab || rows <= 0 || count <= 0.0 || !dgamma || !dbeta || !bwc) return CGNN_EINVAL;
+  k_bn_bwd_finalize_n<<<N, 256, 0, cgnn_stream(stream)>>>(slab, rows, N, count, zero_coef, dgamma, dbeta, bwc);
+  CGNN_CHECK_LAUNCH();
+  return CGNN_OK;
+}
+
+int cgnn_bn_act_bwd_apply(const float* dX, const float* Y, const uint8_t* mask, const float* coef,
+                          const float* bwc, int32_t relu, float p_drop, float* dY, int64_t M, int32_t N,
+                          void* stream) {
+  if (M < 0 || !width_ok(N) || p_drop < 0.f || p_drop >= 1.f) return CGNN_EINVAL;
+  if (M == 0) return CGNN_OK;
+  if (!dX || !Y || !coef || !bwc || !dY || (p_drop > 0.f && !mask)) return CGNN_EINVAL;
+  int use_drop;
+  DropCfg d = make_drop(p_drop, 0, &use_drop);
+  const int64_t total = M * (N >> 2);
+  unsigned grid = (unsigned)((total + 255) / 256);
+  if (grid > 256u * 32u) grid = 256u * 32u;
+  k_bn_act_apply<true><<<grid, 256, 0, cgnn_stream(stream)>>>(Y, dX, coef, bwc, relu, d, use_drop, nullptr,
+                                                             mask, dY, M, N);
+  CGNN_CHECK_LAUNCH();
+  return CGNN_OK;
+}
+
+}  // extern "C"

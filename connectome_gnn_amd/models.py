@@ -99,6 +99,7 @@ def _head(hidden_dim: int, num_classes: int, dropout: float) -> nn.Sequential:
 
 class _ConnectomeModel(nn.Module):
     _layer_cls = None
+    _relu_after_bn = False
 
     def __init__(self, in_channels: int, hidden_dim: int = 64, num_classes: int = 2,
                  num_layers: int = 3, dropout: float = 0.3, *, impl: str = "auto"):
@@ -132,8 +133,12 @@ class _ConnectomeModel(nn.Module):
         x = batch.node_features
         for conv, bn in zip(self.convs, self.batch_norms):
             x = conv(x, batch.edge_index, batch.edge_weight, structure=s, norm=norm)
-            x = self._post(bn(x))
-            x = F.dropout(x, p=self.dropout, training=self.training)
+            if ops.bn_act_drop_supported(bn, x.shape[1]):
+                # BatchNorm (+ReLU) + dropout in two streaming HIP passes each way
+                x = ops.bn_act_drop(x, bn, self._relu_after_bn, self.dropout, self.training)
+            else:                     # SyncBatchNorm / odd widths: torch ops
+                x = self._post(bn(x))
+                x = F.dropout(x, p=self.dropout, training=self.training)
         return ops.pool_mean(x, s.gptr, batch.num_graphs)
 
     def forward(self, batch: ConnectomeBatch) -> torch.Tensor:
@@ -148,6 +153,7 @@ class GCNConnectome(_ConnectomeModel):
     """conv -> BatchNorm1d -> ReLU -> dropout per layer, mean-pool, MLP head
     (reference models.py:159-216)."""
     _layer_cls = GCNLayer
+    _relu_after_bn = True
 
     def _norm(self, structure):
         return structure.gcn_norm()

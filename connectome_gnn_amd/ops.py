@@ -192,3 +192,75 @@ class _PoolMean(torch.autograd.Function):
 
 def pool_mean(x, gptr, num_graphs: int) -> torch.Tensor:
     return _PoolMean.apply(x, gptr, num_graphs)
+
+
+class _BnActDrop(torch.autograd.Function):
+    """X' = dropout(act(BatchNorm1d(Y))) in two streaming passes each way (elementwise.hip)."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, bn_mod, relu, p, training):
+        lib = _lib.load()
+        y = _prep(y, "y")
+        m, n = y.shape
+        dev = y.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        p_eff = float(p) if training else 0.0
+        coef = torch.empty(4 * n, **f32)
+        x = torch.empty_like(y)
+        mask = torch.empty(m * (n // 4), dtype=torch.uint8, device=dev) if p_eff > 0 else None
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p_eff > 0 else 0
+        st = _lib.stream_ptr
+        with torch.cuda.device(dev):
+            rows = int(lib.cgnn_bn_act_slab_rows(m))
+            slab = torch.empty(rows, 2 * n, dtype=torch.float64, device=dev) if training else None
+            if training:
+                _lib.check(lib.cgnn_bn_act_fwd_stats(_lib.ptr(y), m, n, _lib.ptr(slab), st()),
+                           "cgnn_bn_act_fwd_stats")
+            _lib.check(lib.cgnn_bn_act_finalize(
+                _lib.ptr(slab), rows, n, float(max(m, 1)), int(training), _lib.ptr(gamma.contiguous()),
+                _lib.ptr(beta.contiguous()), _lib.ptr(bn_mod.running_mean), _lib.ptr(bn_mod.running_var),
+                float(bn_mod.momentum), float(bn_mod.eps),
+                _lib.ptr(bn_mod.num_batches_tracked) if training else None, _lib.ptr(coef), st()),
+                "cgnn_bn_act_finalize")
+            _lib.check(lib.cgnn_bn_act_fwd_apply(_lib.ptr(y), _lib.ptr(coef), int(relu), p_eff, seed,
+                                                 _lib.ptr(mask), _lib.ptr(x), m, n, st()),
+                       "cgnn_bn_act_fwd_apply")
+        ctx.save_for_backward(y, coef, mask)
+        ctx.cfg = (bool(relu), p_eff, bool(training))
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        lib = _lib.load()
+        y, coef, mask = ctx.saved_tensors
+        relu, p_eff, training = ctx.cfg
+        dx = _prep(dx, "grad")
+        m, n = y.shape
+        dev = y.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        st = _lib.stream_ptr
+        dgamma, dbeta, bwc = torch.empty(n, **f32), torch.empty(n, **f32), torch.empty(2 * n, **f32)
+        dy = torch.empty_like(y)
+        with torch.cuda.device(dev):
+            rows = int(lib.cgnn_bn_act_slab_rows(m))
+            slab = torch.empty(rows, 2 * n, dtype=torch.float64, device=dev)
+            _lib.check(lib.cgnn_bn_act_bwd_stats(_lib.ptr(dx), _lib.ptr(y), _lib.ptr(mask), _lib.ptr(coef),
+                                                 int(relu), p_eff, m, n, _lib.ptr(slab), st()),
+                       "cgnn_bn_act_bwd_stats")
+            _lib.check(lib.cgnn_bn_act_bwd_finalize(_lib.ptr(slab), rows, n, float(max(m, 1)),
+                                                    int(not training), _lib.ptr(dgamma), _lib.ptr(dbeta),
+                                                    _lib.ptr(bwc), st()), "cgnn_bn_act_bwd_finalize")
+            _lib.check(lib.cgnn_bn_act_bwd_apply(_lib.ptr(dx), _lib.ptr(y), _lib.ptr(mask), _lib.ptr(coef),
+                                                 _lib.ptr(bwc), int(relu), p_eff, _lib.ptr(dy), m, n, st()),
+                       "cgnn_bn_act_bwd_apply")
+        return dy, dgamma, dbeta, None, None, None, None
+
+
+def bn_act_drop_supported(bn_mod, width: int) -> bool:
+    """Plain nn.BatchNorm1d (affine, running stats, fixed momentum) of a power-of-two width."""
+    return (type(bn_mod) is torch.nn.BatchNorm1d and bn_mod.affine and bn_mod.track_running_stats
+            and bn_mod.momentum is not None and bool(_lib.load().cgnn_bn_act_width_ok(width)))
+
+
+def bn_act_drop(y, bn_mod, relu: bool, p: float, training: bool) -> torch.Tensor:
+    return _BnActDrop.apply(y, bn_mod.weight, bn_mod.bias, bn_mod, relu, p, training)

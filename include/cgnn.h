@@ -304,6 +304,37 @@ int cgnn_slab_reduce_f32(const float* slab, int32_t rows, int32_t out_rows, int3
 int cgnn_slab_reduce_f64(const double* slab, int32_t rows, int32_t width, float* out,
                          void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * BatchNorm1d (+ReLU) + dropout for the layered path (any power-of-two width 4..1024),
+ * models.py:208-210 (GCN: BN, ReLU, dropout) and :260-261 (SAGE: BN, dropout):
+ *   forward : cgnn_bn_act_fwd_stats -> cgnn_bn_act_finalize -> cgnn_bn_act_fwd_apply
+ *             X' = drop(act(a*Y + b)); coef float[4N] = a | b | mean | invstd
+ *   backward: cgnn_bn_act_bwd_stats -> cgnn_bn_act_bwd_finalize -> cgnn_bn_act_bwd_apply
+ *             dY = a*(dX'*drop'*act' - c1 - xhat*c2); bwc float[2N] = c1 | c2
+ * slabs: fp64 [cgnn_bn_act_slab_rows(M)][2N]; mask: one byte (4 keep bits) per 4-column chunk,
+ * [M*N/4] bytes, may be NULL when p_drop == 0.  Semantics of nn.BatchNorm1d as in
+ * cgnn_bn_finalize (training: batch stats + running update; eval: running stats).
+ * ------------------------------------------------------------------------------------- */
+int cgnn_bn_act_width_ok(int32_t N);
+int64_t cgnn_bn_act_slab_rows(int64_t M);
+int cgnn_bn_act_fwd_stats(const float* Y, int64_t M, int32_t N, double* slab, void* stream);
+int cgnn_bn_act_finalize(const double* slab, int32_t rows, int32_t N, double count, int32_t training,
+                         const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, float momentum, float eps,
+                         int64_t* num_batches_tracked, float* coef, void* stream);
+int cgnn_bn_act_fwd_apply(const float* Y, const float* coef, int32_t relu, float p_drop,
+                          uint64_t seed, uint8_t* mask_out, float* X, int64_t M, int32_t N,
+                          void* stream);
+int cgnn_bn_act_bwd_stats(const float* dX, const float* Y, const uint8_t* mask, const float* coef,
+                          int32_t relu, float p_drop, int64_t M, int32_t N, double* slab,
+                          void* stream);
+int cgnn_bn_act_bwd_finalize(const double* slab, int32_t rows, int32_t N, double count,
+                             int32_t zero_coef, float* dgamma, float* dbeta, float* bwc,
+                             void* stream);
+int cgnn_bn_act_bwd_apply(const float* dX, const float* Y, const uint8_t* mask, const float* coef,
+                          const float* bwc, int32_t relu, float p_drop, float* dY, int64_t M,
+                          int32_t N, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -211,3 +211,59 @@ def test_cpu_tensors_raise():
     g = C.generate_dataset(2, 20, 4)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         C.GCNConnectome(5, 16)(C.collate_graphs(g))
+
+
+@pytest.mark.parametrize("m,n,relu,training", [(1000, 64, True, True), (257, 128, False, True),
+                                               (4100, 32, True, True), (33, 256, False, True),
+                                               (500, 4, True, True), (300, 64, True, False),
+                                               (1, 64, False, False)])
+def test_bn_act_drop_matches_torch(m, n, relu, training):
+    """Layered path's fused BatchNorm(+ReLU)+dropout kernels vs torch CPU (dropout 0 = exact
+    semantics: batch stats / running stats, running-stat update, all gradients)."""
+    from connectome_gnn_amd import ops
+    g = torch.Generator().manual_seed(m + n)
+    y = torch.randn(m, n, generator=g) * 1.7 + 0.3
+    cot = torch.randn(m, n, generator=g)
+
+    def make():
+        bn = torch.nn.BatchNorm1d(n)
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, n)); bn.bias.copy_(torch.linspace(-0.2, 0.3, n))
+            bn.running_mean.copy_(torch.linspace(-0.1, 0.1, n)); bn.running_var.copy_(torch.linspace(0.8, 1.3, n))
+        return bn.train(training)
+
+    ref = make()
+    yc = y.clone().requires_grad_(True)
+    out_r = ref(yc)
+    out_r = torch.relu(out_r) if relu else out_r
+    (out_r * cot).sum().backward()
+    mod = make().to(DEV)
+    assert ops.bn_act_drop_supported(mod, n)
+    yd = y.to(DEV).requires_grad_(True)
+    out = ops.bn_act_drop(yd, mod, relu, 0.0, training)
+    (out * cot.to(DEV)).sum().backward()
+    torch.testing.assert_close(out.cpu(), out_r, rtol=1e-5, atol=2e-6)
+    if m > 1 or not training:
+        torch.testing.assert_close(yd.grad.cpu(), yc.grad, rtol=1e-4, atol=2e-6 + 1e-5 * float(yc.grad.abs().max()))
+        for a, b in ((mod.weight.grad, ref.weight.grad), (mod.bias.grad, ref.bias.grad)):
+            torch.testing.assert_close(a.cpu(), b, rtol=1e-4, atol=1e-5 * float(b.abs().max()) + 1e-6)
+    torch.testing.assert_close(mod.running_mean.cpu(), ref.running_mean, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(mod.running_var.cpu(), ref.running_var, rtol=1e-5, atol=1e-6)
+    assert int(mod.num_batches_tracked) == int(ref.num_batches_tracked)
+
+
+def test_bn_act_drop_dropout_contract():
+    from connectome_gnn_amd import ops
+    y = torch.randn(20000, 64, device=DEV, requires_grad=True)
+    mod = torch.nn.BatchNorm1d(64).to(DEV).train()
+    out = ops.bn_act_drop(y, mod, False, 0.3, True)
+    keep = (out != 0).float().mean().item()
+    assert abs(keep - 0.7) < 0.01
+    # E[dropout(x)] = x  (scale 1/(1-p))
+    ref = torch.nn.functional.batch_norm(y.detach(), None, None, mod.weight, mod.bias, True)
+    assert abs((out.detach() - ref).mean().item()) < 0.01
+    out.sum().backward()
+    # backward uses the forward's mask: a dropped element contributes nothing through dZ
+    out2 = ops.bn_act_drop(y, mod, False, 0.3, True)
+    assert not torch.equal(out2 != 0, out != 0)                  # fresh mask per call
+    assert torch.isfinite(y.grad).all()
