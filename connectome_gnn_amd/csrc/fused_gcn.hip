@@ -253,6 +253,16 @@ __device__ __forceinline__ void reduce_stats(T (&s1)[4], T (&s2)[4], double* red
   __syncthreads();
 }
 
+// rows-in-flight policy of the aggregation (see agg_block): tunables for A/B runs
+#ifndef CGNN_FWD_G
+#define CGNN_FWD_G 4
+#endif
+#ifndef CGNN_BWD_G
+#define CGNN_BWD_G 2
+#endif
+constexpr int FWD_G = CGNN_FWD_G;
+constexpr int BWD_G = CGNN_BWD_G;
+
 // ==========================================================================================
 // forward
 // ==========================================================================================
@@ -408,7 +418,7 @@ __global__ void __launch_bounds__(NTHR) k_gcn_fwd(
       const int off1 = bk == 1 ? boff[1] : boff[2], width1 = bk == 1 ? bwid[1] : bwid[2];
       CGNN_STAMP(2)
       float4 ag[4];
-      agg_block<4, true>(tile, pre, ent + (off0 >> 1), width, q, j, ag);
+      agg_block<FWD_G, true>(tile, pre, ent + (off0 >> 1), width, q, j, ag);
       CGNN_STAMP(3)    // aggregation
       if (b + NWAVE < nblk) pre = meta_issue<true>(ent + (off1 >> 1), width1, q, j);
       off0 = off1; width = width1;
@@ -488,10 +498,6 @@ struct PoolIn {
   const uint8_t* mask_cur;       // keep bits of THIS layer's activation (or NULL)
 };
 
-#ifndef CGNN_BWD_G
-#define CGNN_BWD_G 2
-#endif
-constexpr int BWD_G = CGNN_BWD_G;
 
 template <int MAXR, bool FIRST, bool POOLIN>
 __global__ void __launch_bounds__(NTHR) k_gcn_bwd(

@@ -293,3 +293,34 @@ def test_fused_headline_shape_properties():
     torch.testing.assert_close(m2.batch_norms[2].running_mean, rm1, rtol=1e-4, atol=1e-6)
     e1.sum().backward()
     assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+
+
+def test_edge_cases_empty_graphs_and_fallbacks():
+    """Zero-node / zero-edge graphs inside a batch, a graph larger than the LDS tile (layered
+    fallback), and hidden != 64 (layered) all agree with the oracle."""
+    import connectome_gnn_amd as C
+    g_ok = C.generate_connectome(30, 4, seed=1)
+    empty = C.ConnectomeGraph(torch.zeros(0, 5), torch.zeros(2, 0, dtype=torch.long), torch.zeros(0),
+                              torch.tensor(1))
+    lonely = C.ConnectomeGraph(torch.randn(3, 5), torch.zeros(2, 0, dtype=torch.long), torch.zeros(0),
+                               torch.tensor(0))
+    big = C.generate_connectome(400, 6, seed=2)
+    for graphs, want_impl in (([g_ok, empty, lonely, g_ok], "fused"), ([g_ok, big], "layered")):
+        b = C.collate_graphs(graphs)
+        torch.manual_seed(2)
+        m = C.GCNConnectome(5, 64, dropout=0.0)
+        st = O.require_grad({k: v.clone() for k, v in m.state_dict().items()})
+        ob = O.OBatch(b.node_features, b.edge_index, b.edge_weight, b.batch, b.labels, b.ptr)
+        lo = O.gcn_forward(st, ob, 0.0, True)
+        lo.sum().backward()
+        m = m.to(DEV).train()
+        lg = m(b.to(DEV))
+        assert m.impl_used == want_impl
+        lg.sum().backward()
+        torch.testing.assert_close(lg.cpu(), lo, **TOL)
+        for k, p in m.named_parameters():
+            w = st[k].grad
+            torch.testing.assert_close(p.grad.cpu(), w, rtol=1e-4, atol=2e-6 + 1e-5 * float(w.abs().max()),
+                                       msg=lambda s: f"{k}: {s}")
+    with pytest.raises(RuntimeError, match="not applicable"):
+        C.GCNConnectome(5, 32, impl="fused").to(DEV)(C.collate_graphs([g_ok]).to(DEV))

@@ -1,0 +1,19 @@
+#!/bin/bash
+# A/B kernel timings in ONE process group on ONE box (boxes differ by >10 %):
+#   tools/ab.sh "<hipcc -D flags for A>" "<flags for B>" ...
+# builds one library per flag set into /tmp and runs tools/kernel_times.py on each, twice.
+cd "$(dirname "$0")/.."
+i=0
+for flags in "$@"; do
+  hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wno-unused-function -Wno-pass-failed $flags -shared \
+    -o /tmp/libcgnn_ab_$i.so connectome_gnn_amd/csrc/*.hip || exit 1
+  i=$((i+1))
+done
+for rep in 1 2; do
+  i=0
+  for flags in "$@"; do
+    echo "== [$flags]"
+    CGNN_LIB=/tmp/libcgnn_ab_$i.so python tools/kernel_times.py 2>/dev/null
+    i=$((i+1))
+  done
+done
