@@ -91,6 +91,9 @@ def main() -> None:
     ap.add_argument("--nbuf", type=int, default=2, help="distinct resident batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-bn", action="store_true", help="full-batch BN statistics across ranks")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay a HIP graph of the whole step (single rank; kernel timing then comes "
+                         "from a short eager pass after the timed region)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--one-device", action="store_true",
                     help="rehearsal only: every rank on cuda:0 (use with --backend gloo)")
@@ -132,10 +135,22 @@ def main() -> None:
         if args.sync_bn:
             model = cdist.convert_sync_batchnorm(model)
     sync = cdist.GradSync(model.parameters()) if world > 1 else None
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4, fused=True)
+    if args.graph and world > 1:
+        raise SystemExit("--graph is single-rank only")
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4, fused=True,
+                           capturable=bool(args.graph))
     loss_fn = torch.nn.CrossEntropyLoss()
+    graphed = None
+    if args.graph:
+        from connectome_gnn_amd.graphed import GraphedTrainStep
+        graphed = [GraphedTrainStep(model, opt, b, loss_fn) for b in batches]
 
     def step(i: int):
+        if graphed is not None:
+            return graphed[i % len(graphed)]()
+        return eager_step(i)
+
+    def eager_step(i: int):
         b = batches[i % len(batches)]
         opt.zero_grad(set_to_none=True)
         loss = loss_fn(model(b), b.labels)
@@ -163,13 +178,19 @@ def main() -> None:
     else:
         dom = f"cgnn_aggregate_f32[F={hidden}]"
         dom_bytes_fn = lambda nn_, ee: 2.0 * nn_ * hidden * 4 + 8.0 * ee + 4.0 * (nn_ + 1)
-    _lib.TIMER = _lib.KernelTimer([dom])
+    if graphed is None:
+        _lib.TIMER = _lib.KernelTimer([dom])
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)
     fence()
     dt = time.perf_counter() - t0
+    if graphed is not None:          # kernels inside a graph cannot be bracketed: time them eagerly
+        _lib.TIMER = _lib.KernelTimer([dom])
+        for i in range(4):
+            eager_step(i)
+        torch.cuda.synchronize()
     timer, _lib.TIMER = _lib.TIMER, None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -208,6 +229,7 @@ def main() -> None:
                        "edges_per_graph": e, "hidden": hidden, "layers": 3,
                        "graphs_per_gpu": bsz, "global_batch": world * bsz, "dropout": 0.3,
                        "optimizer": "Adam lr1e-3 wd1e-4", "impl": impl_used,
+                       "launch": "hip-graph replay" if graphed is not None else "eager",
                        "bn": "sync" if (world > 1 and args.sync_bn) else "per-rank",
                        "parallelism": f"graph-sharded dp{world}"},
             "step_algorithmic": {"bytes_per_graph": bpg,

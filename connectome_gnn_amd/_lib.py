@@ -57,7 +57,7 @@ PROTOTYPES = {
     "cgnn_bn_act_slab_rows": (I64, [I64]),
     "cgnn_bn_act_fwd_stats": (c_int, [P, I64, I32, P, P]),
     "cgnn_bn_act_finalize": (c_int, [P, I32, I32, F64, I32, P, P, P, P, F32, F32, P, P, P]),
-    "cgnn_bn_act_fwd_apply": (c_int, [P, P, I32, F32, U64, P, P, I64, I32, P]),
+    "cgnn_bn_act_fwd_apply": (c_int, [P, P, I32, F32, U64, P, P, P, I64, I32, P]),
     "cgnn_bn_act_bwd_stats": (c_int, [P, P, P, P, I32, F32, I64, I32, P, P]),
     "cgnn_bn_act_bwd_finalize": (c_int, [P, I32, I32, F64, I32, P, P, P, P]),
     "cgnn_bn_act_bwd_apply": (c_int, [P, P, P, P, P, I32, F32, P, I64, I32, P]),
@@ -68,10 +68,11 @@ PROTOTYPES = {
     "cgnn_gcn_dis": (c_int, [P, P, I64, P, P]),
     "cgnn_fused_grid": (c_int, []),
     "cgnn_gcn_fused_fwd_first": (c_int, [TP, P, I32, P, P, P, P, P]),
-    "cgnn_gcn_fused_fwd": (c_int, [TP, P, P, F32, U64, P, P, P, P, P, P]),
+    "cgnn_rng_advance": (c_int, [P, I32, P]),
+    "cgnn_gcn_fused_fwd": (c_int, [TP, P, P, F32, U64, P, P, P, P, P, P, P]),
     "cgnn_bn_reduce": (c_int, [P, I32, I32, P, P]),
     "cgnn_bn_finalize": (c_int, [P, F64, P, P, P, P, F32, F32, I32, P, P]),
-    "cgnn_gcn_fused_pool_fwd": (c_int, [P, P, F32, U64, P, P, I32, P, P]),
+    "cgnn_gcn_fused_pool_fwd": (c_int, [P, P, F32, U64, P, P, P, I32, P, P]),
     "cgnn_gcn_fused_pool_bwd": (c_int, [P, P, P, F32, P, P, I32, P, P, P]),
     "cgnn_bn_bwd_finalize": (c_int, [P, F64, P, P, P, P]),
     "cgnn_gcn_fused_bwd": (c_int, [TP, P, P, P, P, P, P, F32, P, P, P, P, P, P, P, P, P, P, P]),

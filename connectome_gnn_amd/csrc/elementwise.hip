@@ -16,6 +16,7 @@ struct DropCfg {
   uint32_t thr16;
   float scale;
   uint32_t key0, key1;
+  const uint32_t* dev_key;   // optional device word XOR-ed into key1 (fresh masks per graph replay)
 };
 
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
@@ -44,6 +45,7 @@ DropCfg make_drop(float p, uint64_t seed, int* use_drop) {
   d.scale = p > 0.f ? (float)(1.0 / (1.0 - (double)d.thr16 / 65536.0)) : 1.0f;
   d.key0 = (uint32_t)(seed & 0xFFFFFFFFu) * 0x9E3779B9u + 0x85EBCA6Bu;
   d.key1 = (uint32_t)(seed >> 32) ^ 0xC2B2AE35u;
+  d.dev_key = nullptr;
   return d;
 }
 
@@ -184,6 +186,7 @@ __global__ void __launch_bounds__(256) k_bn_act_apply(
     const float* __restrict__ bwc, int relu, DropCfg drop, int use_drop,
     uint8_t* __restrict__ mask_out, const uint8_t* __restrict__ mask_in, float* __restrict__ out,
     int64_t M, int N) {
+  if (drop.dev_key) drop.key1 ^= drop.dev_key[0];
   const int nch = N >> 2;
   const int64_t total = M * nch;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -255,12 +258,14 @@ int cgnn_bn_act_finalize(const double* slab, int32_t rows, int32_t N, double cou
 }
 
 int cgnn_bn_act_fwd_apply(const float* Y, const float* coef, int32_t relu, float p_drop, uint64_t seed,
-                          uint8_t* mask_out, float* X, int64_t M, int32_t N, void* stream) {
+                          const uint32_t* seed_dev, uint8_t* mask_out, float* X, int64_t M, int32_t N,
+                          void* stream) {
   if (M < 0 || !width_ok(N) || p_drop < 0.f || p_drop >= 1.f) return CGNN_EINVAL;
   if (M == 0) return CGNN_OK;
   if (!Y || !coef || !X) return CGNN_EINVAL;
   int use_drop;
   DropCfg d = make_drop(p_drop, seed, &use_drop);
+  d.dev_key = seed_dev;
   const int64_t total = M * (N >> 2);
   unsigned grid = (unsigned)((total + 255) / 256);
   if (grid > 256u * 32u) grid = 256u * 32u;

@@ -64,7 +64,14 @@ struct DropCfg {
   uint32_t thr16;     // keep iff 16-bit hash >= thr16  (thr16 = round(p * 65536))
   float scale;        // 1 / (1 - p)
   uint32_t key0, key1;
+  const uint32_t* dev_key;   // optional device word XOR-ed into key1 (graph replay: a captured
+                             // kernel advances it, so replays draw fresh masks)
 };
+
+__device__ __forceinline__ DropCfg drop_resolve(DropCfg d) {
+  if (d.dev_key) d.key1 ^= d.dev_key[0];
+  return d;
+}
 
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
@@ -269,8 +276,9 @@ constexpr int BWD_G = CGNN_BWD_G;
 template <int MAXR, bool FIRST>
 __global__ void __launch_bounds__(NTHR) k_gcn_fwd(
     cgnn_tiles t, const float* __restrict__ Xin, int F0, const float* __restrict__ bn_prev,
-    DropCfg drop, int use_drop, uint8_t* __restrict__ mask_out, const float* __restrict__ W,
+    DropCfg drop_in, int use_drop, uint8_t* __restrict__ mask_out, const float* __restrict__ W,
     const float* __restrict__ bias, float* __restrict__ Y, double* __restrict__ stat_slab) {
+  const DropCfg drop = drop_resolve(drop_in);
   __shared__ __attribute__((aligned(16))) float tile[MAXR * HID];
   __shared__ __attribute__((aligned(16))) float stg_all[NWAVE * STG_FLOATS];
   __shared__ float disl[MAXR];
@@ -808,10 +816,11 @@ __global__ void __launch_bounds__(NTHR) k_gcn_bwd(
 constexpr int PTHR = 256;   // 16 row-lanes x 16 chunks
 
 __global__ void __launch_bounds__(PTHR) k_pool_fwd(const float* __restrict__ Y,
-                                                   const float* __restrict__ bn, DropCfg drop,
+                                                   const float* __restrict__ bn, DropCfg drop_in,
                                                    int use_drop, uint8_t* __restrict__ mask_out,
                                                    const int32_t* __restrict__ gptr, int B,
                                                    float* __restrict__ P) {
+  const DropCfg drop = drop_resolve(drop_in);
   __shared__ float red[16 * HID];
   const int j = threadIdx.x & 15, rr = threadIdx.x >> 4;
   const float4 a = ld4(bn + 4 * j), b = ld4(bn + HID + 4 * j);
@@ -1080,7 +1089,13 @@ DropCfg make_drop(float p, uint64_t seed, int* use_drop) {
   d.scale = p > 0.f ? (float)(1.0 / (1.0 - (double)d.thr16 / 65536.0)) : 1.0f;
   d.key0 = (uint32_t)(seed & 0xFFFFFFFFu) * 0x9E3779B9u + 0x85EBCA6Bu;
   d.key1 = (uint32_t)(seed >> 32) ^ 0xC2B2AE35u;
+  d.dev_key = nullptr;
   return d;
+}
+
+__global__ void k_rng_advance(uint32_t* state, int n) {
+  const int i = threadIdx.x;
+  if (i < n) state[i] = mix32(state[i] + 0x9E3779B9u * (uint32_t)(i + 1));
 }
 
 bool tiles_ok(const cgnn_tiles* t) {
@@ -1117,13 +1132,21 @@ int cgnn_gcn_fused_fwd_first(const cgnn_tiles* t, const float* X0, int32_t F0, c
   return CGNN_OK;
 }
 
+int cgnn_rng_advance(uint32_t* state, int32_t n, void* stream) {
+  if (!state || n <= 0 || n > 64) return CGNN_EINVAL;
+  k_rng_advance<<<1, 64, 0, cgnn_stream(stream)>>>(state, n);
+  CGNN_CHECK_LAUNCH();
+  return CGNN_OK;
+}
+
 int cgnn_gcn_fused_fwd(const cgnn_tiles* t, const float* Yprev, const float* bn_prev, float p_drop,
-                       uint64_t seed, uint8_t* mask_out, const float* W, const float* bias,
-                       float* Y, double* stat_slab, void* stream) {
+                       uint64_t seed, const uint32_t* seed_dev, uint8_t* mask_out, const float* W,
+                       const float* bias, float* Y, double* stat_slab, void* stream) {
   if (!tiles_ok(t)) return t && t->max_tile_rows > CGNN_FUSED_MAX_ROWS ? CGNN_EUNSUPPORTED : CGNN_EINVAL;
   if (!Yprev || !bn_prev || !W || !bias || !Y || p_drop < 0.f || p_drop >= 1.f) return CGNN_EINVAL;
   int use_drop;
   DropCfg d = make_drop(p_drop, seed, &use_drop);
+  d.dev_key = seed_dev;
   k_gcn_fwd<CGNN_FUSED_MAX_ROWS, false><<<fused_grid(), NTHR, 0, cgnn_stream(stream)>>>(
       *t, Yprev, 0, bn_prev, d, use_drop, mask_out, W, bias, Y, stat_slab);
   CGNN_CHECK_LAUNCH();
@@ -1150,13 +1173,14 @@ int cgnn_bn_finalize(const double* sums, double count, const float* gamma, const
 }
 
 int cgnn_gcn_fused_pool_fwd(const float* Y, const float* bn, float p_drop, uint64_t seed,
-                            uint8_t* mask_out, const int32_t* gptr, int32_t num_graphs, float* P,
-                            void* stream) {
+                            const uint32_t* seed_dev, uint8_t* mask_out, const int32_t* gptr,
+                            int32_t num_graphs, float* P, void* stream) {
   if (num_graphs < 0 || p_drop < 0.f || p_drop >= 1.f) return CGNN_EINVAL;
   if (num_graphs == 0) return CGNN_OK;
   if (!Y || !bn || !gptr || !P) return CGNN_EINVAL;
   int use_drop;
   DropCfg d = make_drop(p_drop, seed, &use_drop);
+  d.dev_key = seed_dev;
   const int grid = num_graphs < 8 * fused_grid() ? num_graphs : 8 * fused_grid();
   k_pool_fwd<<<grid, PTHR, 0, cgnn_stream(stream)>>>(Y, bn, d, use_drop, mask_out, gptr, num_graphs, P);
   CGNN_CHECK_LAUNCH();

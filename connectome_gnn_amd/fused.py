@@ -100,7 +100,14 @@ class FusedGCNEncode(torch.autograd.Function):
         narrow0 = L >= 2 and x0.shape[1] <= 8      # layer-0 narrow form (fused_gcn_l0.hip)
         p0 = None
         st = _lib.stream_ptr
+        rng = meta.get("rng_state")       # device uint32 words: set when the step is graph-captured
+
+        def rng_ptr(i: int):
+            return None if rng is None or p <= 0 else rng.data_ptr() + 4 * i
+
         with torch.cuda.device(dev):
+            if rng is not None and p > 0:
+                _lib.check(lib.cgnn_rng_advance(_lib.ptr(rng), L + 1, st()), "cgnn_rng_advance")
             for l in range(L):
                 w, b, gamma, beta = (t.contiguous() for t in params[4 * l:4 * l + 4])
                 y = torch.empty(nn_, HID, **f32)
@@ -124,7 +131,7 @@ class FusedGCNEncode(torch.autograd.Function):
                     seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0
                     with _lib.timed("cgnn_gcn_fused_fwd"):
                         _lib.check(lib.cgnn_gcn_fused_fwd(
-                            tp, _lib.ptr(ys[-1]), _lib.ptr(bns[-1]), p, seed, _lib.ptr(mask),
+                            tp, _lib.ptr(ys[-1]), _lib.ptr(bns[-1]), p, seed, rng_ptr(l), _lib.ptr(mask),
                             _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), _lib.ptr(stat_slab), st()),
                             "cgnn_gcn_fused_fwd")
                     masks.append(mask)
@@ -158,7 +165,7 @@ class FusedGCNEncode(torch.autograd.Function):
             seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0
             pooled = torch.empty(B, HID, **f32)
             _lib.check(lib.cgnn_gcn_fused_pool_fwd(
-                _lib.ptr(ys[-1]), _lib.ptr(bns[-1]), p, seed, _lib.ptr(mask), _lib.ptr(s.gptr), B,
+                _lib.ptr(ys[-1]), _lib.ptr(bns[-1]), p, seed, rng_ptr(L), _lib.ptr(mask), _lib.ptr(s.gptr), B,
                 _lib.ptr(pooled), st()), "cgnn_gcn_fused_pool_fwd")
             masks.append(mask)
         c = _Ctx()
@@ -274,5 +281,6 @@ def encode(model, batch, structure: BatchStructure) -> torch.Tensor:
                 and dist.get_world_size(bn.process_group) > 1:
             sync_group = bn.process_group if bn.process_group is not None else dist.group.WORLD
     meta = {"structure": structure, "batch_norms": list(model.batch_norms),
-            "training": model.training, "dropout": float(model.dropout), "sync_group": sync_group}
+            "training": model.training, "dropout": float(model.dropout), "sync_group": sync_group,
+            "rng_state": getattr(model, "rng_device_state", None)}
     return FusedGCNEncode.apply(batch.node_features, meta, *params)

@@ -109,6 +109,7 @@ class _ConnectomeModel(nn.Module):
         self.dropout = dropout
         self.impl = impl              # execution path; not part of the reference API/state_dict
         self.impl_used = None
+        self.rng_device_state = None  # uint32 device words for graph-captured dropout (graphed.py)
         widths = [in_channels] + [hidden_dim] * num_layers
         self.convs = nn.ModuleList(self._layer_cls(a, b) for a, b in zip(widths, widths[1:]))
         self.batch_norms = nn.ModuleList(nn.BatchNorm1d(hidden_dim) for _ in range(num_layers))
@@ -131,11 +132,17 @@ class _ConnectomeModel(nn.Module):
         self.impl_used = "layered"
         norm = self._norm(s)                  # once per forward pass, shared by all layers
         x = batch.node_features
-        for conv, bn in zip(self.convs, self.batch_norms):
+        rng = getattr(self, "rng_device_state", None)     # set by graphed.GraphedTrainStep
+        if rng is not None and self.training and self.dropout > 0:
+            from . import _lib
+            _lib.check(_lib.load().cgnn_rng_advance(_lib.ptr(rng), len(self.convs) + 1,
+                                                    _lib.stream_ptr()), "cgnn_rng_advance")
+        for li, (conv, bn) in enumerate(zip(self.convs, self.batch_norms)):
             x = conv(x, batch.edge_index, batch.edge_weight, structure=s, norm=norm)
             if ops.bn_act_drop_supported(bn, x.shape[1]):
                 # BatchNorm (+ReLU) + dropout in two streaming HIP passes each way
-                x = ops.bn_act_drop(x, bn, self._relu_after_bn, self.dropout, self.training)
+                x = ops.bn_act_drop(x, bn, self._relu_after_bn, self.dropout, self.training,
+                                    None if rng is None else rng.data_ptr() + 4 * li)
             else:                     # SyncBatchNorm / odd widths: torch ops
                 x = self._post(bn(x))
                 x = F.dropout(x, p=self.dropout, training=self.training)
@@ -144,6 +151,15 @@ class _ConnectomeModel(nn.Module):
     def forward(self, batch: ConnectomeBatch) -> torch.Tensor:
         """Class logits [B, num_classes]."""
         return self.classifier(self.encode(batch))
+
+    def prepare_batch(self, batch: ConnectomeBatch) -> None:
+        """Build every piece of static per-batch metadata this model will use (CSR, and the
+        blocked-ELL of the fused path) now -- these builds read sizes back to the host, so they
+        must not happen inside a HIP-graph capture or a timed region."""
+        s = batch.structure()
+        if self._try_fused(batch, s):
+            from . import _lib, fused
+            s.fused_meta(fused.MAX_ROWS, _lib.load().cgnn_fused_grid())
 
     def _try_fused(self, batch, structure) -> bool:
         return False

@@ -198,7 +198,7 @@ class _BnActDrop(torch.autograd.Function):
     """X' = dropout(act(BatchNorm1d(Y))) in two streaming passes each way (elementwise.hip)."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, bn_mod, relu, p, training):
+    def forward(ctx, y, gamma, beta, bn_mod, relu, p, training, rng_word=None):
         lib = _lib.load()
         y = _prep(y, "y")
         m, n = y.shape
@@ -223,6 +223,7 @@ class _BnActDrop(torch.autograd.Function):
                 _lib.ptr(bn_mod.num_batches_tracked) if training else None, _lib.ptr(coef), st()),
                 "cgnn_bn_act_finalize")
             _lib.check(lib.cgnn_bn_act_fwd_apply(_lib.ptr(y), _lib.ptr(coef), int(relu), p_eff, seed,
+                                                 rng_word if p_eff > 0 else None,
                                                  _lib.ptr(mask), _lib.ptr(x), m, n, st()),
                        "cgnn_bn_act_fwd_apply")
         ctx.save_for_backward(y, coef, mask)
@@ -253,7 +254,7 @@ class _BnActDrop(torch.autograd.Function):
             _lib.check(lib.cgnn_bn_act_bwd_apply(_lib.ptr(dx), _lib.ptr(y), _lib.ptr(mask), _lib.ptr(coef),
                                                  _lib.ptr(bwc), int(relu), p_eff, _lib.ptr(dy), m, n, st()),
                        "cgnn_bn_act_bwd_apply")
-        return dy, dgamma, dbeta, None, None, None, None
+        return dy, dgamma, dbeta, None, None, None, None, None
 
 
 def bn_act_drop_supported(bn_mod, width: int) -> bool:
@@ -262,5 +263,6 @@ def bn_act_drop_supported(bn_mod, width: int) -> bool:
             and bn_mod.momentum is not None and bool(_lib.load().cgnn_bn_act_width_ok(width)))
 
 
-def bn_act_drop(y, bn_mod, relu: bool, p: float, training: bool) -> torch.Tensor:
-    return _BnActDrop.apply(y, bn_mod.weight, bn_mod.bias, bn_mod, relu, p, training)
+def bn_act_drop(y, bn_mod, relu: bool, p: float, training: bool, rng_word=None) -> torch.Tensor:
+    """rng_word: device address of a uint32 that a captured cgnn_rng_advance refreshes (graph replay)."""
+    return _BnActDrop.apply(y, bn_mod.weight, bn_mod.bias, bn_mod, relu, p, training, rng_word)

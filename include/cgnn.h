@@ -220,9 +220,14 @@ int cgnn_gcn_fused_fwd_first(const cgnn_tiles* t, const float* X0, int32_t F0, c
                              const float* bias, float* Y, double* stat_slab, void* stream);
 
 /* Layer l>0 forward.  Yprev [Nn,64] + bn_prev -> X on the fly; W [64,64]; mask_out nullable. */
+/* seed_dev (nullable): device word XOR-ed into the dropout key at kernel start.  Under HIP-graph
+ * replay the by-value `seed` is frozen in the graph; a captured cgnn_rng_advance on the same
+ * stream then makes every replay draw fresh masks. */
+int cgnn_rng_advance(uint32_t* state, int32_t n, void* stream);
 int cgnn_gcn_fused_fwd(const cgnn_tiles* t, const float* Yprev, const float* bn_prev,
-                       float p_drop, uint64_t seed, uint8_t* mask_out, const float* W,
-                       const float* bias, float* Y, double* stat_slab, void* stream);
+                       float p_drop, uint64_t seed, const uint32_t* seed_dev, uint8_t* mask_out,
+                       const float* W, const float* bias, float* Y, double* stat_slab,
+                       void* stream);
 
 /* slab [rows][width] fp64 -> sums [width] fp64 (fixed-order tree). */
 int cgnn_bn_reduce(const double* slab, int32_t rows, int32_t width, double* sums, void* stream);
@@ -237,8 +242,8 @@ int cgnn_bn_finalize(const double* sums, double count, const float* gamma, const
 
 /* Readout: P[g,:] = mean over nodes of drop(relu(a*Y+b)) (models.py:209-211,57-59). */
 int cgnn_gcn_fused_pool_fwd(const float* Y, const float* bn, float p_drop, uint64_t seed,
-                            uint8_t* mask_out, const int32_t* gptr, int32_t num_graphs, float* P,
-                            void* stream);
+                            const uint32_t* seed_dev, uint8_t* mask_out, const int32_t* gptr,
+                            int32_t num_graphs, float* P, void* stream);
 
 /* Backward of the readout through dropout/ReLU: dZ = dP[g]/(n_g+1e-8) * drop' * relu';
  * also the BatchNorm-backward sums of the last layer: s_slab [grid][128] = sum dZ | sum dZ*xhat.
@@ -323,8 +328,8 @@ int cgnn_bn_act_finalize(const double* slab, int32_t rows, int32_t N, double cou
                          float* running_var, float momentum, float eps,
                          int64_t* num_batches_tracked, float* coef, void* stream);
 int cgnn_bn_act_fwd_apply(const float* Y, const float* coef, int32_t relu, float p_drop,
-                          uint64_t seed, uint8_t* mask_out, float* X, int64_t M, int32_t N,
-                          void* stream);
+                          uint64_t seed, const uint32_t* seed_dev, uint8_t* mask_out, float* X,
+                          int64_t M, int32_t N, void* stream);
 int cgnn_bn_act_bwd_stats(const float* dX, const float* Y, const uint8_t* mask, const float* coef,
                           int32_t relu, float p_drop, int64_t M, int32_t N, double* slab,
                           void* stream);

@@ -324,3 +324,45 @@ def test_edge_cases_empty_graphs_and_fallbacks():
                                        msg=lambda s: f"{k}: {s}")
     with pytest.raises(RuntimeError, match="not applicable"):
         C.GCNConnectome(5, 32, impl="fused").to(DEV)(C.collate_graphs([g_ok]).to(DEV))
+
+
+def test_graphed_step_matches_eager_and_redraws_dropout():
+    """HIP-graph replay of the whole step == eager steps (dropout 0), and with dropout > 0 every
+    replay draws a fresh mask (the by-value seed is frozen in the graph; the device key is not)."""
+    import connectome_gnn_amd as C
+    from connectome_gnn_amd.graphed import GraphedTrainStep
+    b = C.collate_graphs(C.generate_dataset(32, 84, 8, seed=6)).to(DEV)
+    b.structure()
+
+    def run(graph: bool, steps=4):
+        torch.manual_seed(11)
+        m = C.GCNConnectome(5, 64, dropout=0.0).to(DEV).train()
+        opt = torch.optim.Adam(m.parameters(), lr=1e-2, capturable=True)
+
+        def eager():
+            opt.zero_grad(set_to_none=True)
+            loss = torch.nn.functional.cross_entropy(m(b), b.labels)
+            loss.backward(); opt.step()
+            return float(loss)
+
+        if graph:
+            # one eager warm-up step (it also creates the optimizer state OUTSIDE the graph,
+            # as torch requires), then replays
+            st = GraphedTrainStep(m, opt, b, warmup=1)
+            return [float(st()) for _ in range(steps)], m
+        eager()
+        return [eager() for _ in range(steps)], m
+
+    le, me = run(False)
+    lg, mg = run(True)
+    np.testing.assert_allclose(lg, le, rtol=1e-5, atol=1e-6)
+    for (k, p), (_, q) in zip(me.named_parameters(), mg.named_parameters()):
+        if not (k.startswith("convs.") and k.endswith(".bias")):     # zero-true-gradient bias: noise
+            torch.testing.assert_close(p, q, rtol=1e-4, atol=1e-5, msg=lambda s: f"{k}: {s}")
+    # dropout: replays must differ from each other
+    torch.manual_seed(1)
+    m = C.GCNConnectome(5, 64, dropout=0.5).to(DEV).train()
+    opt = torch.optim.SGD(m.parameters(), lr=0.0)               # frozen weights: only masks change
+    st = GraphedTrainStep(m, opt, b, warmup=1)
+    vals = {round(float(st()), 7) for _ in range(5)}
+    assert len(vals) >= 4, vals
