@@ -208,7 +208,10 @@ __global__ void __launch_bounds__(L0BTHR) k_l0_bwd(const float* __restrict__ dZ,
   }
 }
 
-int l0_grid() { return 8 * cgnn_fused_grid(); }     // workgroups (= slab rows) of both kernels
+#ifndef CGNN_L0_GRID_MULT
+#define CGNN_L0_GRID_MULT 8
+#endif
+int l0_grid() { return CGNN_L0_GRID_MULT * cgnn_fused_grid(); }     // workgroups (= slab rows) of both kernels
 
 }  // namespace
 
