@@ -152,7 +152,10 @@ def main() -> None:
 
     def eager_step(i: int):
         b = batches[i % len(batches)]
-        opt.zero_grad(set_to_none=True)
+        if sync is not None:
+            sync.zero_grad()                 # grads are views of the flat all-reduce buffer
+        else:
+            opt.zero_grad(set_to_none=True)
         loss = loss_fn(model(b), b.labels)
         loss.backward()
         if sync is not None:

@@ -71,10 +71,10 @@ PROTOTYPES = {
     "cgnn_rng_advance": (c_int, [P, I32, P]),
     "cgnn_gcn_fused_fwd": (c_int, [TP, P, P, F32, U64, P, P, P, P, P, P, P]),
     "cgnn_bn_reduce": (c_int, [P, I32, I32, P, P]),
-    "cgnn_bn_finalize": (c_int, [P, F64, P, P, P, P, F32, F32, I32, P, P]),
+    "cgnn_bn_finalize": (c_int, [P, F64, P, P, P, P, P, F32, F32, I32, P, P]),
     "cgnn_gcn_fused_pool_fwd": (c_int, [P, P, F32, U64, P, P, P, I32, P, P]),
     "cgnn_gcn_fused_pool_bwd": (c_int, [P, P, P, F32, P, P, I32, P, P, P]),
-    "cgnn_bn_bwd_finalize": (c_int, [P, F64, P, P, P, P]),
+    "cgnn_bn_bwd_finalize": (c_int, [P, F64, P, I32, P, P, P, P]),
     "cgnn_gcn_fused_bwd": (c_int, [TP, P, P, P, P, P, P, F32, P, P, P, P, P, P, P, P, P, P, P]),
     "cgnn_gcn_fused_bwd_first": (c_int, [TP, P, P, P, P, P, I32, P, P, F32, P, P, P, P, P]),
     "cgnn_bn_stats_finalize": (c_int, [P, I32, F64, P, P, P, P, F32, F32, P, P, P]),

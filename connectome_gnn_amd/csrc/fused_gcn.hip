@@ -938,11 +938,13 @@ __global__ void __launch_bounds__(256) k_slab_reduce(const T* __restrict__ slab,
 }
 
 __global__ void k_bn_finalize(const double* __restrict__ sums, double count,
+                              const double* __restrict__ count_dev,
                               const float* __restrict__ gamma, const float* __restrict__ beta,
                               float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
                               float eps, int training, float* __restrict__ bn_out) {
   const int c = threadIdx.x;
   if (c >= HID) return;
+  if (count_dev) count = count_dev[0];
   float mean, var;
   if (training) {
     const double m = sums[c] / count;
@@ -966,14 +968,16 @@ __global__ void k_bn_finalize(const double* __restrict__ sums, double count,
 }
 
 __global__ void k_bn_bwd_finalize(const double* __restrict__ sums, double count,
+                                  const double* __restrict__ count_dev, int zero_coef,
                                   float* __restrict__ dgamma, float* __restrict__ dbeta,
                                   float* __restrict__ bwc) {
   const int c = threadIdx.x;
   if (c >= HID) return;
+  if (count_dev) count = count_dev[0];
   dbeta[c] = (float)sums[c];
   dgamma[c] = (float)sums[HID + c];
-  bwc[c] = (float)(sums[c] / count);
-  bwc[HID + c] = (float)(sums[HID + c] / count);
+  bwc[c] = zero_coef ? 0.f : (float)(sums[c] / count);
+  bwc[HID + c] = zero_coef ? 0.f : (float)(sums[HID + c] / count);
 }
 
 // ---- merged "reduce the per-workgroup partials + finalise" kernels (single-GPU fast path) ----
@@ -1161,12 +1165,12 @@ int cgnn_bn_reduce(const double* slab, int32_t rows, int32_t width, double* sums
   return CGNN_OK;
 }
 
-int cgnn_bn_finalize(const double* sums, double count, const float* gamma, const float* beta,
-                     float* running_mean, float* running_var, float momentum, float eps,
-                     int32_t training, float* bn_out, void* stream) {
+int cgnn_bn_finalize(const double* sums, double count, const double* count_dev, const float* gamma,
+                     const float* beta, float* running_mean, float* running_var, float momentum,
+                     float eps, int32_t training, float* bn_out, void* stream) {
   if (!gamma || !beta || !running_mean || !running_var || !bn_out) return CGNN_EINVAL;
-  if (training && (!sums || count <= 0.0)) return CGNN_EINVAL;
-  k_bn_finalize<<<1, 64, 0, cgnn_stream(stream)>>>(sums, count, gamma, beta, running_mean,
+  if (training && (!sums || (!count_dev && count <= 0.0))) return CGNN_EINVAL;
+  k_bn_finalize<<<1, 64, 0, cgnn_stream(stream)>>>(sums, count, count_dev, gamma, beta, running_mean,
                                                    running_var, momentum, eps, training, bn_out);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
@@ -1202,10 +1206,10 @@ int cgnn_gcn_fused_pool_bwd(const float* dP, const float* Y, const float* bn, fl
   return CGNN_OK;
 }
 
-int cgnn_bn_bwd_finalize(const double* sums, double count, float* dgamma, float* dbeta, float* bwc,
-                         void* stream) {
-  if (!sums || !dgamma || !dbeta || !bwc || count <= 0.0) return CGNN_EINVAL;
-  k_bn_bwd_finalize<<<1, 64, 0, cgnn_stream(stream)>>>(sums, count, dgamma, dbeta, bwc);
+int cgnn_bn_bwd_finalize(const double* sums, double count, const double* count_dev,
+                         int32_t zero_coef, float* dgamma, float* dbeta, float* bwc, void* stream) {
+  if (!sums || !dgamma || !dbeta || !bwc || (!count_dev && count <= 0.0)) return CGNN_EINVAL;
+  k_bn_bwd_finalize<<<1, 64, 0, cgnn_stream(stream)>>>(sums, count, count_dev, zero_coef, dgamma, dbeta, bwc);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }

@@ -39,7 +39,13 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
 
 
 class GradSync:
-    """Average gradients over ranks with ONE all-reduce of a persistent flat buffer."""
+    """Average gradients over ranks with ONE all-reduce of a persistent flat buffer.
+
+    Every parameter's ``.grad`` is a permanent VIEW into the flat buffer (like DDP's
+    gradient_as_bucket_view), so a step costs one memset (``zero_grad``), backward accumulating
+    in place, and one all-reduce -- no flatten/unflatten copy kernels.  Use
+    ``sync.zero_grad()`` instead of ``optimizer.zero_grad()`` (which would drop the views).
+    """
 
     def __init__(self, params: Iterable[torch.nn.Parameter], group=None):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
@@ -48,33 +54,48 @@ class GradSync:
         ref = self.params[0]
         self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._avg = dist.is_initialized() and dist.get_backend(group) == "nccl"   # RCCL has AVG
+        self._attach()
+
+    def _attach(self) -> None:
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            off += n
+
+    def zero_grad(self) -> None:
+        """One memset; re-attaches a view if something replaced a ``.grad`` (e.g. set_to_none)."""
+        self.flat.zero_()
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            g = p.grad
+            if g is None or g.data_ptr() != self.flat.data_ptr() + off * self.flat.element_size():
+                p.grad = self.flat[off:off + n].view_as(p)
+            off += n
 
     def __call__(self, local_graphs: Optional[int] = None, global_graphs: Optional[int] = None):
         """Call between ``loss.backward()`` and ``optimizer.step()``.
         With unequal shards pass this rank's and the global graph counts."""
         if self.world == 1:
             return
-        scale = 1.0 / self.world
+        off = 0
+        for p in self.params:          # a grad that autograd replaced (not accumulated in place)
+            n = p.numel()
+            g = p.grad
+            if g is not None and g.data_ptr() != self.flat.data_ptr() + off * self.flat.element_size():
+                self.flat[off:off + n].copy_(g.reshape(-1))
+                p.grad = self.flat[off:off + n].view_as(p)
+            off += n
         if local_graphs is not None and global_graphs:
-            scale = float(local_graphs) / float(global_graphs)
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            if p.grad is None:
-                self.flat[off:off + n].zero_()
-            else:
-                self.flat[off:off + n].copy_(p.grad.reshape(-1))
-            off += n
-        self.flat.mul_(scale)
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            if p.grad is None:
-                p.grad = self.flat[off:off + n].view_as(p).clone()
-            else:
-                p.grad.copy_(self.flat[off:off + n].view_as(p))
-            off += n
+            self.flat.mul_(float(local_graphs) / float(global_graphs))
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        elif self._avg:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            self.flat.mul_(1.0 / self.world)
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> None:

@@ -58,16 +58,14 @@ def _tiles_struct(s: BatchStructure, meta, dis: torch.Tensor):
 
 class _Ctx:
     """Everything of one forward pass that backward needs and autograd must not track."""
-    __slots__ = ("s", "meta", "dis", "tiles", "grid", "ys", "bns", "masks", "p", "x0", "f0", "p0",
+    __slots__ = ("s", "meta", "dis", "tiles", "grid", "ys", "bns", "masks", "p", "x0", "f0", "p0", "count_dev",
                  "count", "sync_group", "num_layers", "training")
 
 
-def _sync_sums(sums: torch.Tensor, count: float, group) -> float:
-    """Full-batch BatchNorm across ranks: all-reduce [sum|sumsq|rows] (SURVEY 8e option i)."""
-    buf = torch.cat([sums, sums.new_tensor([count])])
+def _sync_sums(buf: torch.Tensor, group) -> None:
+    """Full-batch BatchNorm across ranks (SURVEY 8e option i): one all-reduce of the fp64 block
+    [sum | sumsq | rows]; everything, the row count included, stays on the device."""
     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-    sums.copy_(buf[:-1])
-    return float(buf[-1])
 
 
 class FusedGCNEncode(torch.autograd.Function):
@@ -92,11 +90,14 @@ class FusedGCNEncode(torch.autograd.Function):
         tp = ctypes.byref(tiles)
         f32 = dict(dtype=torch.float32, device=dev)
         stat_slab = torch.empty(grid, 128, dtype=torch.float64, device=dev) if training else None
-        sums = torch.empty(128, dtype=torch.float64, device=dev) if training else None
+        # [sum(64) | sumsq(64) | rows]: the 129th word carries this rank's row count through the
+        # sync-BN all-reduce
+        sums = torch.empty(129, dtype=torch.float64, device=dev) if training else None
         ys: List[torch.Tensor] = []
         bns: List[torch.Tensor] = []
         masks: List[Optional[torch.Tensor]] = []
         local_count = count = float(nn_)
+        count_dev = None                           # device copy of the global row count (sync-BN)
         narrow0 = L >= 2 and x0.shape[1] <= 8      # layer-0 narrow form (fused_gcn_l0.hip)
         p0 = None
         st = _lib.stream_ptr
@@ -147,18 +148,21 @@ class FusedGCNEncode(torch.autograd.Function):
                         _lib.ptr(bn_mod.num_batches_tracked), _lib.ptr(bn), st()),
                         "cgnn_bn_stats_finalize")
                 else:
+                    cnt_dev = None
                     if training:
                         _lib.check(lib.cgnn_bn_reduce(_lib.ptr(slab), slab_rows, 128, _lib.ptr(sums), st()),
                                    "cgnn_bn_reduce")
-                        cnt = _sync_sums(sums, local_count, sync_group)
+                        sums[128] = local_count
+                        _sync_sums(sums, sync_group)
+                        cnt_dev = sums.data_ptr() + 128 * 8
+                        if count_dev is None:
+                            count_dev = sums[128:129].clone()     # global rows, for backward
                         bn_mod.num_batches_tracked.add_(1)
                     _lib.check(lib.cgnn_bn_finalize(
-                        _lib.ptr(sums), cnt, _lib.ptr(gamma), _lib.ptr(beta),
+                        _lib.ptr(sums), cnt, cnt_dev, _lib.ptr(gamma), _lib.ptr(beta),
                         _lib.ptr(bn_mod.running_mean), _lib.ptr(bn_mod.running_var),
                         float(bn_mod.momentum), float(bn_mod.eps), int(training), _lib.ptr(bn), st()),
                         "cgnn_bn_finalize")
-                if l == 0:
-                    count = cnt
                 ys.append(y)
                 bns.append(bn)
             mask = torch.empty(nn_ * 16, dtype=torch.uint8, device=dev) if p > 0 else None
@@ -172,6 +176,7 @@ class FusedGCNEncode(torch.autograd.Function):
         c.s, c.meta, c.dis, c.tiles, c.grid = s, fmeta, dis, tiles, grid
         c.ys, c.bns, c.masks, c.p, c.x0, c.f0, c.p0 = ys, bns, masks, p, x0, x0.shape[1], p0
         c.count, c.sync_group, c.num_layers, c.training = count, sync_group, L, training
+        c.count_dev = count_dev
         ctx.c = c
         ctx.save_for_backward(*params)
         return pooled
@@ -208,11 +213,10 @@ class FusedGCNEncode(torch.autograd.Function):
                 _lib.check(lib.cgnn_bn_reduce(_lib.ptr(s_slab), grid, 128, _lib.ptr(sums), st()),
                            "cgnn_bn_reduce")
                 dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=c.sync_group)
-                _lib.check(lib.cgnn_bn_bwd_finalize(_lib.ptr(sums), c.count, _lib.ptr(dgamma),
+                _lib.check(lib.cgnn_bn_bwd_finalize(_lib.ptr(sums), c.count, _lib.ptr(c.count_dev),
+                                                    int(not c.training), _lib.ptr(dgamma),
                                                     _lib.ptr(dbeta), _lib.ptr(bwc), st()),
                            "cgnn_bn_bwd_finalize")
-                if not c.training:
-                    bwc.zero_()      # eval-mode BatchNorm is a fixed affine map: dY = a * dZ
             grads[4 * l + 2], grads[4 * l + 3] = dgamma, dbeta
             return bwc
 

@@ -28,7 +28,10 @@ class Trainer:
     def train_step(self, batch) -> torch.Tensor:
         """One optimisation step (reference train.py:46-51); returns the detached device loss."""
         batch = batch.to(self.device)
-        self.optimizer.zero_grad()
+        if hasattr(self.grad_sync, "zero_grad"):
+            self.grad_sync.zero_grad()       # keeps .grad as views of the all-reduce buffer
+        else:
+            self.optimizer.zero_grad()
         loss = self.loss_fn(self.model(batch), batch.labels)
         loss.backward()
         if self.grad_sync is not None:

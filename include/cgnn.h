@@ -236,9 +236,11 @@ int cgnn_bn_reduce(const double* slab, int32_t rows, int32_t width, double* sums
  * eps, momentum; running_var gets the unbiased variance).  training != 0: from sums
  * (sum(y)|sum(y^2), [128]) over `count` rows, and running stats are updated in place;
  * training == 0: from running stats.  bn_out float[4*64]. */
-int cgnn_bn_finalize(const double* sums, double count, const float* gamma, const float* beta,
-                     float* running_mean, float* running_var, float momentum, float eps,
-                     int32_t training, float* bn_out, void* stream);
+/* count_dev (nullable): device double that overrides `count` -- the all-reduced row count of a
+ * multi-rank batch stays on the device, no host read-back between reduce and finalise. */
+int cgnn_bn_finalize(const double* sums, double count, const double* count_dev, const float* gamma,
+                     const float* beta, float* running_mean, float* running_var, float momentum,
+                     float eps, int32_t training, float* bn_out, void* stream);
 
 /* Readout: P[g,:] = mean over nodes of drop(relu(a*Y+b)) (models.py:209-211,57-59). */
 int cgnn_gcn_fused_pool_fwd(const float* Y, const float* bn, float p_drop, uint64_t seed,
@@ -253,8 +255,8 @@ int cgnn_gcn_fused_pool_bwd(const float* dP, const float* Y, const float* bn, fl
                             float* dZ, double* s_slab, void* stream);
 
 /* BatchNorm backward coefficients: dgamma = sum dZ*xhat, dbeta = sum dZ, bwc = [c1|c2]. */
-int cgnn_bn_bwd_finalize(const double* sums, double count, float* dgamma, float* dbeta,
-                         float* bwc, void* stream);
+int cgnn_bn_bwd_finalize(const double* sums, double count, const double* count_dev,
+                         int32_t zero_coef, float* dgamma, float* dbeta, float* bwc, void* stream);
 
 /* Layer l>0 backward.  Inputs: dZ (grad wrt BN output of layer l), Y (its pre-BN output), bn,
  * bwc; previous layer's Yprev/bn_prev/mask_prev (to rebuild X_l and apply relu'/drop').

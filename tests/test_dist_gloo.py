@@ -71,9 +71,22 @@ def _worker(rank, world, port, q):
         for p, g in zip(params, full):
             torch.testing.assert_close(p.grad, g, rtol=1e-5, atol=1e-7)
         # --- sync-BN sum exchange of the fused encoder: [sum | sumsq] + row count
-        sums = torch.arange(128, dtype=torch.float64) * (rank + 1)
-        cnt = _sync_sums(sums, 10.0 * (rank + 1), None)
-        assert cnt == 30.0 and torch.equal(sums, torch.arange(128, dtype=torch.float64) * 3)
+        buf = torch.cat([torch.arange(128, dtype=torch.float64) * (rank + 1),
+                         torch.tensor([10.0 * (rank + 1)], dtype=torch.float64)])
+        _sync_sums(buf, None)
+        assert float(buf[128]) == 30.0 and torch.equal(buf[:128], torch.arange(128, dtype=torch.float64) * 3)
+        # --- grads as permanent views of the flat buffer: zero_grad + in-place accumulation
+        sync.zero_grad()
+        b = O.collate([g.node_features for g in [graphs[i] for i in mine]],
+                      [g.edge_index for g in [graphs[i] for i in mine]],
+                      [g.edge_weight for g in [graphs[i] for i in mine]],
+                      [g.label for g in [graphs[i] for i in mine]])
+        torch.nn.functional.cross_entropy(O.gcn_forward(st, b, 0.0, False), b.labels).backward()
+        lo, hi = sync.flat.data_ptr(), sync.flat.data_ptr() + sync.flat.numel() * 4
+        assert all(lo <= p.grad.data_ptr() < hi for p in params)      # still views: no copies
+        sync()
+        for p, g in zip(params, full):
+            torch.testing.assert_close(p.grad, g, rtol=1e-5, atol=1e-7)
         # --- sharded loader: same global order on all ranks, disjoint contiguous shards
         torch.manual_seed(11)
         ld = C.ConnectomeDataLoader(graphs, batch_size=4, shuffle=True, rank=rank, world_size=world)
