@@ -212,11 +212,15 @@ class FusedGCNEncode(torch.autograd.Function):
             else:
                 _lib.check(lib.cgnn_bn_reduce(_lib.ptr(s_slab), grid, 128, _lib.ptr(sums), st()),
                            "cgnn_bn_reduce")
+                # parameter gradients are the LOCAL sums (the gradient all-reduce averages them,
+                # exactly like torch's SyncBatchNorm); c1|c2 need the sums over all ranks
+                local_dbeta, local_dgamma = sums[:HID].float(), sums[HID:].float()
                 dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=c.sync_group)
                 _lib.check(lib.cgnn_bn_bwd_finalize(_lib.ptr(sums), c.count, _lib.ptr(c.count_dev),
                                                     int(not c.training), _lib.ptr(dgamma),
                                                     _lib.ptr(dbeta), _lib.ptr(bwc), st()),
                            "cgnn_bn_bwd_finalize")
+                dgamma, dbeta = local_dgamma, local_dbeta
             grads[4 * l + 2], grads[4 * l + 3] = dgamma, dbeta
             return bwc
 
