@@ -16,6 +16,16 @@
 //   C/D reg r of lane l: row = (r&3) + 8*(r>>2) + 4*(l>>5), col = l&31
 #include "common.h"
 
+// weight-stationary kernels for the wide, tall shapes (gemm_ws.hip); false = not applicable
+bool cgnn_ws_linear_fwd(const float* X1, int64_t ldx1, int K1, const float* X2, int64_t ldx2,
+                        int K2, const float* W, const float* bias, int relu, float* Y,
+                        int64_t ldy, int64_t M, int N, hipStream_t st);
+bool cgnn_ws_linear_bwd_input(const float* dY, int64_t lddy, const float* W, int ldw, int k0,
+                              float* dX, int64_t lddx, int64_t M, int N, int K, hipStream_t st);
+int64_t cgnn_ws_bwd_weight_partials(int64_t M, int N, int K);
+bool cgnn_ws_linear_bwd_weight(const float* dY, int64_t lddy, const float* X, int64_t ldx,
+                               float* slab, int64_t M, int N, int K, hipStream_t st);
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -300,6 +310,10 @@ int cgnn_linear_fwd_f32(const float* X1, int64_t ldx1, int32_t K1, const float* 
   if (K2 > 0 && (!X2 || ldx2 < K2)) return CGNN_EINVAL;
   if (M == 0) return CGNN_OK;
   if (!X1 || !W || !Y) return CGNN_EINVAL;
+  if (cgnn_ws_linear_fwd(X1, ldx1, K1, X2, ldx2, K2, W, bias, relu, Y, ldy, M, N, cgnn_stream(stream))) {
+    CGNN_CHECK_LAUNCH();
+    return CGNN_OK;
+  }
   dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
   k_linear_fwd<<<grid, 256, 0, cgnn_stream(stream)>>>(X1, ldx1, K1, X2, ldx2, K2, W, bias, relu, Y,
                                                       ldy, M, N);
@@ -314,6 +328,10 @@ int cgnn_linear_bwd_input_f32(const float* dY, int64_t lddy, const float* W, int
     return CGNN_EINVAL;
   if (M == 0) return CGNN_OK;
   if (!dY || !W || !dX) return CGNN_EINVAL;
+  if (cgnn_ws_linear_bwd_input(dY, lddy, W, ldw, k0, dX, lddx, M, N, K, cgnn_stream(stream))) {
+    CGNN_CHECK_LAUNCH();
+    return CGNN_OK;
+  }
   dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((K + BN - 1) / BN));
   k_linear_bwd_input<<<grid, 256, 0, cgnn_stream(stream)>>>(dY, lddy, W, ldw, k0, dX, lddx, M, N, K);
   CGNN_CHECK_LAUNCH();
@@ -324,6 +342,8 @@ int64_t cgnn_linear_bwd_weight_workspace_bytes(int64_t M, int32_t N, int32_t K) 
   if (M < 0 || N <= 0 || K <= 0) return CGNN_EINVAL;
   int64_t nchunks = (M + WCHUNK - 1) / WCHUNK;
   if (nchunks == 0) nchunks = 1;
+  const int64_t ws = cgnn_ws_bwd_weight_partials(M, N, K);
+  if (ws > nchunks) nchunks = ws;
   return cgnn_align_up(nchunks * (int64_t)N * K * (int64_t)sizeof(float), 256);
 }
 
@@ -335,9 +355,12 @@ int cgnn_linear_bwd_weight_f32(const float* dY, int64_t lddy, const float* X, in
   if (!dW || !slab) return CGNN_EINVAL;
   if (M > 0 && (!dY || !X)) return CGNN_EINVAL;
   hipStream_t st = cgnn_stream(stream);
-  const int64_t nchunks = (M + WCHUNK - 1) / WCHUNK;
+  int64_t nchunks = (M + WCHUNK - 1) / WCHUNK;
   const int tiles_n = (N + 63) / 64, tiles_k = (K + 63) / 64;
-  if (nchunks > 0) {
+  if (cgnn_ws_linear_bwd_weight(dY, lddy, X, ldx, static_cast<float*>(slab), M, N, K, st)) {
+    CGNN_CHECK_LAUNCH();
+    nchunks = cgnn_ws_bwd_weight_partials(M, N, K);
+  } else if (nchunks > 0) {
     dim3 grid((unsigned)nchunks, (unsigned)(tiles_n * tiles_k));
     k_linear_bwd_weight<<<grid, 256, 0, st>>>(dY, lddy, X, ldx, static_cast<float*>(slab), M, N, K,
                                               tiles_n, tiles_k);

@@ -145,7 +145,11 @@ def test_aggregate_deterministic():
 @pytest.mark.parametrize("m,k1,k2,n,relu,bias", [
     (300, 5, 0, 64, False, False), (1000, 64, 0, 64, False, True), (257, 10, 10, 32, True, True),
     (129, 64, 64, 128, True, True), (64, 128, 128, 128, True, True), (77, 33, 0, 7, False, True),
-    (4100, 256, 0, 256, False, False), (1, 4, 0, 7, False, True)])
+    (4100, 256, 0, 256, False, False), (1, 4, 0, 7, False, True),
+    # tall shapes -> the weight-stationary kernels of gemm_ws.hip (M >= 4096, N in {64,128})
+    (5003, 128, 128, 128, True, True), (4097, 64, 64, 64, True, True), (6000, 128, 0, 128, False, True),
+    (4500, 64, 0, 64, False, False), (8191, 64, 64, 128, True, False), (4096, 32, 0, 64, False, True),
+    (4700, 256, 0, 128, False, True), (5001, 128, 0, 64, True, True)])
 def test_linear_forward_backward(m, k1, k2, n, relu, bias):
     from connectome_gnn_amd import ops
     g = torch.Generator().manual_seed(m + n)
