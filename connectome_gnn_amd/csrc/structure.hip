@@ -216,7 +216,7 @@ __global__ void k_bell_width(const int32_t* __restrict__ tile_ptr,
 __global__ void __launch_bounds__(256) k_bell_fill(
     const int32_t* __restrict__ tile_ptr, const int32_t* __restrict__ tile_blk, int num_tiles,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-    const int32_t* __restrict__ eid, const float* __restrict__ w,
+    const int32_t* __restrict__ eid, const float* __restrict__ w, float self_weight,
     const int32_t* __restrict__ blk_off, uint2* __restrict__ ent) {
   const int t = blockIdx.x;
   if (t >= num_tiles) return;
@@ -238,8 +238,8 @@ __global__ void __launch_bounds__(256) k_bell_fill(
         e.x = (uint32_t)(col[beg + s] - base) * 256u;
         e.y = __float_as_uint(w[eid[beg + s]]);
       } else if (s == deg) {
-        e.x = (uint32_t)r * 256u;               // the appended self-loop, weight 1, last
-        e.y = __float_as_uint(1.0f);
+        e.x = (uint32_t)r * 256u;               // the appended self-loop (GCN: weight 1), last
+        e.y = __float_as_uint(self_weight);
       }
       ent[(int64_t)off + 16 * s + i] = e;
     }
@@ -391,12 +391,13 @@ int cgnn_bell_plan(const int32_t* tile_ptr, const int32_t* tile_blk, int32_t num
 
 int cgnn_bell_fill(const int32_t* tile_ptr, const int32_t* tile_blk, int32_t num_tiles,
                    const int32_t* rowptr, const int32_t* col, const int32_t* eid,
-                   const float* edge_weight, const int32_t* blk_off, void* entries, void* stream) {
+                   const float* edge_weight, float self_weight, const int32_t* blk_off,
+                   void* entries, void* stream) {
   if (num_tiles < 0) return CGNN_EINVAL;
   if (num_tiles == 0) return CGNN_OK;
   if (!tile_ptr || !tile_blk || !rowptr || !blk_off || !entries) return CGNN_EINVAL;
   k_bell_fill<<<num_tiles, 256, 0, cgnn_stream(stream)>>>(tile_ptr, tile_blk, num_tiles, rowptr, col,
-                                                         eid, edge_weight, blk_off,
+                                                         eid, edge_weight, self_weight, blk_off,
                                                          static_cast<uint2*>(entries));
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;

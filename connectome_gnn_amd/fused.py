@@ -45,15 +45,7 @@ def eligible(model, batch, structure: BatchStructure) -> Optional[str]:
 
 
 def _tiles_struct(s: BatchStructure, meta, dis: torch.Tensor):
-    t = _lib.CgnnTiles()
-    t.num_nodes = s.num_nodes
-    t.num_tiles = int(meta.tile_ptr.numel()) - 1
-    t.max_tile_rows = meta.max_tile_rows
-    t.tile_ptr, t.tile_blk = meta.tile_ptr.data_ptr(), meta.tile_blk.data_ptr()
-    t.blk_off_dst, t.ent_dst = meta.blk_off_dst.data_ptr(), meta.ent_dst.data_ptr()
-    t.blk_off_src, t.ent_src = meta.blk_off_src.data_ptr(), meta.ent_src.data_ptr()
-    t.dis = dis.data_ptr()
-    return t
+    return s.tiles_struct(meta, dis)
 
 
 class _Ctx:

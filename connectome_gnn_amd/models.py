@@ -31,6 +31,14 @@ from .graph import ConnectomeBatch
 from .structure import BatchStructure, GcnNorm, SageNorm, _require_device
 
 
+_TILE_ROWS = 384
+
+
+def _grid() -> int:
+    from . import _lib
+    return int(_lib.load().cgnn_fused_grid())
+
+
 class _AdHocBatch:
     """Lets a layer be called with raw (x, edge_index, edge_weight) like the reference's
     GCNLayer/SAGELayer (models.py:84-89,136-141): one graph, no batch vector."""
@@ -67,7 +75,12 @@ class GCNLayer(nn.Module):
         if w.shape[1] < w.shape[0]:
             # A_hat (X W^T) == (A_hat X) W^T: aggregate at the narrower width first
             return ops.linear(ops.aggregate(x, None, fwd, bwd), None, w, self.bias)
-        return ops.aggregate(ops.linear(x, None, w, None), self.bias, fwd, bwd)
+        t = ops.linear(x, None, w, None)
+        if s.tiled_ok(t.shape[1]):
+            # wide features: LDS-staged tiles, dis * (A_w + I)(dis * T) with the self-loop in the ELL
+            meta = s.fused_meta(_TILE_ROWS, _grid(), 1.0)
+            return ops.aggregate_tiled(t, self.bias, s, meta, pre=norm.dis, post=norm.dis)
+        return ops.aggregate(t, self.bias, fwd, bwd)
 
 
 class SAGELayer(nn.Module):
@@ -86,8 +99,13 @@ class SAGELayer(nn.Module):
         if norm is None:
             norm = structure.sage_norm()
         s = structure
-        agg = ops.aggregate(x, None, (s.rowptr_dst, s.col_dst, norm.w_dst, None, norm.den),
-                            (s.rowptr_src, s.col_src, norm.coef_src_bwd))
+        if s.tiled_ok(x.shape[1]):
+            # wide features: LDS-staged tiles, (A_w X) / (wsum + 1e-8), no self-loop
+            meta = s.fused_meta(_TILE_ROWS, _grid(), 0.0)
+            agg = ops.aggregate_tiled(x, None, s, meta, post=norm.den, post_div=True)
+        else:
+            agg = ops.aggregate(x, None, (s.rowptr_dst, s.col_dst, norm.w_dst, None, norm.den),
+                                (s.rowptr_src, s.col_src, norm.coef_src_bwd))
         # the [x || agg] concat is never materialised: two K-panels of one GEMM, ReLU epilogue
         return ops.linear(x, agg, self.linear.weight, self.linear.bias, relu=True)
 
@@ -160,6 +178,8 @@ class _ConnectomeModel(nn.Module):
         if self._try_fused(batch, s):
             from . import _lib, fused
             s.fused_meta(fused.MAX_ROWS, _lib.load().cgnn_fused_grid())
+        elif s.tiled_ok(self.convs[-1].linear.weight.shape[0]):
+            s.fused_meta(_TILE_ROWS, _grid(), 1.0 if self._relu_after_bn else 0.0)
 
     def _try_fused(self, batch, structure) -> bool:
         return False

@@ -117,6 +117,54 @@ class _Aggregate(torch.autograd.Function):
         return dx, db, None, None
 
 
+AGG_TRANSPOSED, AGG_PRE_DIV, AGG_POST_DIV, AGG_ACCUMULATE = 1, 2, 4, 8   # include/cgnn.h
+
+
+def aggregate_tiled_raw(structure, meta, flags: int, x, pre, post, bias, out=None) -> torch.Tensor:
+    """Y (+)= post * A(pre * X) (+bias) through cgnn_aggregate_tiled_f32 (LDS-staged tiles)."""
+    lib = _lib.load()
+    n, f = x.shape
+    y = torch.empty(n, f, dtype=torch.float32, device=x.device) if out is None else out
+    tiles = structure.tiles_struct(meta)
+    import ctypes
+    with torch.cuda.device(x.device), _lib.timed("cgnn_aggregate_tiled_f32", f"F={f}"):
+        _lib.check(lib.cgnn_aggregate_tiled_f32(
+            ctypes.byref(tiles), int(flags), _lib.ptr(x), x.stride(0), f, _lib.ptr(pre), _lib.ptr(post),
+            _lib.ptr(bias), _lib.ptr(y), y.stride(0), _lib.stream_ptr()), "cgnn_aggregate_tiled_f32")
+    return y
+
+
+class _AggregateTiled(torch.autograd.Function):
+    """Y = post * A(pre * X) + bias on the blocked-ELL tiles; backward = the transposed ELL with
+    pre and post swapped."""
+
+    @staticmethod
+    def forward(ctx, x, bias, structure, meta, pre, post, pre_div, post_div):
+        x = _prep(x, "x")
+        bias_c = _prep(bias, "bias")
+        flags = (AGG_PRE_DIV if pre_div else 0) | (AGG_POST_DIV if post_div else 0)
+        y = aggregate_tiled_raw(structure, meta, flags, x, pre, post, bias_c)
+        ctx.cfg = (structure, meta, pre, post, pre_div, post_div)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        structure, meta, pre, post, pre_div, post_div = ctx.cfg
+        dy = _prep(dy, "grad")
+        dx = db = None
+        if ctx.needs_input_grad[0]:
+            flags = AGG_TRANSPOSED | (AGG_PRE_DIV if post_div else 0) | (AGG_POST_DIV if pre_div else 0)
+            dx = aggregate_tiled_raw(structure, meta, flags, dy, post, pre, None)
+        if ctx.has_bias and ctx.needs_input_grad[1]:
+            db = colsum_raw(dy)
+        return dx, db, None, None, None, None, None, None
+
+
+def aggregate_tiled(x, bias, structure, meta, pre=None, post=None, pre_div=False, post_div=False):
+    return _AggregateTiled.apply(x, bias, structure, meta, pre, post, pre_div, post_div)
+
+
 def aggregate(x, bias, fwd, bwd) -> torch.Tensor:
     """fwd = (rowptr, col, coef, selfc|None, rowdiv|None) on the dst-sorted CSR;
     bwd = (rowptr, col, coef) on the src-sorted CSR (coef already divided by rowdiv)."""

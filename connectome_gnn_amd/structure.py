@@ -41,6 +41,9 @@ class SageNorm:
     coef_src_bwd: torch.Tensor   # [Ee]  w_e / den[dst_e] in src-CSR slot order
 
 
+TILED_MAX_ROWS = 384      # CGNN_FUSED_MAX_ROWS: rows of one LDS tile
+
+
 @dataclass
 class FusedMeta:
     """Static per-batch metadata of the fused per-tile kernels (see include/cgnn.h)."""
@@ -183,10 +186,11 @@ class BatchStructure:
             self._tiles[key] = (t, rows)
         return self._tiles[key]
 
-    def fused_meta(self, max_rows: int, num_workgroups: int) -> FusedMeta:
-        """Blocked-ELL metadata for the fused kernels, built once per batch by the HIP library
-        (cgnn_bell_plan / cgnn_bell_fill / cgnn_gather_f32)."""
-        key = ("meta", max_rows, num_workgroups)
+    def fused_meta(self, max_rows: int, num_workgroups: int, self_weight: float = 1.0) -> FusedMeta:
+        """Blocked-ELL metadata for the fused / tiled kernels, built once per batch by the HIP
+        library (cgnn_bell_plan / cgnn_bell_fill / cgnn_gather_f32).  self_weight: weight of the
+        appended self-loop entry (GCN 1, GraphSAGE 0 = no self-loop)."""
+        key = ("meta", max_rows, num_workgroups, float(self_weight))
         if key in self._tiles:
             return self._tiles[key]
         lib = _lib.load()
@@ -212,8 +216,9 @@ class BatchStructure:
                 ent = torch.empty(max(total, 1) * 8, dtype=torch.uint8, device=dev)
                 _lib.check(lib.cgnn_bell_fill(_lib.ptr(tptr), _lib.ptr(tile_blk), nt,
                                               _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(eid),
-                                              _lib.ptr(self._edge_weight), _lib.ptr(blk_off),
-                                              _lib.ptr(ent), _lib.stream_ptr()), "cgnn_bell_fill")
+                                              _lib.ptr(self._edge_weight), float(self_weight),
+                                              _lib.ptr(blk_off), _lib.ptr(ent), _lib.stream_ptr()),
+                           "cgnn_bell_fill")
                 out[name] = (blk_off, ent)
             w_src = torch.empty(self.num_edges, dtype=torch.float32, device=dev)
             _lib.check(lib.cgnn_gather_f32(_lib.ptr(self._edge_weight), _lib.ptr(self.eid_src),
@@ -223,6 +228,23 @@ class BatchStructure:
                       out["src"][1], w_src)
         self._tiles[key] = m
         return m
+
+    def tiles_struct(self, meta: FusedMeta, dis: Optional[torch.Tensor] = None):
+        """Host block of device pointers (`struct cgnn_tiles`, include/cgnn.h) for `meta`."""
+        t = _lib.CgnnTiles()
+        t.num_nodes = self.num_nodes
+        t.num_tiles = int(meta.tile_ptr.numel()) - 1
+        t.max_tile_rows = meta.max_tile_rows
+        t.tile_ptr, t.tile_blk = meta.tile_ptr.data_ptr(), meta.tile_blk.data_ptr()
+        t.blk_off_dst, t.ent_dst = meta.blk_off_dst.data_ptr(), meta.ent_dst.data_ptr()
+        t.blk_off_src, t.ent_src = meta.blk_off_src.data_ptr(), meta.ent_src.data_ptr()
+        t.dis = dis.data_ptr() if dis is not None else None
+        return t
+
+    def tiled_ok(self, width: int) -> bool:
+        """The LDS-tiled aggregate (cgnn_aggregate_tiled_f32) covers this batch at this width."""
+        return (width % 64 == 0 and self.block_diagonal and self.num_nodes > 0
+                and self.max_nodes_per_graph <= TILED_MAX_ROWS)
 
     def gcn_dis(self, meta: FusedMeta) -> torch.Tensor:
         """dis = (source-side degree + self-loop + 1e-8)^-1/2, models.py:97-105; every step."""

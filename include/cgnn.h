@@ -186,10 +186,12 @@ int cgnn_pool_mean_bwd_f32(const float* dP, const int32_t* gptr, float* dX, int6
 int cgnn_bell_plan(const int32_t* tile_ptr, const int32_t* tile_blk, int32_t num_tiles,
                    int32_t num_blocks, const int32_t* rowptr, int32_t* blk_off, int32_t* scratch,
                    void* stream);
-/* Pass 2: fill entries (8 bytes each, blk_off[NB] of them). */
+/* Pass 2: fill entries (8 bytes each, blk_off[NB] of them).  self_weight: weight of the appended
+ * self-loop entry -- 1 for GCN (models.py:97-100), 0 for GraphSAGE (no self-loop, models.py:146). */
 int cgnn_bell_fill(const int32_t* tile_ptr, const int32_t* tile_blk, int32_t num_tiles,
                    const int32_t* rowptr, const int32_t* col, const int32_t* eid,
-                   const float* edge_weight, const int32_t* blk_off, void* entries, void* stream);
+                   const float* edge_weight, float self_weight, const int32_t* blk_off,
+                   void* entries, void* stream);
 
 /* out[i] = src[idx[i]] (edge weights permuted to CSR slot order, once per batch). */
 int cgnn_gather_f32(const float* src, const int32_t* idx, int64_t n, float* out, void* stream);
@@ -213,6 +215,23 @@ typedef struct cgnn_tiles {
 
 /* Number of persistent workgroups every fused kernel launches (= rows of every slab). */
 int cgnn_fused_grid(void);
+
+/* Tiled edge-weighted aggregation for wide features (F % 64 == 0), the LDS-staged form of
+ * cgnn_aggregate_f32 (models.py:112-114, :146-149 and their autograd transposes):
+ *     Y[r, :] (+)= post(r) * sum_{e in row r} w_e * pre(c_e) * X[c_e, :]  (+ bias)
+ * over the blocked-ELL of `t` (rows = destinations, or sources when CGNN_AGG_TRANSPOSED), one
+ * persistent workgroup per (tile, 64-column slice): the slice of the tile is staged in LDS once and
+ * every neighbour row is read from there.  pre/post: float [Nn] or NULL; with CGNN_AGG_PRE_DIV /
+ * CGNN_AGG_POST_DIV the row is divided by the vector instead of multiplied (SAGE's
+ * sum / (wsum + 1e-8)).  CGNN_AGG_ACCUMULATE adds into Y.  Whether the ELL carries a self-loop is
+ * decided when it is filled (cgnn_bell_fill self_weight).  t->dis is not read. */
+#define CGNN_AGG_TRANSPOSED 1
+#define CGNN_AGG_PRE_DIV 2
+#define CGNN_AGG_POST_DIV 4
+#define CGNN_AGG_ACCUMULATE 8
+int cgnn_aggregate_tiled_f32(const cgnn_tiles* t, int32_t flags, const float* X, int64_t ldx,
+                             int32_t F, const float* pre, const float* post, const float* bias,
+                             float* Y, int64_t ldy, void* stream);
 
 /* Layer 0 forward.  X0 [Nn,F0] (F0 <= 16), W0 [64,F0], bias [64] -> Y [Nn,64];
  * stat_slab [grid][128] fp64 (sum(y) | sum(y^2)) or NULL (eval). */

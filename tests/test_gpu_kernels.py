@@ -128,6 +128,50 @@ def test_aggregate_forward_backward(f):
     torch.testing.assert_close(bias.grad.cpu(), bc.grad, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("f,sizes,deg", [(64, [20, 35, 84, 3], 6), (128, [360, 7, 360], 14),
+                                         (256, [100] * 9, 40), (128, [384, 1, 17], 5)])
+@pytest.mark.parametrize("kind", ["gcn", "sage"])
+def test_aggregate_tiled_forward_backward(f, sizes, deg, kind):
+    """cgnn_aggregate_tiled_f32 (LDS-staged tiles) against the oracle's layer with an identity
+    projection: GCN = dis*(A_w+I)(dis*x)+b (models.py:94-114), SAGE = A_w x/(wsum+1e-8) (:146-149)."""
+    from connectome_gnn_amd import _lib, ops
+    ei, w, ptr, bid, nn_ = _rand_graph_batch(sizes, deg, 11)
+    b = _batch(ei, w, ptr, bid, nn_, f).to(DEV)
+    s = b.structure()
+    assert s.tiled_ok(f)
+    grid = _lib.load().cgnn_fused_grid()
+    x = b.node_features.clone().requires_grad_(True)
+    cot = torch.randn(nn_, f, generator=torch.Generator().manual_seed(9))
+    xc = b.node_features.cpu().clone().requires_grad_(True)
+    if kind == "gcn":
+        n = s.gcn_norm()
+        bias = torch.randn(f, device=DEV, requires_grad=True)
+        y = ops.aggregate_tiled(x, bias, s, s.fused_meta(384, grid, 1.0), pre=n.dis, post=n.dis)
+        bc = bias.detach().cpu().clone().requires_grad_(True)
+        yr = O.gcn_layer(xc, ei, w, torch.eye(f), bc)
+    else:
+        n = s.sage_norm()
+        y = ops.aggregate_tiled(x, None, s, s.fused_meta(384, grid, 0.0), post=n.den, post_div=True)
+        wsum = torch.zeros(nn_).scatter_add_(0, ei[1], w)
+        msg = xc[ei[0]] * w[:, None]
+        yr = torch.zeros(nn_, f).index_add_(0, ei[1], msg) / (wsum + 1e-8)[:, None]
+    (y * cot.to(DEV)).sum().backward()
+    (yr * cot).sum().backward()
+    torch.testing.assert_close(y.cpu(), yr, **TOL)
+    torch.testing.assert_close(x.grad.cpu(), xc.grad, **TOL)
+    if kind == "gcn":
+        torch.testing.assert_close(bias.grad.cpu(), bc.grad, rtol=1e-5, atol=1e-5)
+    # accumulate flag: Y += A x
+    meta = s.fused_meta(384, grid, 0.0)
+    acc0 = torch.randn(nn_, f, device=DEV)
+    got = ops.aggregate_tiled_raw(s, meta, ops.AGG_ACCUMULATE, b.node_features, None, None, None,
+                                  out=acc0.clone())
+    plain = ops.aggregate_tiled_raw(s, meta, 0, b.node_features, None, None, None)
+    torch.testing.assert_close(got, acc0 + plain, **TOL)
+    # run-to-run deterministic
+    assert torch.equal(plain, ops.aggregate_tiled_raw(s, meta, 0, b.node_features, None, None, None))
+
+
 def test_aggregate_deterministic():
     from connectome_gnn_amd import ops
     ei, w, ptr, bid, nn_ = _rand_graph_batch([84] * 16, 8, 4)
