@@ -48,6 +48,7 @@ PROTOTYPES = {
     "cgnn_linear_bwd_input_f32": (c_int, [P, I64, P, I32, I32, P, I64, I64, I32, I32, P]),
     "cgnn_linear_bwd_weight_workspace_bytes": (I64, [I64, I32, I32]),
     "cgnn_linear_bwd_weight_f32": (c_int, [P, I64, P, I64, P, I32, I32, I64, I32, I32, P, P]),
+    "cgnn_linear_bwd_weight2_f32": (c_int, [P, I64, P, I64, I32, P, I64, I32, P, I32, I64, I32, P, P]),
     "cgnn_colsum_workspace_bytes": (I64, [I64, I32]),
     "cgnn_colsum_f32": (c_int, [P, I64, P, I64, I32, P, P]),
     "cgnn_pool_mean_fwd_f32": (c_int, [P, I64, P, P, I32, I32, P]),
@@ -60,11 +61,12 @@ PROTOTYPES = {
     "cgnn_bn_act_fwd_apply": (c_int, [P, P, I32, F32, U64, P, P, P, I64, I32, P]),
     "cgnn_bn_act_bwd_stats": (c_int, [P, P, P, P, I32, F32, I64, I32, P, P]),
     "cgnn_bn_act_bwd_finalize": (c_int, [P, I32, I32, F64, I32, P, P, P, P]),
-    "cgnn_bn_act_bwd_apply": (c_int, [P, P, P, P, P, I32, F32, P, I64, I32, P]),
+    "cgnn_bn_act_apply_blocks": (I64, [I64, I32]),
+    "cgnn_bn_act_bwd_apply": (c_int, [P, P, P, P, P, I32, F32, I32, P, P, I64, I32, P]),
     # fused per-tile GCN path
     "cgnn_bell_plan": (c_int, [P, P, I32, I32, P, P, P, P]),
     "cgnn_bell_fill": (c_int, [P, P, I32, P, P, P, P, F32, P, P, P]),
-    "cgnn_aggregate_tiled_f32": (c_int, [TP, I32, P, I64, I32, P, P, P, P, I64, P]),
+    "cgnn_aggregate_tiled_f32": (c_int, [TP, I32, P, I64, I32, P, P, P, P, I64, P, I64, P]),
     "cgnn_gather_f32": (c_int, [P, P, I64, P, P]),
     "cgnn_gcn_dis": (c_int, [P, P, I64, P, P]),
     "cgnn_fused_grid": (c_int, []),

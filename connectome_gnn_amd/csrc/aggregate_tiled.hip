@@ -1,6 +1,6 @@
 // aggregate_tiled.hip -- LDS-staged edge-weighted aggregation for wide features (gfx950, fp32).
 //
-//   Y[r,:] (+)= post(r) * sum_{e in row r} w_e * pre(c_e) * X[c_e,:]   (+ bias)
+//   Y[r,:] = post(r) * sum_{e in row r} w_e * pre(c_e) * X[c_e,:]   (+ bias) (+ Yadd[r,:])
 //
 // Replaces gather -> mul -> scatter_add_ of models.py:112-114 (GCN, pre = post = D^-1/2 with the
 // self-loop carried by the ELL) and :146-149 (SAGE, post = 1/(wsum + 1e-8), no self-loop), and
@@ -25,12 +25,12 @@ constexpr int TA_PF = TA_MAXR / 32;            // rows per thread in the staging
 __global__ void __launch_bounds__(TA_THR) k_agg_tiled(
     cgnn_tiles t, int flags, const float* __restrict__ X, int64_t ldx, int nslices,
     const float* __restrict__ pre, const float* __restrict__ post, const float* __restrict__ bias,
-    float* __restrict__ Y, int64_t ldy) {
+    const float* Yadd, int64_t ldadd, float* Y, int64_t ldy) {
   __shared__ __attribute__((aligned(16))) float tile[TA_MAXR * 64];
   __shared__ float postl[TA_MAXR];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, j = lane & 15;
   const bool transposed = flags & CGNN_AGG_TRANSPOSED, pre_div = flags & CGNN_AGG_PRE_DIV;
-  const bool post_div = flags & CGNN_AGG_POST_DIV, accumulate = flags & CGNN_AGG_ACCUMULATE;
+  const bool post_div = flags & CGNN_AGG_POST_DIV, accumulate = Yadd != nullptr;
   const uint4* ent = static_cast<const uint4*>(transposed ? t.ent_src : t.ent_dst);
   const int32_t* blk_off = transposed ? t.blk_off_src : t.blk_off_dst;
   const int units = t.num_tiles * nslices;
@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(TA_THR) k_agg_tiled(
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
           const int row = 16 * b + 4 * q + it;
-          yo[it] = row < n ? ld4(Y + (int64_t)(base + row) * ldy + 64 * slice + 4 * j)
+          yo[it] = row < n ? ld4(Yadd + (int64_t)(base + row) * ldadd + 64 * slice + 4 * j)
                            : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
@@ -129,12 +129,14 @@ __global__ void __launch_bounds__(TA_THR) k_agg_tiled(
 
 extern "C" int cgnn_aggregate_tiled_f32(const cgnn_tiles* t, int32_t flags, const float* X,
                                         int64_t ldx, int32_t F, const float* pre,
-                                        const float* post, const float* bias, float* Y,
-                                        int64_t ldy, void* stream) {
+                                        const float* post, const float* bias, const float* Yadd,
+                                        int64_t ldadd, float* Y, int64_t ldy, void* stream) {
   if (!t || t->num_nodes < 0 || t->num_tiles < 0 || F <= 0 || ldx < F || ldy < F) return CGNN_EINVAL;
-  if (F % 64 || ldx % 4 || ldy % 4 || t->max_tile_rows > TA_MAXR) return CGNN_EUNSUPPORTED;
+  if (Yadd && ldadd < F) return CGNN_EINVAL;
+  if (F % 64 || ldx % 4 || ldy % 4 || (Yadd && ldadd % 4) || t->max_tile_rows > TA_MAXR)
+    return CGNN_EUNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y) |
-       reinterpret_cast<uintptr_t>(bias)) & 15)
+       reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(Yadd)) & 15)
     return CGNN_EUNSUPPORTED;
   if (t->num_nodes == 0 || t->num_tiles == 0) return CGNN_OK;
   const bool tr = flags & CGNN_AGG_TRANSPOSED;
@@ -142,7 +144,7 @@ extern "C" int cgnn_aggregate_tiled_f32(const cgnn_tiles* t, int32_t flags, cons
       !(tr ? t->blk_off_src : t->blk_off_dst))
     return CGNN_EINVAL;
   k_agg_tiled<<<cgnn_fused_grid(), TA_THR, 0, cgnn_stream(stream)>>>(*t, flags, X, ldx, F / 64, pre,
-                                                                     post, bias, Y, ldy);
+                                                                     post, bias, Yadd, ldadd, Y, ldy);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }

@@ -185,10 +185,12 @@ __global__ void __launch_bounds__(256) k_bn_act_apply(
     const float* __restrict__ Y, const float* __restrict__ dXp, const float* __restrict__ coef,
     const float* __restrict__ bwc, int relu, DropCfg drop, int use_drop,
     uint8_t* __restrict__ mask_out, const uint8_t* __restrict__ mask_in, float* __restrict__ out,
-    int64_t M, int N) {
+    int64_t M, int N, int relu_in, double* __restrict__ colsum_slab) {
   if (drop.dev_key) drop.key1 ^= drop.dev_key[0];
   const int nch = N >> 2;
   const int64_t total = M * nch;
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);   // column sums of dY: this thread's chunk is fixed
+                                                 // (gridDim*blockDim is a multiple of nch)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % nch);
@@ -214,16 +216,40 @@ __global__ void __launch_bounds__(256) k_bn_act_apply(
       const float4 g = ld4(dXp + 4 * i);
       const float4 cm = ld4(coef + 2 * N + 4 * c), ci = ld4(coef + 3 * N + 4 * c);
       const float4 c1 = ld4(bwc + 4 * c), c2 = ld4(bwc + N + 4 * c);
-      st4(out + 4 * i, make_float4(ca.x * (g.x * fx - c1.x - (y.x - cm.x) * ci.x * c2.x),
-                                   ca.y * (g.y * fy - c1.y - (y.y - cm.y) * ci.y * c2.y),
-                                   ca.z * (g.z * fz - c1.z - (y.z - cm.z) * ci.z * c2.z),
-                                   ca.w * (g.w * fw - c1.w - (y.w - cm.w) * ci.w * c2.w)));
+      float4 d = make_float4(ca.x * (g.x * fx - c1.x - (y.x - cm.x) * ci.x * c2.x),
+                             ca.y * (g.y * fy - c1.y - (y.y - cm.y) * ci.y * c2.y),
+                             ca.z * (g.z * fz - c1.z - (y.z - cm.z) * ci.z * c2.z),
+                             ca.w * (g.w * fw - c1.w - (y.w - cm.w) * ci.w * c2.w));
+      if (relu_in) {
+        d.x = y.x > 0.f ? d.x : 0.f; d.y = y.y > 0.f ? d.y : 0.f;
+        d.z = y.z > 0.f ? d.z : 0.f; d.w = y.w > 0.f ? d.w : 0.f;
+      }
+      st4(out + 4 * i, d);
+      cs.x += d.x; cs.y += d.y; cs.z += d.z; cs.w += d.w;
+    }
+  }
+  if (BWD && colsum_slab) {
+    __shared__ double red[256 * 4];
+    red[4 * threadIdx.x + 0] = cs.x; red[4 * threadIdx.x + 1] = cs.y;
+    red[4 * threadIdx.x + 2] = cs.z; red[4 * threadIdx.x + 3] = cs.w;
+    __syncthreads();
+    // thread tid owns chunk tid % nch (nch is a power of two <= 256, so it divides the strides)
+    for (int e = threadIdx.x; e < N; e += 256) {
+      double t = 0.0;
+      for (int k = e >> 2; k < 256; k += nch) t += red[4 * k + (e & 3)];
+      colsum_slab[(int64_t)blockIdx.x * N + e] = t;
     }
   }
 }
 
 bool width_ok(int N) { return N >= 4 && N <= 1024 && (N & (N - 1)) == 0; }
 int stat_blocks(int64_t M) { return (int)((M + ROWS - 1) / ROWS); }
+unsigned apply_blocks(int64_t M, int N) {
+  const int64_t total = M * (N >> 2);
+  int64_t grid = (total + 255) / 256;
+  if (grid > 256 * 32) grid = 256 * 32;
+  return (unsigned)(grid < 1 ? 1 : grid);
+}
 
 }  // namespace
 
@@ -266,11 +292,8 @@ int cgnn_bn_act_fwd_apply(const float* Y, const float* coef, int32_t relu, float
   int use_drop;
   DropCfg d = make_drop(p_drop, seed, &use_drop);
   d.dev_key = seed_dev;
-  const int64_t total = M * (N >> 2);
-  unsigned grid = (unsigned)((total + 255) / 256);
-  if (grid > 256u * 32u) grid = 256u * 32u;
-  k_bn_act_apply<false><<<grid, 256, 0, cgnn_stream(stream)>>>(Y, nullptr, coef, nullptr, relu, d, use_drop,
-                                                              mask_out, nullptr, X, M, N);
+  k_bn_act_apply<false><<<apply_blocks(M, N), 256, 0, cgnn_stream(stream)>>>(
+      Y, nullptr, coef, nullptr, relu, d, use_drop, mask_out, nullptr, X, M, N, 0, nullptr);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }
@@ -297,19 +320,20 @@ int cgnn_bn_act_bwd_finalize(const double* slab, int32_t rows, int32_t N, double
   return CGNN_OK;
 }
 
+int64_t cgnn_bn_act_apply_blocks(int64_t M, int32_t N) {
+  return (M < 0 || !width_ok(N)) ? CGNN_EINVAL : (int64_t)apply_blocks(M, N);
+}
+
 int cgnn_bn_act_bwd_apply(const float* dX, const float* Y, const uint8_t* mask, const float* coef,
-                          const float* bwc, int32_t relu, float p_drop, float* dY, int64_t M, int32_t N,
-                          void* stream) {
+                          const float* bwc, int32_t relu, float p_drop, int32_t relu_in,
+                          double* colsum_slab, float* dY, int64_t M, int32_t N, void* stream) {
   if (M < 0 || !width_ok(N) || p_drop < 0.f || p_drop >= 1.f) return CGNN_EINVAL;
   if (M == 0) return CGNN_OK;
   if (!dX || !Y || !coef || !bwc || !dY || (p_drop > 0.f && !mask)) return CGNN_EINVAL;
   int use_drop;
   DropCfg d = make_drop(p_drop, 0, &use_drop);
-  const int64_t total = M * (N >> 2);
-  unsigned grid = (unsigned)((total + 255) / 256);
-  if (grid > 256u * 32u) grid = 256u * 32u;
-  k_bn_act_apply<true><<<grid, 256, 0, cgnn_stream(stream)>>>(Y, dX, coef, bwc, relu, d, use_drop, nullptr,
-                                                             mask, dY, M, N);
+  k_bn_act_apply<true><<<apply_blocks(M, N), 256, 0, cgnn_stream(stream)>>>(
+      Y, dX, coef, bwc, relu, d, use_drop, nullptr, mask, dY, M, N, relu_in, colsum_slab);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }

@@ -23,8 +23,9 @@ bool cgnn_ws_linear_fwd(const float* X1, int64_t ldx1, int K1, const float* X2, 
 bool cgnn_ws_linear_bwd_input(const float* dY, int64_t lddy, const float* W, int ldw, int k0,
                               float* dX, int64_t lddx, int64_t M, int N, int K, hipStream_t st);
 int64_t cgnn_ws_bwd_weight_partials(int64_t M, int N, int K);
-bool cgnn_ws_linear_bwd_weight(const float* dY, int64_t lddy, const float* X, int64_t ldx,
-                               float* slab, int64_t M, int N, int K, hipStream_t st);
+bool cgnn_ws_linear_bwd_weight(const float* dY, int64_t lddy, const float* X1, int64_t ldx1, int K1,
+                               const float* X2, int64_t ldx2, int K2, float* slab, int64_t M,
+                               int N, hipStream_t st);
 
 namespace {
 
@@ -357,7 +358,7 @@ int cgnn_linear_bwd_weight_f32(const float* dY, int64_t lddy, const float* X, in
   hipStream_t st = cgnn_stream(stream);
   int64_t nchunks = (M + WCHUNK - 1) / WCHUNK;
   const int tiles_n = (N + 63) / 64, tiles_k = (K + 63) / 64;
-  if (cgnn_ws_linear_bwd_weight(dY, lddy, X, ldx, static_cast<float*>(slab), M, N, K, st)) {
+  if (cgnn_ws_linear_bwd_weight(dY, lddy, X, ldx, K, nullptr, 0, 0, static_cast<float*>(slab), M, N, st)) {
     CGNN_CHECK_LAUNCH();
     nchunks = cgnn_ws_bwd_weight_partials(M, N, K);
   } else if (nchunks > 0) {
@@ -371,6 +372,28 @@ int cgnn_linear_bwd_weight_f32(const float* dY, int64_t lddy, const float* X, in
                                                                  elems, dW, ldw, k0, K);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
+}
+
+int cgnn_linear_bwd_weight2_f32(const float* dY, int64_t lddy, const float* X1, int64_t ldx1,
+                                int32_t K1, const float* X2, int64_t ldx2, int32_t K2, float* dW,
+                                int32_t ldw, int64_t M, int32_t N, void* slab, void* stream) {
+  if (M < 0 || N <= 0 || K1 <= 0 || K2 <= 0 || ldw < K1 + K2 || lddy < N || ldx1 < K1 || ldx2 < K2)
+    return CGNN_EINVAL;
+  if (!dW || !slab) return CGNN_EINVAL;
+  if (M > 0 && (!dY || !X1 || !X2)) return CGNN_EINVAL;
+  hipStream_t st = cgnn_stream(stream);
+  if (cgnn_ws_linear_bwd_weight(dY, lddy, X1, ldx1, K1, X2, ldx2, K2, static_cast<float*>(slab), M, N, st)) {
+    CGNN_CHECK_LAUNCH();
+    const int64_t elems = (int64_t)N * (K1 + K2);
+    k_reduce_slab<<<(unsigned)((elems + 15) / 16), 256, 0, st>>>(
+        static_cast<float*>(slab), cgnn_ws_bwd_weight_partials(M, N, K1 + K2), elems, dW, ldw, 0, K1 + K2);
+    CGNN_CHECK_LAUNCH();
+    return CGNN_OK;
+  }
+  // shapes outside the weight-stationary kernel: one panel at a time
+  const int rc = cgnn_linear_bwd_weight_f32(dY, lddy, X1, ldx1, dW, ldw, 0, M, N, K1, slab, stream);
+  if (rc != CGNN_OK) return rc;
+  return cgnn_linear_bwd_weight_f32(dY, lddy, X2, ldx2, dW, ldw, K1, M, N, K2, slab, stream);
 }
 
 int64_t cgnn_colsum_workspace_bytes(int64_t M, int32_t N) {

@@ -257,8 +257,9 @@ constexpr int WU = 8;                                // steps (row pairs) per so
 
 template <int NTN>
 __global__ void __launch_bounds__(WS_THR) k_ws_bwd_weight(
-    const float* __restrict__ dY, int64_t lddy, const float* __restrict__ X, int64_t ldx,
-    float* __restrict__ slab, int64_t M, int K, int TK) {
+    const float* __restrict__ dY, int64_t lddy, const float* __restrict__ X1, int64_t ldx1, int K1,
+    const float* __restrict__ X2, int64_t ldx2, float* __restrict__ slab, int64_t M, int K,
+    int TK) {
   constexpr int N = 32 * NTN;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, mh = lane >> 5;
   const int kt = cgnn_uniform(wave % TK), msub = cgnn_uniform(wave / TK), MS = WS_NW / TK;
@@ -268,7 +269,9 @@ __global__ void __launch_bounds__(WS_THR) k_ws_bwd_weight(
   const int64_t piece = (int64_t)blockIdx.x * MS + msub;
   const int64_t mbeg = min(M, piece * per), mend = min(M, mbeg + per);
   const float* ap = dY + NTN * j;
-  const float* bp = X + 32 * kt + j;
+  const bool second = 32 * kt >= K1;              // wave-uniform: which K-panel this strip is in
+  const float* bp = second ? X2 + (32 * kt - K1) + j : X1 + 32 * kt + j;
+  const int64_t ldx = second ? ldx2 : ldx1;
   f32x16 acc[NTN];
 #pragma unroll
   for (int t = 0; t < NTN; ++t) acc[t] = f32x16{0};
@@ -365,12 +368,16 @@ int64_t cgnn_ws_bwd_weight_partials(int64_t M, int N, int K) {
   return (int64_t)cgnn_fused_grid() * (WS_NW / (K / 32));
 }
 
-bool cgnn_ws_linear_bwd_weight(const float* dY, int64_t lddy, const float* X, int64_t ldx,
-                               float* slab, int64_t M, int N, int K, hipStream_t st) {
+bool cgnn_ws_linear_bwd_weight(const float* dY, int64_t lddy, const float* X1, int64_t ldx1, int K1,
+                               const float* X2, int64_t ldx2, int K2, float* slab, int64_t M,
+                               int N, hipStream_t st) {
+  const int K = K1 + K2;
   if (cgnn_ws_bwd_weight_partials(M, N, K) == 0) return false;
-  if (lddy % 4 || !aligned16(dY)) return false;
+  if (lddy % 4 || !aligned16(dY) || (K2 > 0 && K1 % 32)) return false;
   const int grid = cgnn_fused_grid();
-  if (N == 128) k_ws_bwd_weight<4><<<grid, WS_THR, 0, st>>>(dY, lddy, X, ldx, slab, M, K, K / 32);
-  else k_ws_bwd_weight<2><<<grid, WS_THR, 0, st>>>(dY, lddy, X, ldx, slab, M, K, K / 32);
+  if (N == 128)
+    k_ws_bwd_weight<4><<<grid, WS_THR, 0, st>>>(dY, lddy, X1, ldx1, K1, X2, ldx2, slab, M, K, K / 32);
+  else
+    k_ws_bwd_weight<2><<<grid, WS_THR, 0, st>>>(dY, lddy, X1, ldx1, K1, X2, ldx2, slab, M, K, K / 32);
   return true;
 }

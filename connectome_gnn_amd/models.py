@@ -144,9 +144,8 @@ class _ConnectomeModel(nn.Module):
         _require_device(batch.node_features, "batch.node_features")
         s = batch.structure()
         if self._try_fused(batch, s):
-            from . import fused
             self.impl_used = "fused"
-            return fused.encode(self, batch, s)
+            return self._fused_encode(batch, s)
         self.impl_used = "layered"
         norm = self._norm(s)                  # once per forward pass, shared by all layers
         x = batch.node_features
@@ -175,14 +174,20 @@ class _ConnectomeModel(nn.Module):
         blocked-ELL of the fused path) now -- these builds read sizes back to the host, so they
         must not happen inside a HIP-graph capture or a timed region."""
         s = batch.structure()
-        if self._try_fused(batch, s):
-            from . import _lib, fused
-            s.fused_meta(fused.MAX_ROWS, _lib.load().cgnn_fused_grid())
-        elif s.tiled_ok(self.convs[-1].linear.weight.shape[0]):
+        if self._try_fused(batch, s) or s.tiled_ok(self.convs[-1].linear.weight.shape[0]):
+            # GCN's ELL carries the self-loop (weight 1), GraphSAGE's does not (weight 0)
             s.fused_meta(_TILE_ROWS, _grid(), 1.0 if self._relu_after_bn else 0.0)
 
     def _try_fused(self, batch, structure) -> bool:
         return False
+
+    def _fused_encode(self, batch, structure) -> torch.Tensor:
+        raise NotImplementedError
+
+    def _decide(self, why: Optional[str]) -> bool:
+        if why is not None and self.impl == "fused":
+            raise RuntimeError(f"impl='fused' requested but not applicable: {why}")
+        return why is None
 
 
 class GCNConnectome(_ConnectomeModel):
@@ -203,10 +208,11 @@ class GCNConnectome(_ConnectomeModel):
         if self.impl == "layered":
             return False
         from . import fused
-        why = fused.eligible(self, batch, structure)
-        if why is not None and self.impl == "fused":
-            raise RuntimeError(f"impl='fused' requested but not applicable: {why}")
-        return why is None
+        return self._decide(fused.eligible(self, batch, structure))
+
+    def _fused_encode(self, batch, structure):
+        from . import fused
+        return fused.encode(self, batch, structure)
 
 
 class GraphSAGEConnectome(_ConnectomeModel):
@@ -219,3 +225,15 @@ class GraphSAGEConnectome(_ConnectomeModel):
 
     def _post(self, x):
         return x
+
+    def _try_fused(self, batch, structure) -> bool:
+        """One-node encoder with hand-written backward (sage_path.py) when hidden is a multiple
+        of 64 and every graph fits an LDS tile (<= 384 nodes, block-diagonal edges)."""
+        if self.impl == "layered":
+            return False
+        from . import sage_path
+        return self._decide(sage_path.eligible(self, batch, structure))
+
+    def _fused_encode(self, batch, structure):
+        from . import sage_path
+        return sage_path.encode(self, batch, structure)

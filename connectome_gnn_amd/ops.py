@@ -6,6 +6,7 @@ matching backward kernels.  No arithmetic of the message-passing path happens in
 """
 from __future__ import annotations
 
+import ctypes
 from typing import Optional
 
 import torch
@@ -117,20 +118,21 @@ class _Aggregate(torch.autograd.Function):
         return dx, db, None, None
 
 
-AGG_TRANSPOSED, AGG_PRE_DIV, AGG_POST_DIV, AGG_ACCUMULATE = 1, 2, 4, 8   # include/cgnn.h
+AGG_TRANSPOSED, AGG_PRE_DIV, AGG_POST_DIV = 1, 2, 4   # include/cgnn.h
 
 
-def aggregate_tiled_raw(structure, meta, flags: int, x, pre, post, bias, out=None) -> torch.Tensor:
-    """Y (+)= post * A(pre * X) (+bias) through cgnn_aggregate_tiled_f32 (LDS-staged tiles)."""
+def aggregate_tiled_raw(structure, meta, flags: int, x, pre, post, bias, yadd=None) -> torch.Tensor:
+    """Y = post * A(pre * X) (+bias) (+yadd) through cgnn_aggregate_tiled_f32 (LDS-staged tiles).
+    x / yadd may be column slices of wider row-major buffers (their row stride is passed on)."""
     lib = _lib.load()
     n, f = x.shape
-    y = torch.empty(n, f, dtype=torch.float32, device=x.device) if out is None else out
+    y = torch.empty(n, f, dtype=torch.float32, device=x.device)
     tiles = structure.tiles_struct(meta)
-    import ctypes
     with torch.cuda.device(x.device), _lib.timed("cgnn_aggregate_tiled_f32", f"F={f}"):
         _lib.check(lib.cgnn_aggregate_tiled_f32(
             ctypes.byref(tiles), int(flags), _lib.ptr(x), x.stride(0), f, _lib.ptr(pre), _lib.ptr(post),
-            _lib.ptr(bias), _lib.ptr(y), y.stride(0), _lib.stream_ptr()), "cgnn_aggregate_tiled_f32")
+            _lib.ptr(bias), _lib.ptr(yadd), 0 if yadd is None else yadd.stride(0), _lib.ptr(y),
+            y.stride(0), _lib.stream_ptr()), "cgnn_aggregate_tiled_f32")
     return y
 
 
@@ -300,7 +302,8 @@ class _BnActDrop(torch.autograd.Function):
                                                     int(not training), _lib.ptr(dgamma), _lib.ptr(dbeta),
                                                     _lib.ptr(bwc), st()), "cgnn_bn_act_bwd_finalize")
             _lib.check(lib.cgnn_bn_act_bwd_apply(_lib.ptr(dx), _lib.ptr(y), _lib.ptr(mask), _lib.ptr(coef),
-                                                 _lib.ptr(bwc), int(relu), p_eff, _lib.ptr(dy), m, n, st()),
+                                                 _lib.ptr(bwc), int(relu), p_eff, 0, None, _lib.ptr(dy), m, n,
+                                                 st()),
                        "cgnn_bn_act_bwd_apply")
         return dy, dgamma, dbeta, None, None, None, None, None
 

@@ -1,0 +1,190 @@
+"""GraphSAGE encoder as one autograd node (hidden % 64 == 0): host orchestration.
+
+GraphSAGEConnectome.encode (reference models.py:256-262) through the generic ops is ~25 autograd
+nodes per step; autograd then inserts a ReLU-mask multiply, a gradient add and a column sum per
+layer as separate passes over [Nn, H] arrays.  Here the whole encoder is one
+``torch.autograd.Function`` whose backward is written out by hand, so that every pass over a node
+array is a HIP kernel that does several things at once:
+
+  forward, layer l     A  = A_w X / (wsum + 1e-8)            cgnn_aggregate_tiled_f32 (LDS tiles)
+                       Z  = relu([X | A] W^T + b)            cgnn_linear_fwd_f32 (MFMA, W in LDS)
+                       X' = dropout(BatchNorm(Z))            cgnn_bn_act_* (stats, finalize, apply)
+  backward, layer l    dPre = BatchNorm'(dX' * drop') * (Z > 0), db = colsum(dPre)
+                                                             cgnn_bn_act_bwd_* (one apply pass)
+                       dW = dPre^T [X | A]                   cgnn_linear_bwd_weight2_f32 (one pass)
+                       [dX1 | dA] = dPre W                   cgnn_linear_bwd_input_f32 (one pass)
+                       dX = dX1 + A_w^T (dA / (wsum+1e-8))   cgnn_aggregate_tiled_f32 (+Yadd)
+
+No arithmetic of the path happens in torch here; torch allocates buffers and orders the launches.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from . import _lib, ops
+from .structure import BatchStructure
+
+TILE_ROWS = 384
+
+
+def eligible(model, batch, structure: BatchStructure) -> Optional[str]:
+    """None if this path covers (model, batch); else the reason it does not."""
+    hid = model.convs[0].linear.weight.shape[0]
+    if hid % 64 or not bool(_lib.load().cgnn_bn_act_width_ok(hid)):
+        return "hidden_dim is not 64, 128, 256, ..."
+    if not structure.tiled_ok(hid):
+        return "graphs do not fit an LDS tile (or edges cross graph boundaries)"
+    if batch.node_features.requires_grad:
+        return "node_features require grad"
+    for bn in model.batch_norms:
+        if type(bn) is not torch.nn.BatchNorm1d or not (bn.affine and bn.track_running_stats) \
+                or bn.momentum is None:
+            return "BatchNorm is not a plain affine nn.BatchNorm1d with running stats"
+    return None
+
+
+class _Saved:
+    __slots__ = ("s", "ell", "norm", "xs", "aggs", "zs", "coefs", "masks", "p", "training", "ws")
+
+
+def _f32(dev, *shape):
+    return torch.empty(*shape, dtype=torch.float32, device=dev)
+
+
+def _agg_fwd(s: BatchStructure, ell, norm, x):
+    """weighted mean of in-neighbours, models.py:146-149"""
+    if s.tiled_ok(x.shape[1]):
+        return ops.aggregate_tiled_raw(s, ell, ops.AGG_POST_DIV, x, None, norm.den, None)
+    return ops.aggregate_raw(s.rowptr_dst, s.col_dst, norm.w_dst, None, norm.den, None, x)
+
+
+class SageEncode(torch.autograd.Function):
+    """P[B,H] = mean-pool(SAGE stack(x0)); args = x0, cfg, then (W, b, gamma, beta) per layer."""
+
+    @staticmethod
+    def forward(ctx, x0, cfg, *params):
+        lib = _lib.load()
+        s: BatchStructure = cfg["structure"]
+        bns_mod = cfg["batch_norms"]
+        training: bool = cfg["training"]
+        p: float = cfg["dropout"] if training else 0.0
+        rng = cfg.get("rng_state")
+        L = len(params) // 4
+        dev = x0.device
+        st = _lib.stream_ptr
+        x = x0.contiguous()
+        n_nodes = s.num_nodes
+        sv = _Saved()
+        sv.s, sv.p, sv.training = s, p, training
+        sv.ell = s.fused_meta(TILE_ROWS, int(lib.cgnn_fused_grid()), 0.0)
+        sv.norm = s.sage_norm()
+        sv.xs, sv.aggs, sv.zs, sv.coefs, sv.masks, sv.ws = [], [], [], [], [], []
+        with torch.cuda.device(dev):
+            if rng is not None and p > 0:
+                _lib.check(lib.cgnn_rng_advance(_lib.ptr(rng), L + 1, st()), "cgnn_rng_advance")
+            rows = int(lib.cgnn_bn_act_slab_rows(n_nodes))
+            for li in range(L):
+                w, b, gamma, beta = (t.contiguous() for t in params[4 * li:4 * li + 4])
+                hid = w.shape[0]
+                agg = _agg_fwd(s, sv.ell, sv.norm, x)
+                z = ops.linear_fwd_raw(x, agg, w, b, True)
+                bn = bns_mod[li]
+                coef = _f32(dev, 4 * hid)
+                slab = torch.empty(rows, 2 * hid, dtype=torch.float64, device=dev) if training else None
+                if training:
+                    _lib.check(lib.cgnn_bn_act_fwd_stats(_lib.ptr(z), n_nodes, hid, _lib.ptr(slab), st()),
+                               "cgnn_bn_act_fwd_stats")
+                _lib.check(lib.cgnn_bn_act_finalize(
+                    _lib.ptr(slab), rows, hid, float(max(n_nodes, 1)), int(training), _lib.ptr(gamma),
+                    _lib.ptr(beta), _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var),
+                    float(bn.momentum), float(bn.eps),
+                    _lib.ptr(bn.num_batches_tracked) if training else None, _lib.ptr(coef), st()),
+                    "cgnn_bn_act_finalize")
+                mask = torch.empty(n_nodes * (hid // 4), dtype=torch.uint8, device=dev) if p > 0 else None
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0
+                xn = torch.empty_like(z)
+                _lib.check(lib.cgnn_bn_act_fwd_apply(
+                    _lib.ptr(z), _lib.ptr(coef), 0, p, seed,
+                    None if (rng is None or p <= 0) else rng.data_ptr() + 4 * li,
+                    _lib.ptr(mask), _lib.ptr(xn), n_nodes, hid, st()), "cgnn_bn_act_fwd_apply")
+                sv.xs.append(x); sv.aggs.append(agg); sv.zs.append(z); sv.coefs.append(coef)
+                sv.masks.append(mask); sv.ws.append(w)
+                x = xn
+            hid = x.shape[1]
+            pooled = _f32(dev, s.num_graphs, hid)
+            _lib.check(lib.cgnn_pool_mean_fwd_f32(_lib.ptr(x), x.stride(0), _lib.ptr(s.gptr),
+                                                  _lib.ptr(pooled), s.num_graphs, hid, st()),
+                       "cgnn_pool_mean_fwd_f32")
+        ctx.sv = sv
+        ctx.L = L
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dP):
+        lib = _lib.load()
+        sv: _Saved = ctx.sv
+        s, L = sv.s, ctx.L
+        dev = dP.device
+        st = _lib.stream_ptr
+        n_nodes = s.num_nodes
+        dP = dP.contiguous()
+        grads: List[Optional[torch.Tensor]] = [None] * (4 * L)
+        with torch.cuda.device(dev):
+            hid = sv.zs[-1].shape[1]
+            dx = _f32(dev, n_nodes, hid)
+            _lib.check(lib.cgnn_pool_mean_bwd_f32(_lib.ptr(dP), _lib.ptr(s.gptr), _lib.ptr(dx),
+                                                  dx.stride(0), s.num_graphs, hid, st()),
+                       "cgnn_pool_mean_bwd_f32")
+            rows = int(lib.cgnn_bn_act_slab_rows(n_nodes))
+            for li in range(L - 1, -1, -1):
+                x, agg, z, coef, mask, w = (sv.xs[li], sv.aggs[li], sv.zs[li], sv.coefs[li],
+                                            sv.masks[li], sv.ws[li])
+                hid, fin = w.shape[0], x.shape[1]
+                # ---- BatchNorm + dropout backward, ReLU' of the layer and db in two passes
+                slab = torch.empty(rows, 2 * hid, dtype=torch.float64, device=dev)
+                dgamma, dbeta, bwc = _f32(dev, hid), _f32(dev, hid), _f32(dev, 2 * hid)
+                _lib.check(lib.cgnn_bn_act_bwd_stats(_lib.ptr(dx), _lib.ptr(z), _lib.ptr(mask),
+                                                     _lib.ptr(coef), 0, sv.p, n_nodes, hid,
+                                                     _lib.ptr(slab), st()), "cgnn_bn_act_bwd_stats")
+                _lib.check(lib.cgnn_bn_act_bwd_finalize(_lib.ptr(slab), rows, hid,
+                                                        float(max(n_nodes, 1)), int(not sv.training),
+                                                        _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(bwc),
+                                                        st()), "cgnn_bn_act_bwd_finalize")
+                cs_rows = int(lib.cgnn_bn_act_apply_blocks(n_nodes, hid))
+                cs_slab = torch.empty(cs_rows, hid, dtype=torch.float64, device=dev)
+                dpre = torch.empty_like(z)
+                _lib.check(lib.cgnn_bn_act_bwd_apply(_lib.ptr(dx), _lib.ptr(z), _lib.ptr(mask),
+                                                     _lib.ptr(coef), _lib.ptr(bwc), 0, sv.p, 1,
+                                                     _lib.ptr(cs_slab), _lib.ptr(dpre), n_nodes, hid,
+                                                     st()), "cgnn_bn_act_bwd_apply")
+                db = _f32(dev, hid)
+                _lib.check(lib.cgnn_slab_reduce_f64(_lib.ptr(cs_slab), cs_rows, hid, _lib.ptr(db), st()),
+                           "cgnn_slab_reduce_f64")
+                # ---- dW = dPre^T [X | A]
+                dw = torch.empty_like(w)
+                ws = torch.empty(max(int(lib.cgnn_linear_bwd_weight_workspace_bytes(n_nodes, hid, 2 * fin)), 16),
+                                 dtype=torch.uint8, device=dev)
+                _lib.check(lib.cgnn_linear_bwd_weight2_f32(
+                    _lib.ptr(dpre), dpre.stride(0), _lib.ptr(x), x.stride(0), fin, _lib.ptr(agg),
+                    agg.stride(0), fin, _lib.ptr(dw), dw.stride(0), n_nodes, hid, _lib.ptr(ws), st()),
+                    "cgnn_linear_bwd_weight2_f32")
+                grads[4 * li:4 * li + 4] = [dw, db, dgamma, dbeta]
+                if li == 0:
+                    break
+                # ---- [dX1 | dA] = dPre W, then dX = dX1 + A_w^T (dA / den)
+                dcat = ops.linear_bwd_input_raw(dpre, w, 0, 2 * fin)
+                dx = ops.aggregate_tiled_raw(s, sv.ell, ops.AGG_TRANSPOSED | ops.AGG_PRE_DIV,
+                                             dcat[:, fin:], sv.norm.den, None, None, yadd=dcat[:, :fin])
+        ctx.sv = None
+        return (None, None, *grads)
+
+
+def encode(model, batch, structure: BatchStructure) -> torch.Tensor:
+    params = []
+    for conv, bn in zip(model.convs, model.batch_norms):
+        params += [conv.linear.weight, conv.linear.bias, bn.weight, bn.bias]
+    cfg = {"structure": structure, "batch_norms": list(model.batch_norms), "training": model.training,
+           "dropout": float(model.dropout), "rng_state": getattr(model, "rng_device_state", None)}
+    return SageEncode.apply(batch.node_features, cfg, *params)

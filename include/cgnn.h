@@ -124,6 +124,12 @@ int cgnn_linear_bwd_weight_f32(const float* dY, int64_t lddy, const float* X, in
                                float* dW, int32_t ldw, int32_t k0,
                                int64_t M, int32_t N, int32_t K, void* slab, void* stream);
 
+/* Both K-panels of dW = dY^T [X1 | X2] in one pass over dY (SAGELayer's Linear(2*in, out)).
+ * slab: cgnn_linear_bwd_weight_workspace_bytes(M, N, K1 + K2) bytes. */
+int cgnn_linear_bwd_weight2_f32(const float* dY, int64_t lddy, const float* X1, int64_t ldx1,
+                                int32_t K1, const float* X2, int64_t ldx2, int32_t K2, float* dW,
+                                int32_t ldw, int64_t M, int32_t N, void* slab, void* stream);
+
 /* Column sums (bias gradients, models.py:81,114): out[j] = sum_r A[r, j]; fp64 combine.
  * slab: cgnn_colsum_workspace_bytes(M, N) bytes. */
 int64_t cgnn_colsum_workspace_bytes(int64_t M, int32_t N);
@@ -218,20 +224,20 @@ int cgnn_fused_grid(void);
 
 /* Tiled edge-weighted aggregation for wide features (F % 64 == 0), the LDS-staged form of
  * cgnn_aggregate_f32 (models.py:112-114, :146-149 and their autograd transposes):
- *     Y[r, :] (+)= post(r) * sum_{e in row r} w_e * pre(c_e) * X[c_e, :]  (+ bias)
+ *     Y[r, :] = post(r) * sum_{e in row r} w_e * pre(c_e) * X[c_e, :]  (+ bias) (+ Yadd[r, :])
  * over the blocked-ELL of `t` (rows = destinations, or sources when CGNN_AGG_TRANSPOSED), one
  * persistent workgroup per (tile, 64-column slice): the slice of the tile is staged in LDS once and
  * every neighbour row is read from there.  pre/post: float [Nn] or NULL; with CGNN_AGG_PRE_DIV /
  * CGNN_AGG_POST_DIV the row is divided by the vector instead of multiplied (SAGE's
- * sum / (wsum + 1e-8)).  CGNN_AGG_ACCUMULATE adds into Y.  Whether the ELL carries a self-loop is
- * decided when it is filled (cgnn_bell_fill self_weight).  t->dis is not read. */
+ * sum / (wsum + 1e-8)).  Yadd (nullable, may alias Y) is added row-wise: the SAGE backward's
+ * dX = dPre W1 + A^T(dPre W2) in one pass.  Whether the ELL carries a self-loop is decided when
+ * it is filled (cgnn_bell_fill self_weight).  t->dis is not read. */
 #define CGNN_AGG_TRANSPOSED 1
 #define CGNN_AGG_PRE_DIV 2
 #define CGNN_AGG_POST_DIV 4
-#define CGNN_AGG_ACCUMULATE 8
 int cgnn_aggregate_tiled_f32(const cgnn_tiles* t, int32_t flags, const float* X, int64_t ldx,
                              int32_t F, const float* pre, const float* post, const float* bias,
-                             float* Y, int64_t ldy, void* stream);
+                             const float* Yadd, int64_t ldadd, float* Y, int64_t ldy, void* stream);
 
 /* Layer 0 forward.  X0 [Nn,F0] (F0 <= 16), W0 [64,F0], bias [64] -> Y [Nn,64];
  * stat_slab [grid][128] fp64 (sum(y) | sum(y^2)) or NULL (eval). */
@@ -357,9 +363,14 @@ int cgnn_bn_act_bwd_stats(const float* dX, const float* Y, const uint8_t* mask, 
 int cgnn_bn_act_bwd_finalize(const double* slab, int32_t rows, int32_t N, double count,
                              int32_t zero_coef, float* dgamma, float* dbeta, float* bwc,
                              void* stream);
+/* relu_in != 0: Y is itself the output of a ReLU (SAGELayer, models.py:152): dY is additionally
+ * masked by Y > 0, i.e. it is the gradient of the layer's pre-activation.  colsum_slab (nullable):
+ * fp64 [cgnn_bn_act_apply_blocks(M, N)][N] per-block column sums of dY (the bias gradient),
+ * combined with cgnn_slab_reduce_f64. */
+int64_t cgnn_bn_act_apply_blocks(int64_t M, int32_t N);
 int cgnn_bn_act_bwd_apply(const float* dX, const float* Y, const uint8_t* mask, const float* coef,
-                          const float* bwc, int32_t relu, float p_drop, float* dY, int64_t M,
-                          int32_t N, void* stream);
+                          const float* bwc, int32_t relu, float p_drop, int32_t relu_in,
+                          double* colsum_slab, float* dY, int64_t M, int32_t N, void* stream);
 
 #ifdef __cplusplus
 }

@@ -161,15 +161,14 @@ def test_aggregate_tiled_forward_backward(f, sizes, deg, kind):
     torch.testing.assert_close(x.grad.cpu(), xc.grad, **TOL)
     if kind == "gcn":
         torch.testing.assert_close(bias.grad.cpu(), bc.grad, rtol=1e-5, atol=1e-5)
-    # accumulate flag: Y += A x
+    # Yadd: Y = A x + Yadd, with x and Yadd column slices of one wider buffer (SAGE backward)
     meta = s.fused_meta(384, grid, 0.0)
-    acc0 = torch.randn(nn_, f, device=DEV)
-    got = ops.aggregate_tiled_raw(s, meta, ops.AGG_ACCUMULATE, b.node_features, None, None, None,
-                                  out=acc0.clone())
-    plain = ops.aggregate_tiled_raw(s, meta, 0, b.node_features, None, None, None)
-    torch.testing.assert_close(got, acc0 + plain, **TOL)
+    wide = torch.randn(nn_, 2 * f, device=DEV)
+    got = ops.aggregate_tiled_raw(s, meta, 0, wide[:, f:], None, None, None, yadd=wide[:, :f])
+    plain = ops.aggregate_tiled_raw(s, meta, 0, wide[:, f:].contiguous(), None, None, None)
+    torch.testing.assert_close(got, wide[:, :f] + plain, **TOL)
     # run-to-run deterministic
-    assert torch.equal(plain, ops.aggregate_tiled_raw(s, meta, 0, b.node_features, None, None, None))
+    assert torch.equal(plain, ops.aggregate_tiled_raw(s, meta, 0, wide[:, f:].contiguous(), None, None, None))
 
 
 def test_aggregate_deterministic():

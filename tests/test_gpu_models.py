@@ -106,18 +106,36 @@ def test_g7_trainer_trajectory(kind):
 
 @pytest.mark.parametrize("kind,n,k,hidden,nb", [("gcn", 84, 8, 64, 32), ("sage", 84, 8, 64, 16),
                                                ("gcn", 360, 14, 64, 8), ("sage", 360, 14, 128, 4),
-                                               ("gcn", 50, 6, 256, 3)])
+                                               ("gcn", 50, 6, 256, 3), ("sage", 50, 6, 256, 3),
+                                               ("sage", 100, 10, 128, 48), ("gcn", 100, 10, 128, 48)])
 def test_models_vs_oracle_fresh(kind, n, k, hidden, nb):
-    """Seeded fresh inputs (our generator), train mode dropout 0: logits, loss, all grads."""
+    """Seeded fresh inputs (our generator), train mode dropout 0: logits, loss, all grads.
+
+    A gradient passes if it is within GTOL of the fp32 oracle, or -- where the fp32 CPU arithmetic
+    of the reference is itself the noisy side (a ReLU pre-activation within rounding of 0 moves a
+    weight gradient by ~1e-5) -- if it is at least as close to the oracle evaluated in fp64 as the
+    fp32 oracle is."""
     import connectome_gnn_amd as C
     b = C.collate_graphs(C.generate_dataset(nb, n, k, seed=123))
     torch.manual_seed(7)
     m = _model(kind, 5, hidden, dropout=0.0)
-    st = O.require_grad({k_: v.clone() for k_, v in m.state_dict().items()})
-    ob = O.OBatch(b.node_features, b.edge_index, b.edge_weight, b.batch, b.labels, b.ptr)
-    lo = O.FORWARD[kind](st, ob, 0.0, True)
-    loss_o = torch.nn.functional.cross_entropy(lo, ob.labels)
-    loss_o.backward()
+
+    def oracle(dt):
+        torch.set_default_dtype(dt)
+        try:
+            st = O.require_grad({k_: (v.clone().to(dt) if v.is_floating_point() else v.clone())
+                                 for k_, v in m.state_dict().items()})
+            ob = O.OBatch(b.node_features.to(dt), b.edge_index, b.edge_weight.to(dt), b.batch,
+                          b.labels, b.ptr)
+            lo = O.FORWARD[kind](st, ob, 0.0, True)
+            loss = torch.nn.functional.cross_entropy(lo, ob.labels)
+            loss.backward()
+        finally:
+            torch.set_default_dtype(torch.float32)
+        return lo.detach(), loss.detach(), {k_: v.grad for k_, v in st.items() if v.grad is not None}
+
+    lo, loss_o, g32 = oracle(torch.float32)
+    _, _, g64 = oracle(torch.float64)
     m = m.to(DEV).train()
     bd = b.to(DEV)
     lg = m(bd)
@@ -126,7 +144,13 @@ def test_models_vs_oracle_fresh(kind, n, k, hidden, nb):
     torch.testing.assert_close(lg.cpu(), lo, **TOL)
     torch.testing.assert_close(loss_g.cpu(), loss_o, **TOL)
     for k_, p in m.named_parameters():
-        torch.testing.assert_close(p.grad.cpu(), st[k_].grad, **GTOL, msg=lambda s: f"{k_}: {s}")
+        got = p.grad.cpu()
+        try:
+            torch.testing.assert_close(got, g32[k_], **GTOL)
+        except AssertionError:
+            err_gpu = float((got.double() - g64[k_]).abs().max())
+            err_cpu = float((g32[k_].double() - g64[k_]).abs().max())
+            assert err_gpu <= err_cpu + 1e-9, f"{k_}: GPU {err_gpu:.2e} vs fp32 oracle {err_cpu:.2e} from fp64"
 
 
 def test_resident_assemble_matches_collate():
@@ -366,3 +390,41 @@ def test_graphed_step_matches_eager_and_redraws_dropout():
     st = GraphedTrainStep(m, opt, b, warmup=1)
     vals = {round(float(st()), 7) for _ in range(5)}
     assert len(vals) >= 4, vals
+
+
+def test_sage_one_node_encoder_matches_layered_and_is_deterministic():
+    """GraphSAGE: the one-node encoder (sage_path.py) against the op-by-op layered path on the same
+    weights (dropout 0), and its dropout contract: same torch seed -> identical step, masks used
+    consistently forward/backward (finite grads, BatchNorm statistics updated once)."""
+    import connectome_gnn_amd as C
+    b = C.collate_graphs(C.generate_dataset(6, 84, 8, seed=5) + C.generate_dataset(3, 200, 10, seed=6)).to(DEV)
+    outs = {}
+    for impl in ("fused", "layered"):
+        torch.manual_seed(11)
+        m = C.GraphSAGEConnectome(5, 128, dropout=0.0, impl=impl).to(DEV).train()
+        lg = m(b)
+        torch.nn.functional.cross_entropy(lg, b.labels).backward()
+        assert m.impl_used == impl
+        outs[impl] = (lg.detach(), {k: p.grad.clone() for k, p in m.named_parameters()},
+                      {k: v.clone() for k, v in m.state_dict().items() if "running" in k})
+    torch.testing.assert_close(outs["fused"][0], outs["layered"][0], **TOL)
+    for k, g in outs["layered"][1].items():
+        torch.testing.assert_close(outs["fused"][1][k], g, rtol=1e-4, atol=1e-5 * float(g.abs().max()) + 1e-7,
+                                   msg=lambda s_: f"{k}: {s_}")
+    for k, v in outs["layered"][2].items():
+        torch.testing.assert_close(outs["fused"][2][k], v, **TOL)
+    runs = []
+    for _ in range(2):
+        torch.manual_seed(3)
+        m = C.GraphSAGEConnectome(5, 64, dropout=0.4, impl="fused").to(DEV).train()
+        lg = m(b)
+        torch.nn.functional.cross_entropy(lg, b.labels).backward()
+        assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+        assert int(m.batch_norms[0].num_batches_tracked) == 1
+        runs.append((lg.detach(), [p.grad.clone() for p in m.parameters()]))
+    assert torch.equal(runs[0][0], runs[1][0])
+    assert all(torch.equal(a, c) for a, c in zip(runs[0][1], runs[1][1]))
+    m.eval()
+    with torch.no_grad():
+        e = m.encode(b)
+    assert m.impl_used == "fused" and e.shape == (9, 64) and torch.isfinite(e).all()
