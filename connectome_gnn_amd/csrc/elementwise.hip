@@ -244,10 +244,12 @@ __global__ void __launch_bounds__(256) k_bn_act_apply(
 
 bool width_ok(int N) { return N >= 4 && N <= 1024 && (N & (N - 1)) == 0; }
 int stat_blocks(int64_t M) { return (int)((M + ROWS - 1) / ROWS); }
-unsigned apply_blocks(int64_t M, int N) {
+unsigned apply_blocks(int64_t M, int N, bool colsum = false) {
   const int64_t total = M * (N >> 2);
   int64_t grid = (total + 255) / 256;
-  if (grid > 256 * 32) grid = 256 * 32;
+  // with column sums every block leaves a partial row in the slab: fewer, longer-running blocks
+  const int64_t cap = colsum ? 1024 : 256 * 32;
+  if (grid > cap) grid = cap;
   return (unsigned)(grid < 1 ? 1 : grid);
 }
 
@@ -321,7 +323,7 @@ int cgnn_bn_act_bwd_finalize(const double* slab, int32_t rows, int32_t N, double
 }
 
 int64_t cgnn_bn_act_apply_blocks(int64_t M, int32_t N) {
-  return (M < 0 || !width_ok(N)) ? CGNN_EINVAL : (int64_t)apply_blocks(M, N);
+  return (M < 0 || !width_ok(N)) ? CGNN_EINVAL : (int64_t)apply_blocks(M, N, true);
 }
 
 int cgnn_bn_act_bwd_apply(const float* dX, const float* Y, const uint8_t* mask, const float* coef,
@@ -332,7 +334,7 @@ int cgnn_bn_act_bwd_apply(const float* dX, const float* Y, const uint8_t* mask, 
   if (!dX || !Y || !coef || !bwc || !dY || (p_drop > 0.f && !mask)) return CGNN_EINVAL;
   int use_drop;
   DropCfg d = make_drop(p_drop, 0, &use_drop);
-  k_bn_act_apply<true><<<apply_blocks(M, N), 256, 0, cgnn_stream(stream)>>>(
+  k_bn_act_apply<true><<<apply_blocks(M, N, colsum_slab != nullptr), 256, 0, cgnn_stream(stream)>>>(
       Y, dX, coef, bwc, relu, d, use_drop, nullptr, mask, dY, M, N, relu_in, colsum_slab);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;

@@ -364,7 +364,7 @@ bool cgnn_ws_linear_bwd_input(const float* dY, int64_t lddy, const float* W, int
 // number of fp32 [N x K] partials the weight-stationary bwd_weight writes (0 = not eligible)
 int64_t cgnn_ws_bwd_weight_partials(int64_t M, int N, int K) {
   if (M < WS_MIN_ROWS || (N != 64 && N != 128)) return 0;
-  if (K != 64 && K != 128 && K != 256) return 0;
+  if (K != 32 && K != 64 && K != 128 && K != 256) return 0;
   return (int64_t)cgnn_fused_grid() * (WS_NW / (K / 32));
 }
 

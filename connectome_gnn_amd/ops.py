@@ -30,10 +30,11 @@ def _scratch(nbytes: int, device) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------ raw launchers
-def aggregate_raw(rowptr, col, coef, selfc, rowdiv, bias, x) -> torch.Tensor:
+def aggregate_raw(rowptr, col, coef, selfc, rowdiv, bias, x, out=None) -> torch.Tensor:
+    """out: optional [n, f] destination (may be a column slice of a wider row-major buffer)."""
     lib = _lib.load()
     n, f = x.shape
-    y = torch.empty_like(x)
+    y = torch.empty_like(x) if out is None else out
     with torch.cuda.device(x.device), _lib.timed("cgnn_aggregate_f32", f"F={f}"):
         _lib.check(lib.cgnn_aggregate_f32(
             _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(coef), _lib.ptr(selfc), _lib.ptr(rowdiv),

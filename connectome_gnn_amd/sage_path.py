@@ -46,7 +46,11 @@ def eligible(model, batch, structure: BatchStructure) -> Optional[str]:
 
 
 class _Saved:
-    __slots__ = ("s", "ell", "norm", "xs", "aggs", "zs", "coefs", "masks", "p", "training", "ws")
+    __slots__ = ("s", "ell", "norm", "xs", "aggs", "zs", "coefs", "masks", "p", "training", "ws", "xa0")
+
+
+PAD_K = 32          # layer 0: [x0 | agg(x0) | 0] packed to one 32-wide panel
+PAD_MIN_ROWS = 4096  # (= the row count from which the weight-stationary GEMMs apply)
 
 
 def _f32(dev, *shape):
@@ -81,6 +85,7 @@ class SageEncode(torch.autograd.Function):
         sv.ell = s.fused_meta(TILE_ROWS, int(lib.cgnn_fused_grid()), 0.0)
         sv.norm = s.sage_norm()
         sv.xs, sv.aggs, sv.zs, sv.coefs, sv.masks, sv.ws = [], [], [], [], [], []
+        sv.xa0 = None
         with torch.cuda.device(dev):
             if rng is not None and p > 0:
                 _lib.check(lib.cgnn_rng_advance(_lib.ptr(rng), L + 1, st()), "cgnn_rng_advance")
@@ -88,8 +93,22 @@ class SageEncode(torch.autograd.Function):
             for li in range(L):
                 w, b, gamma, beta = (t.contiguous() for t in params[4 * li:4 * li + 4])
                 hid = w.shape[0]
-                agg = _agg_fwd(s, sv.ell, sv.norm, x)
-                z = ops.linear_fwd_raw(x, agg, w, b, True)
+                fin = x.shape[1]
+                if li == 0 and 2 * fin <= PAD_K and hid in (64, 128) and n_nodes >= PAD_MIN_ROWS:
+                    # narrow input layer: pack [x0 | agg(x0) | 0] and the zero-padded weight into
+                    # 32-wide panels so that the tall weight-stationary GEMMs apply (K = 10 would
+                    # otherwise run the per-tile kernels at a few % of the matrix-core rate)
+                    xa = torch.zeros(n_nodes, PAD_K, dtype=torch.float32, device=dev)
+                    xa[:, :fin].copy_(x)
+                    agg = ops.aggregate_raw(s.rowptr_dst, s.col_dst, sv.norm.w_dst, None, sv.norm.den,
+                                            None, x, out=xa[:, fin:2 * fin])
+                    wp = torch.zeros(hid, PAD_K, dtype=torch.float32, device=dev)
+                    wp[:, :2 * fin].copy_(w)
+                    z = ops.linear_fwd_raw(xa, None, wp, b, True)
+                    sv.xa0 = xa
+                else:
+                    agg = _agg_fwd(s, sv.ell, sv.norm, x)
+                    z = ops.linear_fwd_raw(x, agg, w, b, True)
                 bn = bns_mod[li]
                 coef = _f32(dev, 4 * hid)
                 slab = torch.empty(rows, 2 * hid, dtype=torch.float64, device=dev) if training else None
@@ -163,6 +182,11 @@ class SageEncode(torch.autograd.Function):
                 _lib.check(lib.cgnn_slab_reduce_f64(_lib.ptr(cs_slab), cs_rows, hid, _lib.ptr(db), st()),
                            "cgnn_slab_reduce_f64")
                 # ---- dW = dPre^T [X | A]
+                if li == 0 and sv.xa0 is not None:
+                    dwp = _f32(dev, hid, PAD_K)
+                    ops.linear_bwd_weight_raw(dpre, sv.xa0, dwp, 0)
+                    grads[0:4] = [dwp[:, :2 * fin].contiguous(), db, dgamma, dbeta]
+                    break
                 dw = torch.empty_like(w)
                 ws = torch.empty(max(int(lib.cgnn_linear_bwd_weight_workspace_bytes(n_nodes, hid, 2 * fin)), 16),
                                  dtype=torch.uint8, device=dev)
