@@ -52,6 +52,21 @@ DropCfg make_drop(float p, uint64_t seed, int* use_drop) {
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
 
+// Readout gradient in place of a stored dX' (models.py:57-59 backward): the row's gradient is
+// dP[graph] / (n_graph + 1e-8), rebuilt on the fly instead of written out and read back.
+struct PoolGrad {
+  const float* dP;               // [B, N] or NULL (= read dX')
+  const int32_t* node_graph;     // [M]
+  const int32_t* gptr;           // [B+1]
+};
+
+__device__ __forceinline__ float4 pool_grad(const PoolGrad& pg, int64_t r, int N, int c) {
+  const int g = pg.node_graph[r];
+  const float inv = 1.0f / ((float)(pg.gptr[g + 1] - pg.gptr[g]) + 1e-8f);
+  const float4 v = ld4(pg.dP + (int64_t)g * N + 4 * c);
+  return make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+}
+
 constexpr int ROWS = 256;     // rows per block of the reduction kernels
 constexpr int THR = 256;
 
@@ -60,7 +75,7 @@ template <bool BWD>
 __global__ void __launch_bounds__(THR) k_colstats(
     const float* __restrict__ A /* Y (fwd) or dX' (bwd) */, const float* __restrict__ Y,
     const uint8_t* __restrict__ mask, const float* __restrict__ coef, int relu, DropCfg drop,
-    int use_drop, int64_t M, int N, double* __restrict__ slab) {
+    int use_drop, int64_t M, int N, double* __restrict__ slab, PoolGrad pg) {
   extern __shared__ double red[];                    // [rpp][2N]
   const int nch = N >> 2;
   const int c = threadIdx.x % nch, rr = threadIdx.x / nch, rpp = THR / nch;
@@ -73,7 +88,7 @@ __global__ void __launch_bounds__(THR) k_colstats(
   }
   if (rr < rpp) {
     for (int64_t r = rbeg + rr; r < rend; r += rpp) {
-      const float4 a = ld4(A + r * N + 4 * c);
+      const float4 a = (BWD && pg.dP) ? pool_grad(pg, r, N, c) : ld4(A + r * N + 4 * c);
       if (!BWD) {
         s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
         s2.x = fmaf(a.x, a.x, s2.x); s2.y = fmaf(a.y, a.y, s2.y);
@@ -185,7 +200,7 @@ __global__ void __launch_bounds__(256) k_bn_act_apply(
     const float* __restrict__ Y, const float* __restrict__ dXp, const float* __restrict__ coef,
     const float* __restrict__ bwc, int relu, DropCfg drop, int use_drop,
     uint8_t* __restrict__ mask_out, const uint8_t* __restrict__ mask_in, float* __restrict__ out,
-    int64_t M, int N, int relu_in, double* __restrict__ colsum_slab) {
+    int64_t M, int N, int relu_in, double* __restrict__ colsum_slab, PoolGrad pg) {
   if (drop.dev_key) drop.key1 ^= drop.dev_key[0];
   const int nch = N >> 2;
   const int64_t total = M * nch;
@@ -213,7 +228,7 @@ __global__ void __launch_bounds__(256) k_bn_act_apply(
     if (!BWD) {
       st4(out + 4 * i, make_float4(zx * fx, zy * fy, zz * fz, zw * fw));
     } else {
-      const float4 g = ld4(dXp + 4 * i);
+      const float4 g = pg.dP ? pool_grad(pg, i / nch, N, c) : ld4(dXp + 4 * i);
       const float4 cm = ld4(coef + 2 * N + 4 * c), ci = ld4(coef + 3 * N + 4 * c);
       const float4 c1 = ld4(bwc + 4 * c), c2 = ld4(bwc + N + 4 * c);
       float4 d = make_float4(ca.x * (g.x * fx - c1.x - (y.x - cm.x) * ci.x * c2.x),
@@ -242,6 +257,60 @@ __global__ void __launch_bounds__(256) k_bn_act_apply(
   }
 }
 
+// Readout fused with the last layer's BatchNorm (+act) + dropout: P[g] = mean_rows drop(act(a*Y+b)).
+// One 1024-thread block per graph at a time; X' itself is never written.
+constexpr int PTHR = 1024;
+
+__global__ void __launch_bounds__(PTHR) k_bn_act_pool_fwd(
+    const float* __restrict__ Y, const float* __restrict__ coef, int relu, DropCfg drop, int use_drop,
+    uint8_t* __restrict__ mask_out, const int32_t* __restrict__ gptr, int B, float* __restrict__ P,
+    int N) {
+  if (drop.dev_key) drop.key1 ^= drop.dev_key[0];
+  extern __shared__ float pred[];                    // [rpp][N]
+  const int nch = N >> 2;
+  const int c = threadIdx.x % nch, rr = threadIdx.x / nch, rpp = PTHR / nch;
+  const float4 ca = ld4(coef + 4 * c), cb = ld4(coef + N + 4 * c);
+  for (int g = blockIdx.x; g < B; g += gridDim.x) {
+    const int rbeg = gptr[g], rend = gptr[g + 1];
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int U = 4;                             // rows in flight per thread
+    for (int row0 = rbeg + rr; row0 < rend; row0 += U * rpp) {
+      float4 yb[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int row = row0 + u * rpp;
+        yb[u] = row < rend ? ld4(Y + ((int64_t)row * nch + c) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int row = row0 + u * rpp;
+        if (row < rend) {
+          const int64_t i = (int64_t)row * nch + c;
+          const float zx = fmaf(ca.x, yb[u].x, cb.x), zy = fmaf(ca.y, yb[u].y, cb.y);
+          const float zz = fmaf(ca.z, yb[u].z, cb.z), zw = fmaf(ca.w, yb[u].w, cb.w);
+          uint32_t kb = 0xFu;
+          if (use_drop) {
+            kb = drop_bits(drop, (uint32_t)i);
+            if (mask_out) mask_out[i] = (uint8_t)kb;
+          }
+          s.x += ((!relu || zx > 0.f) && (kb & 1u)) ? zx * drop.scale : 0.f;
+          s.y += ((!relu || zy > 0.f) && (kb & 2u)) ? zy * drop.scale : 0.f;
+          s.z += ((!relu || zz > 0.f) && (kb & 4u)) ? zz * drop.scale : 0.f;
+          s.w += ((!relu || zw > 0.f) && (kb & 8u)) ? zw * drop.scale : 0.f;
+        }
+      }
+    }
+    if (rr < rpp) st4(pred + rr * N + 4 * c, s);
+    __syncthreads();
+    for (int e = threadIdx.x; e < N; e += PTHR) {
+      float tot = 0.f;
+      for (int k = 0; k < rpp; ++k) tot += pred[k * N + e];
+      P[(int64_t)g * N + e] = tot / ((float)(rend - rbeg) + 1e-8f);
+    }
+    __syncthreads();
+  }
+}
+
 bool width_ok(int N) { return N >= 4 && N <= 1024 && (N & (N - 1)) == 0; }
 int stat_blocks(int64_t M) { return (int)((M + ROWS - 1) / ROWS); }
 unsigned apply_blocks(int64_t M, int N, bool colsum = false) {
@@ -267,7 +336,7 @@ int cgnn_bn_act_fwd_stats(const float* Y, int64_t M, int32_t N, double* slab, vo
   DropCfg d{};
   const int rpp = THR / (N >> 2);
   k_colstats<false><<<stat_blocks(M), THR, (size_t)rpp * 2 * N * sizeof(double), cgnn_stream(stream)>>>(
-      Y, nullptr, nullptr, nullptr, 0, d, 0, M, N, slab);
+      Y, nullptr, nullptr, nullptr, 0, d, 0, M, N, slab, PoolGrad{nullptr, nullptr, nullptr});
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }
@@ -295,21 +364,42 @@ int cgnn_bn_act_fwd_apply(const float* Y, const float* coef, int32_t relu, float
   DropCfg d = make_drop(p_drop, seed, &use_drop);
   d.dev_key = seed_dev;
   k_bn_act_apply<false><<<apply_blocks(M, N), 256, 0, cgnn_stream(stream)>>>(
-      Y, nullptr, coef, nullptr, relu, d, use_drop, mask_out, nullptr, X, M, N, 0, nullptr);
+      Y, nullptr, coef, nullptr, relu, d, use_drop, mask_out, nullptr, X, M, N, 0, nullptr,
+      PoolGrad{nullptr, nullptr, nullptr});
+  CGNN_CHECK_LAUNCH();
+  return CGNN_OK;
+}
+
+int cgnn_bn_act_pool_fwd(const float* Y, const float* coef, int32_t relu, float p_drop, uint64_t seed,
+                         const uint32_t* seed_dev, uint8_t* mask_out, const int32_t* gptr,
+                         int32_t num_graphs, float* P, int32_t N, void* stream) {
+  if (num_graphs < 0 || !width_ok(N) || p_drop < 0.f || p_drop >= 1.f) return CGNN_EINVAL;
+  if (num_graphs == 0) return CGNN_OK;
+  if (!Y || !coef || !gptr || !P) return CGNN_EINVAL;
+  int use_drop;
+  DropCfg d = make_drop(p_drop, seed, &use_drop);
+  d.dev_key = seed_dev;
+  const int rpp = PTHR / (N >> 2);
+  const unsigned grid = (unsigned)(num_graphs < 2048 ? num_graphs : 2048);
+  k_bn_act_pool_fwd<<<grid, PTHR, (size_t)rpp * N * sizeof(float), cgnn_stream(stream)>>>(
+      Y, coef, relu, d, use_drop, mask_out, gptr, num_graphs, P, N);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }
 
 int cgnn_bn_act_bwd_stats(const float* dX, const float* Y, const uint8_t* mask, const float* coef,
-                          int32_t relu, float p_drop, int64_t M, int32_t N, double* slab, void* stream) {
+                          int32_t relu, float p_drop, int64_t M, int32_t N, double* slab,
+                          const float* dP, const int32_t* node_graph, const int32_t* gptr,
+                          void* stream) {
   if (M < 0 || !width_ok(N) || !slab || p_drop < 0.f || p_drop >= 1.f) return CGNN_EINVAL;
   if (M == 0) return CGNN_OK;
-  if (!dX || !Y || !coef || (p_drop > 0.f && !mask)) return CGNN_EINVAL;
+  if ((!dX && !dP) || !Y || !coef || (p_drop > 0.f && !mask)) return CGNN_EINVAL;
+  if (dP && (!node_graph || !gptr)) return CGNN_EINVAL;
   int use_drop;
   DropCfg d = make_drop(p_drop, 0, &use_drop);
   const int rpp = THR / (N >> 2);
   k_colstats<true><<<stat_blocks(M), THR, (size_t)rpp * 2 * N * sizeof(double), cgnn_stream(stream)>>>(
-      dX, Y, mask, coef, relu, d, use_drop, M, N, slab);
+      dX, Y, mask, coef, relu, d, use_drop, M, N, slab, PoolGrad{dP, node_graph, gptr});
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }
@@ -328,14 +418,17 @@ int64_t cgnn_bn_act_apply_blocks(int64_t M, int32_t N) {
 
 int cgnn_bn_act_bwd_apply(const float* dX, const float* Y, const uint8_t* mask, const float* coef,
                           const float* bwc, int32_t relu, float p_drop, int32_t relu_in,
-                          double* colsum_slab, float* dY, int64_t M, int32_t N, void* stream) {
+                          double* colsum_slab, float* dY, int64_t M, int32_t N, const float* dP,
+                          const int32_t* node_graph, const int32_t* gptr, void* stream) {
   if (M < 0 || !width_ok(N) || p_drop < 0.f || p_drop >= 1.f) return CGNN_EINVAL;
   if (M == 0) return CGNN_OK;
-  if (!dX || !Y || !coef || !bwc || !dY || (p_drop > 0.f && !mask)) return CGNN_EINVAL;
+  if ((!dX && !dP) || !Y || !coef || !bwc || !dY || (p_drop > 0.f && !mask)) return CGNN_EINVAL;
+  if (dP && (!node_graph || !gptr)) return CGNN_EINVAL;
   int use_drop;
   DropCfg d = make_drop(p_drop, 0, &use_drop);
   k_bn_act_apply<true><<<apply_blocks(M, N, colsum_slab != nullptr), 256, 0, cgnn_stream(stream)>>>(
-      Y, dX, coef, bwc, relu, d, use_drop, nullptr, mask, dY, M, N, relu_in, colsum_slab);
+      Y, dX, coef, bwc, relu, d, use_drop, nullptr, mask, dY, M, N, relu_in, colsum_slab,
+      PoolGrad{dP, node_graph, gptr});
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }

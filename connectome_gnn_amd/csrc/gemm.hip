@@ -19,7 +19,7 @@
 // weight-stationary kernels for the wide, tall shapes (gemm_ws.hip); false = not applicable
 bool cgnn_ws_linear_fwd(const float* X1, int64_t ldx1, int K1, const float* X2, int64_t ldx2,
                         int K2, const float* W, const float* bias, int relu, float* Y,
-                        int64_t ldy, int64_t M, int N, hipStream_t st);
+                        int64_t ldy, int64_t M, int N, double* stat_slab, hipStream_t st);
 bool cgnn_ws_linear_bwd_input(const float* dY, int64_t lddy, const float* W, int ldw, int k0,
                               float* dX, int64_t lddx, int64_t M, int N, int K, hipStream_t st);
 int64_t cgnn_ws_bwd_weight_partials(int64_t M, int N, int K);
@@ -311,13 +311,28 @@ int cgnn_linear_fwd_f32(const float* X1, int64_t ldx1, int32_t K1, const float* 
   if (K2 > 0 && (!X2 || ldx2 < K2)) return CGNN_EINVAL;
   if (M == 0) return CGNN_OK;
   if (!X1 || !W || !Y) return CGNN_EINVAL;
-  if (cgnn_ws_linear_fwd(X1, ldx1, K1, X2, ldx2, K2, W, bias, relu, Y, ldy, M, N, cgnn_stream(stream))) {
+  if (cgnn_ws_linear_fwd(X1, ldx1, K1, X2, ldx2, K2, W, bias, relu, Y, ldy, M, N, nullptr,
+                         cgnn_stream(stream))) {
     CGNN_CHECK_LAUNCH();
     return CGNN_OK;
   }
   dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
   k_linear_fwd<<<grid, 256, 0, cgnn_stream(stream)>>>(X1, ldx1, K1, X2, ldx2, K2, W, bias, relu, Y,
                                                       ldy, M, N);
+  CGNN_CHECK_LAUNCH();
+  return CGNN_OK;
+}
+
+int cgnn_linear_fwd_stats_f32(const float* X1, int64_t ldx1, int32_t K1, const float* X2,
+                              int64_t ldx2, int32_t K2, const float* W, const float* bias,
+                              int32_t relu, float* Y, int64_t ldy, int64_t M, int32_t N,
+                              double* stat_slab, void* stream) {
+  if (M <= 0 || N <= 0 || K1 <= 0 || K2 < 0 || ldx1 < K1 || ldy < N || !stat_slab) return CGNN_EINVAL;
+  if (K2 > 0 && (!X2 || ldx2 < K2)) return CGNN_EINVAL;
+  if (!X1 || !W || !Y) return CGNN_EINVAL;
+  if (!cgnn_ws_linear_fwd(X1, ldx1, K1, X2, ldx2, K2, W, bias, relu, Y, ldy, M, N, stat_slab,
+                          cgnn_stream(stream)))
+    return CGNN_EUNSUPPORTED;      // caller: cgnn_linear_fwd_f32 + cgnn_bn_act_fwd_stats
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }

@@ -48,7 +48,7 @@ template <int NT>
 __global__ void __launch_bounds__(FW_THR) k_ws_fwd(
     const float* __restrict__ X1, int64_t ldx1, int K1, const float* __restrict__ X2,
     int64_t ldx2, int K2, const float* __restrict__ W, const float* __restrict__ bias, int relu,
-    float* __restrict__ Y, int64_t ldy, int64_t M) {
+    float* __restrict__ Y, int64_t ldy, int64_t M, double* __restrict__ stat_slab) {
   constexpr int N = 32 * NT;
   __shared__ __attribute__((aligned(16))) float Wl[WS_LDS_FLOATS];   // Wl[k][n] = W[n][k]
   const int K = K1 + K2;
@@ -88,6 +88,9 @@ __global__ void __launch_bounds__(FW_THR) k_ws_fwd(
 
   int64_t rb = (int64_t)blockIdx.x * FW_NW + wave;
   float4 cur[UNR], nxt[UNR];
+  double s1[NT], s2[NT];                            // column sums of Y, Y^2 (BatchNorm statistics)
+#pragma unroll
+  for (int t = 0; t < NT; ++t) s1[t] = s2[t] = 0.0;
   if (rb < nrb) {
 #pragma unroll
     for (int u = 0; u < UNR; ++u) cur[u] = ldg4(row_ptr(rb, c0 + 4 * u));
@@ -129,6 +132,9 @@ __global__ void __launch_bounds__(FW_THR) k_ws_fwd(
       for (int u = 0; u < UNR; ++u) cur[u] = nxt[u];
     }
     // epilogue: bias, activation, 16-byte (NT = 4) / 8-byte (NT = 2) stores
+    float p1[NT], p2[NT];                           // this block's 16 rows: fp32 partials
+#pragma unroll
+    for (int t = 0; t < NT; ++t) p1[t] = p2[t] = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int64_t row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
@@ -138,11 +144,36 @@ __global__ void __launch_bounds__(FW_THR) k_ws_fwd(
         for (int t = 0; t < NT; ++t) {
           v[t] = acc[t][r] + bv[t];
           if (relu) v[t] = fmaxf(v[t], 0.f);
+          p1[t] += v[t];
+          p2[t] = fmaf(v[t], v[t], p2[t]);
         }
         float* yp = Y + row * ldy + NT * j;
         if (NT == 4) *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[NT > 2 ? 2 : 0], v[NT > 3 ? 3 : 0]);
         else *reinterpret_cast<float2*>(yp) = make_float2(v[0], v[1]);
       }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { s1[t] += (double)p1[t]; s2[t] += (double)p2[t]; }
+  }
+  if (stat_slab) {
+    // lane (j, kh) holds columns NT*j + t; fold the two row halves, then the waves (fixed order)
+    double* red = reinterpret_cast<double*>(Wl);   // [FW_NW][2N], the weight panel is dead now
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      s1[t] += __shfl_xor(s1[t], 32, 64);
+      s2[t] += __shfl_xor(s2[t], 32, 64);
+      if (kh == 0) {
+        red[wave * 2 * N + NT * j + t] = s1[t];
+        red[wave * 2 * N + N + NT * j + t] = s2[t];
+      }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * N; e += FW_THR) {
+      double tsum = 0.0;
+#pragma unroll
+      for (int w2 = 0; w2 < FW_NW; ++w2) tsum += red[w2 * 2 * N + e];
+      stat_slab[(int64_t)blockIdx.x * 2 * N + e] = tsum;
     }
   }
 }
@@ -331,7 +362,7 @@ constexpr int64_t WS_MIN_ROWS = 4096;    // below this the launch-per-tile kerne
 // Internal hooks for gemm.hip: return true if the weight-stationary kernel was launched.
 bool cgnn_ws_linear_fwd(const float* X1, int64_t ldx1, int K1, const float* X2, int64_t ldx2,
                         int K2, const float* W, const float* bias, int relu, float* Y,
-                        int64_t ldy, int64_t M, int N, hipStream_t st) {
+                        int64_t ldy, int64_t M, int N, double* stat_slab, hipStream_t st) {
   const int K = K1 + K2;
   if (M < WS_MIN_ROWS || (N != 64 && N != 128) || K % 32 || K1 % 4 || K2 % 4 ||
       (int64_t)N * K > WS_LDS_FLOATS)
@@ -340,8 +371,10 @@ bool cgnn_ws_linear_fwd(const float* X1, int64_t ldx1, int K1, const float* X2, 
       !aligned16(W) || !aligned16(Y))
     return false;
   const int grid = cgnn_fused_grid();
-  if (N == 128) k_ws_fwd<4><<<grid, FW_THR, 0, st>>>(X1, ldx1, K1, X2, ldx2, K2, W, bias, relu, Y, ldy, M);
-  else k_ws_fwd<2><<<grid, FW_THR, 0, st>>>(X1, ldx1, K1, X2, ldx2, K2, W, bias, relu, Y, ldy, M);
+  if (N == 128)
+    k_ws_fwd<4><<<grid, FW_THR, 0, st>>>(X1, ldx1, K1, X2, ldx2, K2, W, bias, relu, Y, ldy, M, stat_slab);
+  else
+    k_ws_fwd<2><<<grid, FW_THR, 0, st>>>(X1, ldx1, K1, X2, ldx2, K2, W, bias, relu, Y, ldy, M, stat_slab);
   return true;
 }
 

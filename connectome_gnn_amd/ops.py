@@ -297,14 +297,15 @@ class _BnActDrop(torch.autograd.Function):
             rows = int(lib.cgnn_bn_act_slab_rows(m))
             slab = torch.empty(rows, 2 * n, dtype=torch.float64, device=dev)
             _lib.check(lib.cgnn_bn_act_bwd_stats(_lib.ptr(dx), _lib.ptr(y), _lib.ptr(mask), _lib.ptr(coef),
-                                                 int(relu), p_eff, m, n, _lib.ptr(slab), st()),
+                                                 int(relu), p_eff, m, n, _lib.ptr(slab), None, None, None,
+                                                 st()),
                        "cgnn_bn_act_bwd_stats")
             _lib.check(lib.cgnn_bn_act_bwd_finalize(_lib.ptr(slab), rows, n, float(max(m, 1)),
                                                     int(not training), _lib.ptr(dgamma), _lib.ptr(dbeta),
                                                     _lib.ptr(bwc), st()), "cgnn_bn_act_bwd_finalize")
             _lib.check(lib.cgnn_bn_act_bwd_apply(_lib.ptr(dx), _lib.ptr(y), _lib.ptr(mask), _lib.ptr(coef),
                                                  _lib.ptr(bwc), int(relu), p_eff, 0, None, _lib.ptr(dy), m, n,
-                                                 st()),
+                                                 None, None, None, st()),
                        "cgnn_bn_act_bwd_apply")
         return dy, dgamma, dbeta, None, None, None, None, None
 

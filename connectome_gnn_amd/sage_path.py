@@ -64,6 +64,23 @@ def _agg_fwd(s: BatchStructure, ell, norm, x):
     return ops.aggregate_raw(s.rowptr_dst, s.col_dst, norm.w_dst, None, norm.den, None, x)
 
 
+def _linear_fwd_stats(lib, x1, x2, w, b, grid):
+    """relu([x1 | x2] W^T + b) and the per-workgroup (sum | sum of squares) slab of the result, or
+    (None, None) when the shape is outside the weight-stationary kernel."""
+    m, k1 = x1.shape
+    k2 = 0 if x2 is None else x2.shape[1]
+    n = w.shape[0]
+    y = torch.empty(m, n, dtype=torch.float32, device=x1.device)
+    slab = torch.empty(grid, 2 * n, dtype=torch.float64, device=x1.device)
+    rc = lib.cgnn_linear_fwd_stats_f32(
+        _lib.ptr(x1), x1.stride(0), k1, _lib.ptr(x2), 0 if x2 is None else x2.stride(0), k2,
+        _lib.ptr(w), _lib.ptr(b), 1, _lib.ptr(y), y.stride(0), m, n, _lib.ptr(slab), _lib.stream_ptr())
+    if rc == _lib.CGNN_EUNSUPPORTED:
+        return None, None
+    _lib.check(rc, "cgnn_linear_fwd_stats_f32")
+    return y, slab
+
+
 class SageEncode(torch.autograd.Function):
     """P[B,H] = mean-pool(SAGE stack(x0)); args = x0, cfg, then (W, b, gamma, beta) per layer."""
 
@@ -82,7 +99,8 @@ class SageEncode(torch.autograd.Function):
         n_nodes = s.num_nodes
         sv = _Saved()
         sv.s, sv.p, sv.training = s, p, training
-        sv.ell = s.fused_meta(TILE_ROWS, int(lib.cgnn_fused_grid()), 0.0)
+        grid = int(lib.cgnn_fused_grid())
+        sv.ell = s.fused_meta(TILE_ROWS, grid, 0.0)
         sv.norm = s.sage_norm()
         sv.xs, sv.aggs, sv.zs, sv.coefs, sv.masks, sv.ws = [], [], [], [], [], []
         sv.xa0 = None
@@ -94,6 +112,8 @@ class SageEncode(torch.autograd.Function):
                 w, b, gamma, beta = (t.contiguous() for t in params[4 * li:4 * li + 4])
                 hid = w.shape[0]
                 fin = x.shape[1]
+                slab = None
+                srows = rows
                 if li == 0 and 2 * fin <= PAD_K and hid in (64, 128) and n_nodes >= PAD_MIN_ROWS:
                     # narrow input layer: pack [x0 | agg(x0) | 0] and the zero-padded weight into
                     # 32-wide panels so that the tall weight-stationary GEMMs apply (K = 10 would
@@ -104,38 +124,49 @@ class SageEncode(torch.autograd.Function):
                                             None, x, out=xa[:, fin:2 * fin])
                     wp = torch.zeros(hid, PAD_K, dtype=torch.float32, device=dev)
                     wp[:, :2 * fin].copy_(w)
-                    z = ops.linear_fwd_raw(xa, None, wp, b, True)
                     sv.xa0 = xa
+                    gemm_in = (xa, None, wp)
                 else:
                     agg = _agg_fwd(s, sv.ell, sv.norm, x)
-                    z = ops.linear_fwd_raw(x, agg, w, b, True)
+                    gemm_in = (x, agg, w)
+                z = None
+                if training:
+                    # projection with the BatchNorm statistics of its output in the epilogue
+                    z, slab = _linear_fwd_stats(lib, *gemm_in, b, grid)
+                    srows = grid
+                if z is None:
+                    z = ops.linear_fwd_raw(*gemm_in, b, True)
+                    if training:
+                        slab = torch.empty(rows, 2 * hid, dtype=torch.float64, device=dev)
+                        srows = rows
+                        _lib.check(lib.cgnn_bn_act_fwd_stats(_lib.ptr(z), n_nodes, hid, _lib.ptr(slab), st()),
+                                   "cgnn_bn_act_fwd_stats")
                 bn = bns_mod[li]
                 coef = _f32(dev, 4 * hid)
-                slab = torch.empty(rows, 2 * hid, dtype=torch.float64, device=dev) if training else None
-                if training:
-                    _lib.check(lib.cgnn_bn_act_fwd_stats(_lib.ptr(z), n_nodes, hid, _lib.ptr(slab), st()),
-                               "cgnn_bn_act_fwd_stats")
                 _lib.check(lib.cgnn_bn_act_finalize(
-                    _lib.ptr(slab), rows, hid, float(max(n_nodes, 1)), int(training), _lib.ptr(gamma),
+                    _lib.ptr(slab), srows, hid, float(max(n_nodes, 1)), int(training), _lib.ptr(gamma),
                     _lib.ptr(beta), _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var),
                     float(bn.momentum), float(bn.eps),
                     _lib.ptr(bn.num_batches_tracked) if training else None, _lib.ptr(coef), st()),
                     "cgnn_bn_act_finalize")
                 mask = torch.empty(n_nodes * (hid // 4), dtype=torch.uint8, device=dev) if p > 0 else None
                 seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0
-                xn = torch.empty_like(z)
-                _lib.check(lib.cgnn_bn_act_fwd_apply(
-                    _lib.ptr(z), _lib.ptr(coef), 0, p, seed,
-                    None if (rng is None or p <= 0) else rng.data_ptr() + 4 * li,
-                    _lib.ptr(mask), _lib.ptr(xn), n_nodes, hid, st()), "cgnn_bn_act_fwd_apply")
+                rw = None if (rng is None or p <= 0) else rng.data_ptr() + 4 * li
                 sv.xs.append(x); sv.aggs.append(agg); sv.zs.append(z); sv.coefs.append(coef)
                 sv.masks.append(mask); sv.ws.append(w)
+                if li == L - 1:
+                    # last layer: BatchNorm + dropout + mean-pool in one pass, X' never written
+                    pooled = _f32(dev, s.num_graphs, hid)
+                    _lib.check(lib.cgnn_bn_act_pool_fwd(_lib.ptr(z), _lib.ptr(coef), 0, p, seed, rw,
+                                                        _lib.ptr(mask), _lib.ptr(s.gptr), s.num_graphs,
+                                                        _lib.ptr(pooled), hid, st()),
+                               "cgnn_bn_act_pool_fwd")
+                    break
+                xn = torch.empty_like(z)
+                _lib.check(lib.cgnn_bn_act_fwd_apply(_lib.ptr(z), _lib.ptr(coef), 0, p, seed, rw,
+                                                     _lib.ptr(mask), _lib.ptr(xn), n_nodes, hid, st()),
+                           "cgnn_bn_act_fwd_apply")
                 x = xn
-            hid = x.shape[1]
-            pooled = _f32(dev, s.num_graphs, hid)
-            _lib.check(lib.cgnn_pool_mean_fwd_f32(_lib.ptr(x), x.stride(0), _lib.ptr(s.gptr),
-                                                  _lib.ptr(pooled), s.num_graphs, hid, st()),
-                       "cgnn_pool_mean_fwd_f32")
         ctx.sv = sv
         ctx.L = L
         return pooled
@@ -151,11 +182,7 @@ class SageEncode(torch.autograd.Function):
         dP = dP.contiguous()
         grads: List[Optional[torch.Tensor]] = [None] * (4 * L)
         with torch.cuda.device(dev):
-            hid = sv.zs[-1].shape[1]
-            dx = _f32(dev, n_nodes, hid)
-            _lib.check(lib.cgnn_pool_mean_bwd_f32(_lib.ptr(dP), _lib.ptr(s.gptr), _lib.ptr(dx),
-                                                  dx.stride(0), s.num_graphs, hid, st()),
-                       "cgnn_pool_mean_bwd_f32")
+            dx = None                      # last layer: gradient rebuilt from dP inside the kernels
             rows = int(lib.cgnn_bn_act_slab_rows(n_nodes))
             for li in range(L - 1, -1, -1):
                 x, agg, z, coef, mask, w = (sv.xs[li], sv.aggs[li], sv.zs[li], sv.coefs[li],
@@ -164,9 +191,11 @@ class SageEncode(torch.autograd.Function):
                 # ---- BatchNorm + dropout backward, ReLU' of the layer and db in two passes
                 slab = torch.empty(rows, 2 * hid, dtype=torch.float64, device=dev)
                 dgamma, dbeta, bwc = _f32(dev, hid), _f32(dev, hid), _f32(dev, 2 * hid)
+                pool = (_lib.ptr(dP), _lib.ptr(s.node_graph), _lib.ptr(s.gptr)) if li == L - 1 \
+                    else (None, None, None)
                 _lib.check(lib.cgnn_bn_act_bwd_stats(_lib.ptr(dx), _lib.ptr(z), _lib.ptr(mask),
                                                      _lib.ptr(coef), 0, sv.p, n_nodes, hid,
-                                                     _lib.ptr(slab), st()), "cgnn_bn_act_bwd_stats")
+                                                     _lib.ptr(slab), *pool, st()), "cgnn_bn_act_bwd_stats")
                 _lib.check(lib.cgnn_bn_act_bwd_finalize(_lib.ptr(slab), rows, hid,
                                                         float(max(n_nodes, 1)), int(not sv.training),
                                                         _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(bwc),
@@ -177,7 +206,7 @@ class SageEncode(torch.autograd.Function):
                 _lib.check(lib.cgnn_bn_act_bwd_apply(_lib.ptr(dx), _lib.ptr(z), _lib.ptr(mask),
                                                      _lib.ptr(coef), _lib.ptr(bwc), 0, sv.p, 1,
                                                      _lib.ptr(cs_slab), _lib.ptr(dpre), n_nodes, hid,
-                                                     st()), "cgnn_bn_act_bwd_apply")
+                                                     *pool, st()), "cgnn_bn_act_bwd_apply")
                 db = _f32(dev, hid)
                 _lib.check(lib.cgnn_slab_reduce_f64(_lib.ptr(cs_slab), cs_rows, hid, _lib.ptr(db), st()),
                            "cgnn_slab_reduce_f64")

@@ -113,6 +113,17 @@ int cgnn_linear_fwd_f32(const float* X1, int64_t ldx1, int32_t K1,
                         const float* W, const float* bias, int32_t relu,
                         float* Y, int64_t ldy, int64_t M, int32_t N, void* stream);
 
+/* cgnn_linear_fwd_f32 that also leaves the BatchNorm statistics of its output behind:
+ * stat_slab fp64 [cgnn_fused_grid()][2N] = per-workgroup (sum Y | sum Y^2), the layout
+ * cgnn_bn_act_finalize reads -- saves the separate pass of cgnn_bn_act_fwd_stats over Y.
+ * Only the tall weight-stationary shapes (M >= 4096, N in {64,128}, K % 32 == 0, K*N <= 32768,
+ * 16-byte aligned rows) are covered; others return CGNN_EUNSUPPORTED and launch nothing. */
+int cgnn_linear_fwd_stats_f32(const float* X1, int64_t ldx1, int32_t K1,
+                              const float* X2, int64_t ldx2, int32_t K2,
+                              const float* W, const float* bias, int32_t relu,
+                              float* Y, int64_t ldy, int64_t M, int32_t N,
+                              double* stat_slab, void* stream);
+
 int cgnn_linear_bwd_input_f32(const float* dY, int64_t lddy, const float* W, int32_t ldw,
                               int32_t k0, float* dX, int64_t lddx,
                               int64_t M, int32_t N, int32_t K, void* stream);
@@ -357,8 +368,16 @@ int cgnn_bn_act_finalize(const double* slab, int32_t rows, int32_t N, double cou
 int cgnn_bn_act_fwd_apply(const float* Y, const float* coef, int32_t relu, float p_drop,
                           uint64_t seed, const uint32_t* seed_dev, uint8_t* mask_out, float* X,
                           int64_t M, int32_t N, void* stream);
+/* Readout fused with the last layer's BatchNorm(+act)+dropout (models.py:211 / :262):
+ * P[g,:] = sum_{rows of g} drop(act(a*Y+b)) / (n_g + 1e-8); X' is never materialised.  gptr int32
+ * [B+1].  Its backward is the dP form of the two kernels below: dP != NULL replaces dX by
+ * dP[node_graph[r],:] / (n_g + 1e-8), rebuilt per row (dX may then be NULL). */
+int cgnn_bn_act_pool_fwd(const float* Y, const float* coef, int32_t relu, float p_drop, uint64_t seed,
+                         const uint32_t* seed_dev, uint8_t* mask_out, const int32_t* gptr,
+                         int32_t num_graphs, float* P, int32_t N, void* stream);
 int cgnn_bn_act_bwd_stats(const float* dX, const float* Y, const uint8_t* mask, const float* coef,
                           int32_t relu, float p_drop, int64_t M, int32_t N, double* slab,
+                          const float* dP, const int32_t* node_graph, const int32_t* gptr,
                           void* stream);
 int cgnn_bn_act_bwd_finalize(const double* slab, int32_t rows, int32_t N, double count,
                              int32_t zero_coef, float* dgamma, float* dbeta, float* bwc,
@@ -370,7 +389,8 @@ int cgnn_bn_act_bwd_finalize(const double* slab, int32_t rows, int32_t N, double
 int64_t cgnn_bn_act_apply_blocks(int64_t M, int32_t N);
 int cgnn_bn_act_bwd_apply(const float* dX, const float* Y, const uint8_t* mask, const float* coef,
                           const float* bwc, int32_t relu, float p_drop, int32_t relu_in,
-                          double* colsum_slab, float* dY, int64_t M, int32_t N, void* stream);
+                          double* colsum_slab, float* dY, int64_t M, int32_t N, const float* dP,
+                          const int32_t* node_graph, const int32_t* gptr, void* stream);
 
 #ifdef __cplusplus
 }

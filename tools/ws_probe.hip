@@ -18,8 +18,8 @@ int main() {
     float ms; hipEventElapsedTime(&ms, a, b);
     printf("%s %.1f us  (%.1f TFLOP/s)\n", name, ms * 100, 2.0 * M * K * N / (ms / 10) / 1e9);
   };
-  run("fwd", [&] { cgnn_ws_linear_fwd(X, K, K, nullptr, 0, 0, W, nullptr, 0, Y, N, M, N, 0); });
+  run("fwd", [&] { cgnn_ws_linear_fwd(X, K, K, nullptr, 0, 0, W, nullptr, 0, Y, N, M, N, nullptr, 0); });
   run("bwd_input", [&] { cgnn_ws_linear_bwd_input(Y, N, W, K, 0, dX, K, M, N, K, 0); });
-  run("bwd_weight", [&] { cgnn_ws_linear_bwd_weight(Y, N, X, K, slab, M, N, K, 0); });
+  run("bwd_weight", [&] { cgnn_ws_linear_bwd_weight(Y, N, X, K, K, nullptr, 0, 0, slab, M, N, 0); });
   return 0;
 }
