@@ -39,6 +39,9 @@ WORKLOADS = {
     "cfg4-headline-gcn-4096x360-h64": dict(model="gcn", n=360, k=14, hidden=64, batch=4096),
     "cfg2-gcn-512x84-h64": dict(model="gcn", n=84, k=8, hidden=64, batch=512),
     "cfg3-sage-512x360-h128": dict(model="sage", n=360, k=14, hidden=128, batch=512),
+    # BASELINE config 5's shape run in fp32 (fp16 storage exists for its scatter kernel only:
+    # tools/scatter_bench.py); dense 1000-ROI graphs, 100k edges each
+    "cfg5-gcn-64x1000-h256-fp32": dict(model="gcn", n=1000, k=100, hidden=256, batch=64),
 }
 
 
@@ -53,7 +56,7 @@ def cpu_baseline(model: str, n: int, k: int, hidden: int, budget_s: float = 20.0
     from oracle import reference_path as O
     from connectome_gnn_amd.synthetic import generate_packed
     from connectome_gnn_amd.resident import assemble_batch
-    sample = 128 if n >= 360 else 512
+    sample = 8 if n >= 1000 else (128 if n >= 360 else 512)
     # a 1-GPU box's CPU share is 16 cores; more threads only oversubscribe the ATen loops
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     ds = generate_packed(sample, n, k, seed=42)

@@ -137,6 +137,22 @@ def aggregate_tiled_raw(structure, meta, flags: int, x, pre, post, bias, yadd=No
     return y
 
 
+def aggregate_tiled_f16_raw(structure, meta, flags: int, x, pre, post, bias) -> torch.Tensor:
+    """fp16-storage / fp32-accumulate tiled aggregate (cgnn_aggregate_tiled_f16): x, result half."""
+    lib = _lib.load()
+    _require_device(x, "x")
+    if x.dtype != torch.float16:
+        raise TypeError(f"x must be float16, got {x.dtype}")
+    n, f = x.shape
+    y = torch.empty(n, f, dtype=torch.float16, device=x.device)
+    tiles = structure.tiles_struct(meta)
+    with torch.cuda.device(x.device), _lib.timed("cgnn_aggregate_tiled_f16", f"F={f}"):
+        _lib.check(lib.cgnn_aggregate_tiled_f16(
+            ctypes.byref(tiles), int(flags), _lib.ptr(x), x.stride(0), f, _lib.ptr(pre), _lib.ptr(post),
+            _lib.ptr(bias), _lib.ptr(y), y.stride(0), _lib.stream_ptr()), "cgnn_aggregate_tiled_f16")
+    return y
+
+
 class _AggregateTiled(torch.autograd.Function):
     """Y = post * A(pre * X) + bias on the blocked-ELL tiles; backward = the transposed ELL with
     pre and post swapped."""

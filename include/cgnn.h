@@ -250,6 +250,16 @@ int cgnn_aggregate_tiled_f32(const cgnn_tiles* t, int32_t flags, const float* X,
                              int32_t F, const float* pre, const float* post, const float* bias,
                              const float* Yadd, int64_t ldadd, float* Y, int64_t ldy, void* stream);
 
+/* fp16-storage / fp32-accumulate form of cgnn_aggregate_tiled_f32 for large dense parcellations
+ * (BASELINE config 5: 1000-ROI graphs, 10 % density, hidden 256): X, Y are IEEE half [Nn, F],
+ * tiles of up to CGNN_H16_MAX_ROWS rows (a whole 1000-ROI graph x 64 columns = 128 KB of LDS),
+ * entries streamed 16 steps at a time (any degree).  pre/post/bias stay fp32.  The reference has
+ * no fp16 path; results are the fp32 oracle's to fp16 resolution (tests use 2e-3 of the scale). */
+#define CGNN_H16_MAX_ROWS 1024
+int cgnn_aggregate_tiled_f16(const cgnn_tiles* t, int32_t flags, const void* X, int64_t ldx,
+                             int32_t F, const float* pre, const float* post, const float* bias,
+                             void* Y, int64_t ldy, void* stream);
+
 /* Layer 0 forward.  X0 [Nn,F0] (F0 <= 16), W0 [64,F0], bias [64] -> Y [Nn,64];
  * stat_slab [grid][128] fp64 (sum(y) | sum(y^2)) or NULL (eval). */
 int cgnn_gcn_fused_fwd_first(const cgnn_tiles* t, const float* X0, int32_t F0, const float* W0,

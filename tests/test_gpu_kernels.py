@@ -171,6 +171,39 @@ def test_aggregate_tiled_forward_backward(f, sizes, deg, kind):
     assert torch.equal(plain, ops.aggregate_tiled_raw(s, meta, 0, wide[:, f:].contiguous(), None, None, None))
 
 
+@pytest.mark.parametrize("sizes,deg,f", [([1000, 37, 500], 60, 128), ([84] * 5, 8, 64), ([1024], 100, 64)])
+def test_aggregate_tiled_f16_storage(sizes, deg, f):
+    """Config-5 scatter kernel: fp16 storage, fp32 accumulate, graphs of up to 1024 nodes and
+    ~100 neighbours per node.  No fp16 reference exists -> compared with the fp32
+    aggregation of the same half-rounded inputs at fp16 resolution of the result's scale."""
+    from connectome_gnn_amd import _lib, ops
+    ei, w, ptr, bid, nn_ = _rand_graph_batch(sizes, deg, 21)
+    b = _batch(ei, w, ptr, bid, nn_, f).to(DEV)
+    s = b.structure()
+    grid = _lib.load().cgnn_fused_grid()
+    xh = b.node_features.half()
+    xr = xh.float().cpu()
+    n = s.gcn_norm()
+    dis = n.dis.cpu()
+    for kind in ("gcn", "sage_T"):
+        if kind == "gcn":
+            meta = s.fused_meta(1024, grid, 1.0)
+            got = ops.aggregate_tiled_f16_raw(s, meta, 0, xh, n.dis, n.dis, None)
+            xs = (xr * dis[:, None]).half().float()              # the staged operand is rounded to half
+            msg = xs[ei[0]] * w[:, None]
+            want = (torch.zeros(nn_, f).index_add_(0, ei[1], msg) + xs) * dis[:, None]
+        else:
+            meta = s.fused_meta(1024, grid, 0.0)
+            got = ops.aggregate_tiled_f16_raw(s, meta, ops.AGG_TRANSPOSED, xh, None, None, None)
+            msg = xr[ei[1]] * w[:, None]
+            want = torch.zeros(nn_, f).index_add_(0, ei[0], msg)
+        scale = float(want.abs().max())
+        torch.testing.assert_close(got.float().cpu(), want, rtol=2e-3, atol=2e-3 * scale)
+        assert torch.equal(got, ops.aggregate_tiled_f16_raw(
+            s, meta, 0 if kind == "gcn" else ops.AGG_TRANSPOSED, xh,
+            n.dis if kind == "gcn" else None, n.dis if kind == "gcn" else None, None))
+
+
 def test_aggregate_deterministic():
     from connectome_gnn_amd import ops
     ei, w, ptr, bid, nn_ = _rand_graph_batch([84] * 16, 8, 4)
