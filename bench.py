@@ -178,12 +178,19 @@ def main() -> None:
     # dominant kernel of the step and its ALGORITHMIC bytes per launch (SURVEY 8d per-unit
     # figures): fused path -> the per-layer backward kernel: BN-backward 5*Nn*H*s +
     # Nn*s*(H + 2*F_l) + 8*Ee; layered path -> the aggregate: 2*Nn*F*s + 8*Ee + 4*(Nn+1).
-    if impl_used == "fused":
+    agg_bytes = lambda nn_, ee: 2.0 * nn_ * hidden * 4 + 8.0 * ee + 4.0 * (nn_ + 1)
+    candidates = {
+        "cgnn_gcn_fused_bwd": lambda nn_, ee: nn_ * 4.0 * (5 * hidden + hidden + 2 * hidden) + 8.0 * ee,
+        f"cgnn_aggregate_tiled_f32[F={hidden}]": agg_bytes,     # LDS-tiled aggregate (wide layers)
+        f"cgnn_aggregate_f32[F={hidden}]": agg_bytes,           # gather form (graphs > 384 nodes)
+    }
+    if impl_used == "fused" and model_kind == "gcn":
         dom = "cgnn_gcn_fused_bwd"
-        dom_bytes_fn = lambda nn_, ee: nn_ * 4.0 * (5 * hidden + hidden + 2 * hidden) + 8.0 * ee
+    elif batches[0].structure().tiled_ok(hidden):
+        dom = f"cgnn_aggregate_tiled_f32[F={hidden}]"
     else:
         dom = f"cgnn_aggregate_f32[F={hidden}]"
-        dom_bytes_fn = lambda nn_, ee: 2.0 * nn_ * hidden * 4 + 8.0 * ee + 4.0 * (nn_ + 1)
+    dom_bytes_fn = candidates[dom]
     if graphed is None:
         _lib.TIMER = _lib.KernelTimer([dom])
     fence()
