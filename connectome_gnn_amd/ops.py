@@ -153,6 +153,36 @@ def aggregate_tiled_f16_raw(structure, meta, flags: int, x, pre, post, bias) -> 
     return y
 
 
+def dense_adj_f16(structure, coef, selfc, transposed: bool = False) -> torch.Tensor:
+    """[B, P, P] half dense operator of one CSR ordering (cgnn_dense_adj_f16); static per batch."""
+    lib = _lib.load()
+    s = structure
+    pitch = (s.max_nodes_per_graph + 63) // 64 * 64
+    m = torch.empty(s.num_graphs, pitch, pitch, dtype=torch.float16, device=coef.device)
+    rowptr, col = (s.rowptr_src, s.col_src) if transposed else (s.rowptr_dst, s.col_dst)
+    with torch.cuda.device(coef.device):
+        _lib.check(lib.cgnn_dense_adj_f16(_lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(coef), _lib.ptr(selfc),
+                                          _lib.ptr(s.gptr), s.num_graphs, pitch, _lib.ptr(m),
+                                          _lib.stream_ptr()), "cgnn_dense_adj_f16")
+    return m
+
+
+def dense_aggregate_f16_raw(structure, m, x, bias=None) -> torch.Tensor:
+    """Y_g = M_g X_g on the fp16 matrix cores (cgnn_dense_aggregate_f16); x, result half."""
+    lib = _lib.load()
+    _require_device(x, "x")
+    if x.dtype != torch.float16 or m.dtype != torch.float16:
+        raise TypeError("x and m must be float16")
+    n, f = x.shape
+    y = torch.empty(n, f, dtype=torch.float16, device=x.device)
+    with torch.cuda.device(x.device), _lib.timed("cgnn_dense_aggregate_f16", f"F={f}"):
+        _lib.check(lib.cgnn_dense_aggregate_f16(
+            _lib.ptr(m), m.shape[1], _lib.ptr(structure.gptr), structure.num_graphs, _lib.ptr(x),
+            x.stride(0), f, _lib.ptr(bias), _lib.ptr(y), y.stride(0), _lib.stream_ptr()),
+            "cgnn_dense_aggregate_f16")
+    return y
+
+
 class _AggregateTiled(torch.autograd.Function):
     """Y = post * A(pre * X) + bias on the blocked-ELL tiles; backward = the transposed ELL with
     pre and post swapped."""

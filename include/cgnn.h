@@ -260,6 +260,21 @@ int cgnn_aggregate_tiled_f16(const cgnn_tiles* t, int32_t flags, const void* X, 
                              int32_t F, const float* pre, const float* post, const float* bias,
                              void* Y, int64_t ldy, void* stream);
 
+/* Dense form of the same aggregation for large dense parcellations, on the fp16 matrix cores
+ * (v_mfma_f32_32x32x16_f16, fp32 accumulate): Y_g = M_g X_g per graph.
+ * cgnn_dense_adj_f16 builds M [B][P][P] half once per batch from a CSR ordering: M_g[r][c] = sum of
+ * coef over the slots (row r, column c) (+ selfc[r] on the diagonal, nullable); rows/columns past a
+ * graph's size are zero.  The element order inside M is the kernel's own (MFMA-fragment-major):
+ * M is only ever passed back to cgnn_dense_aggregate_f16.  Pass the dst-sorted CSR + coef_dst for the forward operator, the
+ * src-sorted CSR + coef_src for its transpose.  P: common pitch, multiple of 64, <= 1024, >= the
+ * largest graph.  X, Y half [Nn, F], F % 64 == 0; bias fp32 or NULL. */
+int cgnn_dense_adj_f16(const int32_t* rowptr, const int32_t* col, const float* coef,
+                       const float* selfc, const int32_t* gptr, int32_t num_graphs, int32_t P,
+                       void* M, void* stream);
+int cgnn_dense_aggregate_f16(const void* M, int32_t P, const int32_t* gptr, int32_t num_graphs,
+                             const void* X, int64_t ldx, int32_t F, const float* bias, void* Y,
+                             int64_t ldy, void* stream);
+
 /* Layer 0 forward.  X0 [Nn,F0] (F0 <= 16), W0 [64,F0], bias [64] -> Y [Nn,64];
  * stat_slab [grid][128] fp64 (sum(y) | sum(y^2)) or NULL (eval). */
 int cgnn_gcn_fused_fwd_first(const cgnn_tiles* t, const float* X0, int32_t F0, const float* W0,

@@ -204,6 +204,32 @@ def test_aggregate_tiled_f16_storage(sizes, deg, f):
             n.dis if kind == "gcn" else None, n.dis if kind == "gcn" else None, None))
 
 
+@pytest.mark.parametrize("sizes,deg,f", [([1000, 37, 500], 60, 128), ([84] * 5, 8, 64), ([1024], 100, 64),
+                                         ([1008, 3], 30, 256)])
+def test_dense_aggregate_f16(sizes, deg, f):
+    """Dense per-graph operator on the fp16 matrix cores (config 5's scatter): forward (dst CSR) and
+    transpose (src CSR) against the fp32 aggregation with the coefficients and inputs rounded to
+    half (what the kernel is given), at fp16 resolution of the result."""
+    from connectome_gnn_amd import ops
+    ei, w, ptr, bid, nn_ = _rand_graph_batch(sizes, deg, 31)
+    b = _batch(ei, w, ptr, bid, nn_, f).to(DEV)
+    s = b.structure()
+    n = s.gcn_norm()
+    xh = b.node_features.half()
+    xr = xh.float().cpu()
+    dis = n.dis.cpu()
+    c = dis[ei[0]] * w * dis[ei[1]]
+    for transposed in (False, True):
+        m = ops.dense_adj_f16(s, n.coef_src if transposed else n.coef_dst, n.selfc, transposed)
+        got = ops.dense_aggregate_f16_raw(s, m, xh)
+        src, dst = (ei[1], ei[0]) if transposed else (ei[0], ei[1])
+        want = torch.zeros(nn_, f).index_add_(0, dst, xr[src] * c[:, None]) + xr * (dis * dis)[:, None]
+        scale = float(want.abs().max())
+        torch.testing.assert_close(got.float().cpu(), want, rtol=3e-3, atol=3e-3 * scale)
+        assert torch.equal(got, ops.dense_aggregate_f16_raw(s, m, xh))
+        assert torch.equal(m, ops.dense_adj_f16(s, n.coef_src if transposed else n.coef_dst, n.selfc, transposed))
+
+
 def test_aggregate_deterministic():
     from connectome_gnn_amd import ops
     ei, w, ptr, bid, nn_ = _rand_graph_batch([84] * 16, 8, 4)

@@ -43,7 +43,10 @@ def alg_bytes(sz):
 
 out = {"workload": f"cfg5 scatter: {B} x {N}-ROI graphs, k={K} ({s.num_edges // B} edges/graph), hidden {H}",
        "hbm_peak_GBps": 8000.0, "results": []}
+mden = ops.dense_adj_f16(s, norm.coef_dst, norm.selfc)
 for name, fn, sz in (
+        ("cgnn_dense_aggregate_f16 (fp16 storage, dense M_g on the fp16 matrix cores)",
+         lambda: ops.dense_aggregate_f16_raw(s, mden, x16), 2),
         ("cgnn_aggregate_tiled_f16 (fp16 storage, LDS tiles)",
          lambda: ops.aggregate_tiled_f16_raw(s, meta, 0, x16, norm.dis, norm.dis, None), 2),
         ("cgnn_aggregate_tiled_f16 transposed",
