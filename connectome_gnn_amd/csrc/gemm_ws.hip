@@ -17,8 +17,8 @@
 // v_mfma_f32_32x32x2_f32 operand maps (cdna_hip_programming.md section 3):
 //   A: lane l holds A[i = l&31][k = l>>5]      B: lane l holds B[k = l>>5][j = l&31]
 //   C/D reg r of lane l: row = (r&3) + 8*(r>>2) + 4*(l>>5), col = l&31
-// The reduction index and the tile->column map are permuted freely: lane half h owns the
-// reduction range [h*K/2, (h+1)*K/2) (so a lane reads consecutive floats of its row), and output
+// The reduction index and the tile->column map are permuted freely: the two lane halves of a row
+// read alternating 16-byte pieces of that row (k = 8*i + 4*h + e), and output
 // tile t of a group holds the columns {4*j + t}, so a lane ends up with 4 consecutive columns
 // of each of its rows = 16-byte stores.
 #include "common.h"
@@ -72,7 +72,10 @@ __global__ void __launch_bounds__(FW_THR) k_ws_fwd(
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, kh = lane >> 5;
-  const int c0 = kh * (K / 2);                       // first reduction index of this lane half
+  // reduction index of lane half kh at load u of chunk c: 8*(c*UNR + u) + 4*kh + e -- the two
+  // lanes of a row read ADJACENT 16-byte pieces, so a wave load touches 32 lines, not 64 (the
+  // L1 request rate, ~0.3 lines/clk/CU for such partial-line accesses, is what the A stream costs)
+  const int c0 = 4 * kh;
   const int nchunks = (K / 8) / UNR;
   const int64_t nrb = (M + 31) / 32;
   const int64_t stride = (int64_t)gridDim.x * FW_NW;
@@ -93,7 +96,7 @@ __global__ void __launch_bounds__(FW_THR) k_ws_fwd(
   for (int t = 0; t < NT; ++t) s1[t] = s2[t] = 0.0;
   if (rb < nrb) {
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) cur[u] = ldg4(row_ptr(rb, c0 + 4 * u));
+    for (int u = 0; u < UNR; ++u) cur[u] = ldg4(row_ptr(rb, c0 + 8 * u));
   }
   for (; rb < nrb; rb += stride) {
     f32x16 acc[NT];
@@ -106,15 +109,15 @@ __global__ void __launch_bounds__(FW_THR) k_ws_fwd(
       const int cn = last ? 0 : c + 1;
       if (rbn < nrb) {
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) nxt[u] = ldg4(row_ptr(rbn, c0 + 4 * (cn * UNR + u)));
+        for (int u = 0; u < UNR; ++u) nxt[u] = ldg4(row_ptr(rbn, c0 + 8 * (cn * UNR + u)));
       }
-      const float* wl = Wl + (int64_t)(c0 + 4 * c * UNR) * N + NT * j;
+      const float* wl = Wl + (int64_t)(c0 + 8 * c * UNR) * N + NT * j;
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         const float av[4] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float* wp = wl + (4 * u + e) * N;
+          const float* wp = wl + (8 * u + e) * N;
           if (NT == 4) {
             const float4 b = *reinterpret_cast<const float4*>(wp);
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], b.x, acc[0], 0, 0, 0);
@@ -204,7 +207,7 @@ __global__ void __launch_bounds__(FW_THR) k_ws_bwd_input(
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, nh = lane >> 5;
-  const int c0 = nh * (N / 2);
+  const int c0 = 4 * nh;                             // same interleaved reduction map as k_ws_fwd
   const int nchunks = (N / 8) / UNR;
   const int64_t nrb = (M + 31) / 32;
   const int64_t stride = (int64_t)gridDim.x * FW_NW;
@@ -220,7 +223,7 @@ __global__ void __launch_bounds__(FW_THR) k_ws_bwd_input(
   if (rb < nrb) {
     const float* p = row_ptr(rb);
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) cur[u] = ldg4(p + 4 * u);
+    for (int u = 0; u < UNR; ++u) cur[u] = ldg4(p + 8 * u);
   }
   for (; rb < nrb; rb += stride) {
     f32x16 acc[NT];
@@ -231,17 +234,17 @@ __global__ void __launch_bounds__(FW_THR) k_ws_bwd_input(
       const int64_t rbn = last ? rb + stride : rb;
       const int cn = last ? 0 : c + 1;
       if (rbn < nrb) {
-        const float* p = row_ptr(rbn) + 4 * cn * UNR;
+        const float* p = row_ptr(rbn) + 8 * cn * UNR;
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) nxt[u] = ldg4(p + 4 * u);
+        for (int u = 0; u < UNR; ++u) nxt[u] = ldg4(p + 8 * u);
       }
-      const float* wl = Wl + (c0 + 4 * c * UNR) * K + VW * j;
+      const float* wl = Wl + (c0 + 8 * c * UNR) * K + VW * j;
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         const float av[4] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float* wp = wl + (4 * u + e) * K;
+          const float* wp = wl + (8 * u + e) * K;
 #pragma unroll
           for (int g = 0; g < NG; ++g) {
             if (VW == 4) {

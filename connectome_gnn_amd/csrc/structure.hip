@@ -361,7 +361,7 @@ int cgnn_sage_norm(const int64_t* edge_index, const float* w, int64_t nn, int64_
                    void* stream) {
   if (nn < 0 || ne < 0) return CGNN_EINVAL;
   if (nn > 0 && (!rowptr_dst || !den)) return CGNN_EINVAL;
-  if (ne > 0 && (!edge_index || !w || !eid_dst || !eid_src || !w_dst || !coef_src_bwd))
+  if (ne > 0 && (!edge_index || !w || !eid_dst || !w_dst || (coef_src_bwd && !eid_src)))
     return CGNN_EINVAL;
   (void)rowptr_src;
   hipStream_t st = cgnn_stream(stream);
@@ -369,7 +369,7 @@ int cgnn_sage_norm(const int64_t* edge_index, const float* w, int64_t nn, int64_
     k_sage_den<<<blocks_for(nn, 256), 256, 0, st>>>(w, rowptr_dst, eid_dst, nn, den, w_dst);
     CGNN_CHECK_LAUNCH();
   }
-  if (ne > 0) {
+  if (ne > 0 && coef_src_bwd) {
     k_sage_coef_bwd<<<blocks_for(ne, 256), 256, 0, st>>>(edge_index + ne, w, den, eid_src, ne,
                                                          coef_src_bwd);
     CGNN_CHECK_LAUNCH();

@@ -101,7 +101,7 @@ class SageEncode(torch.autograd.Function):
         sv.s, sv.p, sv.training = s, p, training
         grid = int(lib.cgnn_fused_grid())
         sv.ell = s.fused_meta(TILE_ROWS, grid, 0.0)
-        sv.norm = s.sage_norm()
+        sv.norm = s.sage_norm(backward_coef=False)
         sv.xs, sv.aggs, sv.zs, sv.coefs, sv.masks, sv.ws = [], [], [], [], [], []
         sv.xa0 = None
         with torch.cuda.device(dev):

@@ -140,13 +140,14 @@ class BatchStructure:
                 _lib.stream_ptr()), "cgnn_gcn_norm")
         return n
 
-    def sage_norm(self) -> SageNorm:
-        """models.py:146-149 via cgnn_sage_norm."""
+    def sage_norm(self, backward_coef: bool = True) -> SageNorm:
+        """models.py:146-149 via cgnn_sage_norm.  backward_coef=False skips the per-edge
+        w_e / den[dst_e] array of the gather-form backward (the tiled form divides by den itself)."""
         lib = _lib.load()
         dev = self.rowptr_dst.device
         f32 = dict(dtype=torch.float32, device=dev)
         n = SageNorm(torch.empty(self.num_nodes, **f32), torch.empty(self.num_edges, **f32),
-                     torch.empty(self.num_edges, **f32))
+                     torch.empty(self.num_edges, **f32) if backward_coef else None)
         with torch.cuda.device(dev):
             _lib.check(lib.cgnn_sage_norm(
                 _lib.ptr(self._edge_index), _lib.ptr(self._edge_weight), self.num_nodes,

@@ -78,7 +78,8 @@ int cgnn_gcn_norm(const int64_t* edge_index, const float* edge_weight,
 
 /* GraphSAGE weighted-mean normalisation, models.py:146-149:
  * den[d] = sum_{e: dst=d} w_e + 1e-8; w_dst [Ee] = w permuted to dst-CSR slots;
- * coef_src_bwd [Ee] = w_e / den[dst_e] in src-CSR slots (backward of the mean). */
+ * coef_src_bwd [Ee] = w_e / den[dst_e] in src-CSR slots (backward of the mean; may be NULL when
+ * the caller's backward divides by den itself, as cgnn_aggregate_tiled_f32 does). */
 int cgnn_sage_norm(const int64_t* edge_index, const float* edge_weight,
                    int64_t num_nodes, int64_t num_edges,
                    const int32_t* rowptr_dst, const int32_t* eid_dst,
