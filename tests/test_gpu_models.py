@@ -350,6 +350,38 @@ def test_edge_cases_empty_graphs_and_fallbacks():
         C.GCNConnectome(5, 32, impl="fused").to(DEV)(C.collate_graphs([g_ok]).to(DEV))
 
 
+def test_sage_edge_cases_empty_graphs_and_fallbacks():
+    """GraphSAGE: zero-node / zero-edge graphs inside a batch on the one-node encoder, a graph
+    larger than the LDS tile and hidden 32 on the op-by-op path -- all against the oracle."""
+    import connectome_gnn_amd as C
+    g_ok = C.generate_connectome(30, 4, seed=1)
+    empty = C.ConnectomeGraph(torch.zeros(0, 5), torch.zeros(2, 0, dtype=torch.long), torch.zeros(0),
+                              torch.tensor(1))
+    lonely = C.ConnectomeGraph(torch.randn(3, 5), torch.zeros(2, 0, dtype=torch.long), torch.zeros(0),
+                               torch.tensor(0))
+    big = C.generate_connectome(400, 6, seed=2)
+    for graphs, hidden, want_impl in (([g_ok, empty, lonely, g_ok], 64, "fused"),
+                                      ([g_ok, big], 64, "layered"), ([g_ok, lonely], 32, "layered")):
+        b = C.collate_graphs(graphs)
+        torch.manual_seed(2)
+        m = C.GraphSAGEConnectome(5, hidden, dropout=0.0)
+        st = O.require_grad({k: v.clone() for k, v in m.state_dict().items()})
+        ob = O.OBatch(b.node_features, b.edge_index, b.edge_weight, b.batch, b.labels, b.ptr)
+        lo = O.sage_forward(st, ob, 0.0, True)
+        lo.sum().backward()
+        m = m.to(DEV).train()
+        lg = m(b.to(DEV))
+        assert m.impl_used == want_impl
+        lg.sum().backward()
+        torch.testing.assert_close(lg.cpu(), lo, **TOL)
+        for k, p in m.named_parameters():
+            w = st[k].grad
+            torch.testing.assert_close(p.grad.cpu(), w, rtol=1e-4, atol=2e-6 + 1e-5 * float(w.abs().max()),
+                                       msg=lambda s_: f"{k}: {s_}")
+    with pytest.raises(RuntimeError, match="not applicable"):
+        C.GraphSAGEConnectome(5, 32, impl="fused").to(DEV)(C.collate_graphs([g_ok]).to(DEV))
+
+
 def test_graphed_step_matches_eager_and_redraws_dropout():
     """HIP-graph replay of the whole step == eager steps (dropout 0), and with dropout > 0 every
     replay draws a fresh mask (the by-value seed is frozen in the graph; the device key is not)."""
