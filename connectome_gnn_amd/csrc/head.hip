@@ -1,0 +1,225 @@
+// head.hip -- the graph-level classifier head in one kernel each way (gfx950, fp32).
+//
+//   logits = Linear2( dropout( relu( Linear1(P) ) ) )        reference models.py:196-201, 213-216
+//
+// P is [B, H] (one row per GRAPH, B = 512..4096), so the head is a few MFLOP: through generic
+// GEMM libraries it is six launches of 5-36 us each (tile shapes meant for large problems); here
+// it is one forward and one backward kernel of a few us.  Weights live in LDS, one thread per
+// (row, output unit); the backward leaves per-workgroup partial parameter gradients in a slab
+// [grid][H2*H + H2 + C*H2 + C] that cgnn_slab_reduce_f32 combines in fixed order.
+#include "common.h"
+
+namespace {
+
+constexpr int HTHR = 256;
+constexpr int HEAD_MAX_H = 128;          // input width (wider heads stay on the generic GEMMs)
+constexpr int HEAD_MAX_C = 16;           // classes
+
+__device__ __forceinline__ uint32_t hmix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+
+struct HeadDrop {
+  uint32_t thr16;      // keep iff 16-bit hash >= thr16
+  float scale;         // 1 / (1 - p)
+  uint32_t key0, key1;
+  const uint32_t* dev_key;
+};
+
+// ---------------------------------------------------------------------------------- forward
+// block: rows [r0, r0 + RB), RB = HTHR / H2 (H2 <= 128 -> RB >= 2)
+__global__ void __launch_bounds__(HTHR) k_head_fwd(
+    const float* __restrict__ P, int B, int H, int H2, int C, const float* __restrict__ W1,
+    const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2,
+    HeadDrop drop, int use_drop, float* __restrict__ H1, float* __restrict__ fac,
+    float* __restrict__ logits) {
+  extern __shared__ float sm[];
+  float* w1 = sm;                          // [H2][H + 1]
+  float* pl = w1 + H2 * (H + 1);           // [RB][H]
+  float* hl = pl + (HTHR / H2) * H;        // [RB][H2]
+  if (drop.dev_key) drop.key1 ^= drop.dev_key[0];
+  const int RB = HTHR / H2;
+  for (int i = threadIdx.x; i < H2 * H; i += HTHR) w1[(i / H) * (H + 1) + i % H] = W1[i];
+  const int j = threadIdx.x % H2, rr = threadIdx.x / H2;
+  const float bj = b1[j];
+  for (int r0 = blockIdx.x * RB; r0 < B; r0 += gridDim.x * RB) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < RB * H; i += HTHR) {
+      const int r = r0 + i / H;
+      pl[i] = r < B ? P[(int64_t)r * H + i % H] : 0.f;
+    }
+    __syncthreads();
+    const int r = r0 + rr;
+    if (rr < RB) {
+      float z = bj;
+      const float* wr = w1 + j * (H + 1);
+      const float* pr = pl + rr * H;
+      for (int k = 0; k < H; ++k) z = fmaf(pr[k], wr[k], z);
+      float f = z > 0.f ? 1.f : 0.f;
+      if (use_drop) {
+        const uint32_t e = (uint32_t)r * (uint32_t)H2 + (uint32_t)j;
+        const uint32_t hsh = hmix32(hmix32(e ^ drop.key0) + drop.key1);
+        f = ((hsh & 0xFFFFu) >= drop.thr16) ? f * drop.scale : 0.f;
+      }
+      const float hv = z * f;
+      hl[rr * H2 + j] = hv;
+      if (r < B) {
+        H1[(int64_t)r * H2 + j] = hv;
+        fac[(int64_t)r * H2 + j] = f;
+      }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < RB * C; t += HTHR) {
+      const int rl = t / C, c = t % C, row = r0 + rl;
+      if (row < B) {
+        float acc = b2[c];
+        for (int k = 0; k < H2; ++k) acc = fmaf(hl[rl * H2 + k], W2[c * H2 + k], acc);
+        logits[(int64_t)row * C + c] = acc;
+      }
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------- backward
+// slab row layout: dW1 [H2*H] | db1 [H2] | dW2 [C*H2] | db2 [C]
+__global__ void __launch_bounds__(HTHR) k_head_bwd(
+    const float* __restrict__ dL, const float* __restrict__ P, const float* __restrict__ H1,
+    const float* __restrict__ fac, int B, int H, int H2, int C, const float* __restrict__ W1,
+    const float* __restrict__ W2, float* __restrict__ dP, float* __restrict__ slab) {
+  extern __shared__ float sm[];
+  float* w1 = sm;                          // [H2][H]  (row-major: dP reads along k)
+  float* pl = w1 + H2 * H;                 // [RB][H]
+  float* dh = pl + (HTHR / H2) * H;        // [RB][H2]
+  float* hl = dh + (HTHR / H2) * H2;       // [RB][H2]
+  float* dl = hl + (HTHR / H2) * H2;       // [RB][C]
+  const int RB = HTHR / H2;
+  const int WD = H2 * H + H2 + C * H2 + C;
+  for (int i = threadIdx.x; i < H2 * H; i += HTHR) w1[i] = W1[i];
+  // parameter-gradient accumulators of this thread: elements threadIdx + HTHR*u of the slab row
+  constexpr int MAXE = (HEAD_MAX_H / 2 * HEAD_MAX_H + HEAD_MAX_H / 2 + HEAD_MAX_C * HEAD_MAX_H / 2 + HEAD_MAX_C + HTHR - 1) / HTHR;
+  float g[MAXE];
+#pragma unroll
+  for (int u = 0; u < MAXE; ++u) g[u] = 0.f;
+  const int j = threadIdx.x % H2, rr = threadIdx.x / H2;
+  for (int r0 = blockIdx.x * RB; r0 < B; r0 += gridDim.x * RB) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < RB * H; i += HTHR) {
+      const int r = r0 + i / H;
+      pl[i] = r < B ? P[(int64_t)r * H + i % H] : 0.f;
+    }
+    for (int i = threadIdx.x; i < RB * C; i += HTHR) {
+      const int r = r0 + i / C;
+      dl[i] = r < B ? dL[(int64_t)r * C + i % C] : 0.f;
+    }
+    __syncthreads();
+    if (rr < RB) {
+      const int r = r0 + rr;
+      float d = 0.f, hv = 0.f;
+      if (r < B) {
+        for (int c = 0; c < C; ++c) d = fmaf(dl[rr * C + c], W2[c * H2 + j], d);
+        d *= fac[(int64_t)r * H2 + j];
+        hv = H1[(int64_t)r * H2 + j];
+      }
+      dh[rr * H2 + j] = d;
+      hl[rr * H2 + j] = hv;
+    }
+    __syncthreads();
+    // dP[r][k] = sum_j dh[r][j] W1[j][k]
+    for (int t = threadIdx.x; t < RB * H; t += HTHR) {
+      const int rl = t / H, k = t % H, row = r0 + rl;
+      if (row < B) {
+        float acc = 0.f;
+        for (int jj = 0; jj < H2; ++jj) acc = fmaf(dh[rl * H2 + jj], w1[jj * H + k], acc);
+        dP[(int64_t)row * H + k] = acc;
+      }
+    }
+    // parameter gradients: this block's rows into the thread's accumulators
+#pragma unroll
+    for (int u = 0; u < MAXE; ++u) {
+      const int e = threadIdx.x + HTHR * u;
+      if (e < WD) {
+        float acc = 0.f;
+        if (e < H2 * H) {                                   // dW1[jj][k]
+          const int jj = e / H, k = e % H;
+          for (int rl = 0; rl < RB; ++rl) acc = fmaf(dh[rl * H2 + jj], pl[rl * H + k], acc);
+        } else if (e < H2 * H + H2) {                       // db1[jj]
+          const int jj = e - H2 * H;
+          for (int rl = 0; rl < RB; ++rl) acc += dh[rl * H2 + jj];
+        } else if (e < H2 * H + H2 + C * H2) {              // dW2[c][jj]
+          const int q = e - H2 * H - H2, c = q / H2, jj = q % H2;
+          for (int rl = 0; rl < RB; ++rl) acc = fmaf(dl[rl * C + c], hl[rl * H2 + jj], acc);
+        } else {                                            // db2[c]
+          const int c = e - H2 * H - H2 - C * H2;
+          for (int rl = 0; rl < RB; ++rl) acc += dl[rl * C + c];
+        }
+        g[u] += acc;
+      }
+    }
+  }
+  float* out = slab + (int64_t)blockIdx.x * WD;
+#pragma unroll
+  for (int u = 0; u < MAXE; ++u) {
+    const int e = threadIdx.x + HTHR * u;
+    if (e < WD) out[e] = g[u];
+  }
+}
+
+bool head_ok(int H, int H2, int C) {
+  return H >= 1 && H <= HEAD_MAX_H && H2 >= 1 && H2 <= HEAD_MAX_H / 2 && HTHR % H2 == 0 && C >= 1 &&
+         C <= HEAD_MAX_C;
+}
+
+int head_grid(int B, int H2) {
+  const int RB = HTHR / H2;
+  int g = (B + RB - 1) / RB;
+  const int cap = cgnn_fused_grid();
+  return g < 1 ? 1 : (g > cap ? cap : g);
+}
+
+}  // namespace
+
+extern "C" {
+
+int cgnn_head_supported(int32_t H, int32_t H2, int32_t C) { return head_ok(H, H2, C) ? 1 : 0; }
+int cgnn_head_grid(int32_t B, int32_t H2) { return (B < 0 || H2 <= 0 || HTHR % H2) ? CGNN_EINVAL : head_grid(B, H2); }
+
+int cgnn_head_fwd_f32(const float* P, int32_t B, int32_t H, int32_t H2, int32_t C, const float* W1,
+                      const float* b1, const float* W2, const float* b2, float p_drop,
+                      uint64_t seed, const uint32_t* seed_dev, float* H1, float* fac, float* logits,
+                      void* stream) {
+  if (B < 0 || p_drop < 0.f || p_drop >= 1.f) return CGNN_EINVAL;
+  if (!head_ok(H, H2, C)) return CGNN_EUNSUPPORTED;
+  if (B == 0) return CGNN_OK;
+  if (!P || !W1 || !b1 || !W2 || !b2 || !H1 || !fac || !logits) return CGNN_EINVAL;
+  HeadDrop d;
+  double thr = (double)p_drop * 65536.0 + 0.5;
+  if (thr > 65535.0) thr = 65535.0;
+  d.thr16 = (uint32_t)thr;
+  d.scale = p_drop > 0.f ? (float)(1.0 / (1.0 - (double)d.thr16 / 65536.0)) : 1.0f;
+  d.key0 = (uint32_t)(seed & 0xFFFFFFFFu) * 0x9E3779B9u + 0x7F4A7C15u;
+  d.key1 = (uint32_t)(seed >> 32) ^ 0x94D049BBu;
+  d.dev_key = seed_dev;
+  const int RB = HTHR / H2;
+  const size_t lds = sizeof(float) * ((size_t)H2 * (H + 1) + (size_t)RB * H + (size_t)RB * H2);
+  k_head_fwd<<<head_grid(B, H2), HTHR, lds, cgnn_stream(stream)>>>(
+      P, B, H, H2, C, W1, b1, W2, b2, d, p_drop > 0.f ? 1 : 0, H1, fac, logits);
+  CGNN_CHECK_LAUNCH();
+  return CGNN_OK;
+}
+
+int cgnn_head_bwd_f32(const float* dlogits, const float* P, const float* H1, const float* fac,
+                      int32_t B, int32_t H, int32_t H2, int32_t C, const float* W1, const float* W2,
+                      float* dP, float* slab, void* stream) {
+  if (B <= 0) return CGNN_EINVAL;
+  if (!head_ok(H, H2, C)) return CGNN_EUNSUPPORTED;
+  if (!dlogits || !P || !H1 || !fac || !W1 || !W2 || !dP || !slab) return CGNN_EINVAL;
+  const int RB = HTHR / H2;
+  const size_t lds = sizeof(float) * ((size_t)H2 * H + (size_t)RB * H + 2 * (size_t)RB * H2 + (size_t)RB * C);
+  k_head_bwd<<<head_grid(B, H2), HTHR, lds, cgnn_stream(stream)>>>(dlogits, P, H1, fac, B, H, H2, C, W1,
+                                                                 W2, dP, slab);
+  CGNN_CHECK_LAUNCH();
+  return CGNN_OK;
+}
+
+}  // extern "C"

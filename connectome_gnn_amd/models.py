@@ -167,7 +167,13 @@ class _ConnectomeModel(nn.Module):
 
     def forward(self, batch: ConnectomeBatch) -> torch.Tensor:
         """Class logits [B, num_classes]."""
-        return self.classifier(self.encode(batch))
+        pooled = self.encode(batch)
+        if ops.head_supported(self.classifier):
+            # Linear -> ReLU -> Dropout -> Linear on [B, hidden] in one HIP kernel each way
+            rng = getattr(self, "rng_device_state", None)
+            word = None if rng is None else rng.data_ptr() + 4 * len(self.convs)
+            return ops.head(self.classifier, pooled, self.training, word)
+        return self.classifier(pooled)
 
     def prepare_batch(self, batch: ConnectomeBatch) -> None:
         """Build every piece of static per-batch metadata this model will use (CSR, and the

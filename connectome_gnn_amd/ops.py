@@ -365,3 +365,68 @@ def bn_act_drop_supported(bn_mod, width: int) -> bool:
 def bn_act_drop(y, bn_mod, relu: bool, p: float, training: bool, rng_word=None) -> torch.Tensor:
     """rng_word: device address of a uint32 that a captured cgnn_rng_advance refreshes (graph replay)."""
     return _BnActDrop.apply(y, bn_mod.weight, bn_mod.bias, bn_mod, relu, p, training, rng_word)
+
+
+class _Head(torch.autograd.Function):
+    """logits = Linear2(dropout(relu(Linear1(P)))) in one HIP kernel each way (csrc/head.hip)."""
+
+    @staticmethod
+    def forward(ctx, p, w1, b1, w2, b2, p_drop, training, rng_word):
+        lib = _lib.load()
+        p, w1, b1, w2, b2 = (_prep(t, "head tensor") for t in (p, w1, b1, w2, b2))
+        bsz, h = p.shape
+        h2, c = w1.shape[0], w2.shape[0]
+        dev = p.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        p_eff = float(p_drop) if training else 0.0
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p_eff > 0 else 0
+        h1, fac = torch.empty(bsz, h2, **f32), torch.empty(bsz, h2, **f32)
+        logits = torch.empty(bsz, c, **f32)
+        with torch.cuda.device(dev):
+            _lib.check(lib.cgnn_head_fwd_f32(_lib.ptr(p), bsz, h, h2, c, _lib.ptr(w1), _lib.ptr(b1),
+                                             _lib.ptr(w2), _lib.ptr(b2), p_eff, seed,
+                                             rng_word if p_eff > 0 else None, _lib.ptr(h1), _lib.ptr(fac),
+                                             _lib.ptr(logits), _lib.stream_ptr()), "cgnn_head_fwd_f32")
+        ctx.save_for_backward(p, w1, w2, h1, fac)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dl):
+        lib = _lib.load()
+        p, w1, w2, h1, fac = ctx.saved_tensors
+        dl = _prep(dl, "grad")
+        bsz, h = p.shape
+        h2, c = w1.shape[0], w2.shape[0]
+        dev = p.device
+        wd = h2 * h + h2 + c * h2 + c
+        with torch.cuda.device(dev):
+            rows = int(lib.cgnn_head_grid(bsz, h2))
+            slab = torch.empty(rows, wd, dtype=torch.float32, device=dev)
+            dp = torch.empty_like(p)
+            flat = torch.empty(wd, dtype=torch.float32, device=dev)
+            _lib.check(lib.cgnn_head_bwd_f32(_lib.ptr(dl), _lib.ptr(p), _lib.ptr(h1), _lib.ptr(fac), bsz, h,
+                                             h2, c, _lib.ptr(w1), _lib.ptr(w2), _lib.ptr(dp), _lib.ptr(slab),
+                                             _lib.stream_ptr()), "cgnn_head_bwd_f32")
+            _lib.check(lib.cgnn_slab_reduce_f32(_lib.ptr(slab), rows, 1, wd, wd, _lib.ptr(flat), wd,
+                                                _lib.stream_ptr()), "cgnn_slab_reduce_f32")
+        o1, o2, o3 = h2 * h, h2 * h + h2, h2 * h + h2 + c * h2
+        return (dp, flat[:o1].view(h2, h), flat[o1:o2], flat[o2:o3].view(c, h2), flat[o3:],
+                None, None, None)
+
+
+def head_supported(classifier) -> bool:
+    """The reference's head layout: Sequential(Linear, ReLU, Dropout, Linear) at a covered width."""
+    import torch.nn as nn
+    if not (isinstance(classifier, nn.Sequential) and len(classifier) == 4):
+        return False
+    l1, act, drop, l2 = classifier
+    if not (type(l1) is nn.Linear and type(act) is nn.ReLU and type(drop) is nn.Dropout
+            and type(l2) is nn.Linear and l1.bias is not None and l2.bias is not None
+            and l2.in_features == l1.out_features):
+        return False
+    return bool(_lib.load().cgnn_head_supported(l1.in_features, l1.out_features, l2.out_features))
+
+
+def head(classifier, pooled, training: bool, rng_word=None) -> torch.Tensor:
+    l1, _, drop, l2 = classifier
+    return _Head.apply(pooled, l1.weight, l1.bias, l2.weight, l2.bias, drop.p, training, rng_word)

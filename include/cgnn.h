@@ -418,6 +418,26 @@ int cgnn_bn_act_bwd_apply(const float* dX, const float* Y, const uint8_t* mask, 
                           double* colsum_slab, float* dY, int64_t M, int32_t N, const float* dP,
                           const int32_t* node_graph, const int32_t* gptr, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Graph-level classifier head, models.py:196-201 + :213-216:
+ *   logits = Linear2(dropout(relu(Linear1(P)))),  P [B,H] (one row per graph), W1 [H2,H], W2 [C,H2].
+ * One kernel each way instead of six small library GEMM/elementwise launches.
+ * forward also writes H1 [B,H2] (the activations after ReLU and dropout) and fac [B,H2] (relu' *
+ * dropout' factor).  backward: dP [B,H] and a slab [cgnn_head_grid(B,H2)][WD] of per-workgroup
+ * partial parameter gradients, row layout dW1 [H2*H] | db1 [H2] | dW2 [C*H2] | db2 [C]
+ * (WD = their sum), combined with cgnn_slab_reduce_f32(slab, rows, 1, WD, WD, out, WD).
+ * cgnn_head_supported: H <= 128, H2 <= 64 and a divisor of 256, C <= 16.
+ * ------------------------------------------------------------------------------------- */
+int cgnn_head_supported(int32_t H, int32_t H2, int32_t C);
+int cgnn_head_grid(int32_t B, int32_t H2);
+int cgnn_head_fwd_f32(const float* P, int32_t B, int32_t H, int32_t H2, int32_t C, const float* W1,
+                      const float* b1, const float* W2, const float* b2, float p_drop,
+                      uint64_t seed, const uint32_t* seed_dev, float* H1, float* fac, float* logits,
+                      void* stream);
+int cgnn_head_bwd_f32(const float* dlogits, const float* P, const float* H1, const float* fac,
+                      int32_t B, int32_t H, int32_t H2, int32_t C, const float* W1, const float* W2,
+                      float* dP, float* slab, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
