@@ -142,7 +142,8 @@ def main() -> None:
         raise SystemExit("--graph is single-rank only")
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4, fused=True,
                            capturable=bool(args.graph))
-    loss_fn = torch.nn.CrossEntropyLoss()
+    from connectome_gnn_amd import ops as cops
+    loss_fn = cops.CrossEntropyLoss()        # the Trainer's criterion: CrossEntropyLoss defaults
     graphed = None
     if args.graph:
         from connectome_gnn_amd.graphed import GraphedTrainStep

@@ -704,16 +704,28 @@ __global__ void __launch_bounds__(PTHR) k_pool_fwd(const float* __restrict__ Y,
   for (int g = blockIdx.x; g < B; g += gridDim.x) {
     const int rbeg = gptr[g], rend = gptr[g + 1];
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int row = rbeg + rr; row < rend; row += 16) {
-      const float4 y = ld4(Y + (int64_t)row * HID + 4 * j);
-      uint32_t keep = 0xFu;
-      if (use_drop) {
-        keep = drop_bits(drop, (uint32_t)row, (uint32_t)j);
-        if (mask_out) mask_out[(int64_t)row * 16 + j] = (uint8_t)keep;
+    constexpr int U = 4;                       // rows in flight per thread (latency-bound otherwise)
+    for (int row0 = rbeg + rr; row0 < rend; row0 += 16 * U) {
+      float4 yb[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int row = row0 + 16 * u;
+        yb[u] = row < rend ? ld4(Y + (int64_t)row * HID + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      float4 f;
-      const float4 x = act4(y, a, b, keep, drop.scale, f);
-      s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int row = row0 + 16 * u;
+        if (row < rend) {
+          uint32_t keep = 0xFu;
+          if (use_drop) {
+            keep = drop_bits(drop, (uint32_t)row, (uint32_t)j);
+            if (mask_out) mask_out[(int64_t)row * 16 + j] = (uint8_t)keep;
+          }
+          float4 f;
+          const float4 x = act4(yb[u], a, b, keep, drop.scale, f);
+          s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
+        }
+      }
     }
     st4(red + rr * HID + 4 * j, s);
     __syncthreads();

@@ -165,6 +165,41 @@ __global__ void __launch_bounds__(HTHR) k_head_bwd(
   }
 }
 
+// ----------------------------------------------------------- mean cross-entropy over the batch
+// loss = mean_i ( logsumexp(logits[i,:]) - logits[i, label_i] )   (torch CrossEntropyLoss defaults,
+// reference train.py:39,49); also leaves dlogits for a unit upstream gradient:
+// (softmax(logits[i,:]) - onehot(label_i)) / B.  One workgroup; rows summed in fp64, fixed order.
+constexpr int CETHR = 1024;
+
+__global__ void __launch_bounds__(CETHR) k_ce_fwd(const float* __restrict__ logits,
+                                                  const int64_t* __restrict__ labels, int B, int C,
+                                                  float* __restrict__ loss,
+                                                  float* __restrict__ dlogits) {
+  __shared__ double red[CETHR];
+  double acc = 0.0;
+  const float invb = 1.0f / (float)B;
+  for (int i = threadIdx.x; i < B; i += CETHR) {
+    const float* row = logits + (int64_t)i * C;
+    float m = row[0];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, row[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(row[c] - m);
+    const float lse = m + logf(se);
+    const int lab = (int)labels[i];
+    const bool ok = lab >= 0 && lab < C;
+    acc += ok ? (double)(lse - row[lab]) : 0.0;
+    for (int c = 0; c < C; ++c)
+      dlogits[(int64_t)i * C + c] = (expf(row[c] - lse) - ((ok && c == lab) ? 1.f : 0.f)) * invb;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = CETHR / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = (float)(red[0] / (double)B);
+}
+
 bool head_ok(int H, int H2, int C) {
   return H >= 1 && H <= HEAD_MAX_H && H2 >= 1 && H2 <= HEAD_MAX_H / 2 && HTHR % H2 == 0 && C >= 1 &&
          C <= HEAD_MAX_C;
@@ -204,6 +239,14 @@ int cgnn_head_fwd_f32(const float* P, int32_t B, int32_t H, int32_t H2, int32_t 
   const size_t lds = sizeof(float) * ((size_t)H2 * (H + 1) + (size_t)RB * H + (size_t)RB * H2);
   k_head_fwd<<<head_grid(B, H2), HTHR, lds, cgnn_stream(stream)>>>(
       P, B, H, H2, C, W1, b1, W2, b2, d, p_drop > 0.f ? 1 : 0, H1, fac, logits);
+  CGNN_CHECK_LAUNCH();
+  return CGNN_OK;
+}
+
+int cgnn_cross_entropy_f32(const float* logits, const int64_t* labels, int32_t B, int32_t C,
+                           float* loss, float* dlogits, void* stream) {
+  if (B <= 0 || C <= 0 || !logits || !labels || !loss || !dlogits) return CGNN_EINVAL;
+  k_ce_fwd<<<1, CETHR, 0, cgnn_stream(stream)>>>(logits, labels, B, C, loss, dlogits);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }

@@ -430,3 +430,42 @@ def head_supported(classifier) -> bool:
 def head(classifier, pooled, training: bool, rng_word=None) -> torch.Tensor:
     l1, _, drop, l2 = classifier
     return _Head.apply(pooled, l1.weight, l1.bias, l2.weight, l2.bias, drop.p, training, rng_word)
+
+
+class _CrossEntropy(torch.autograd.Function):
+    """Mean cross-entropy and its gradient in one launch (csrc/head.hip, cgnn_cross_entropy_f32)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        lib = _lib.load()
+        logits = _prep(logits, "logits")
+        _require_device(labels, "labels")
+        if labels.dtype != torch.int64:
+            raise TypeError(f"labels must be int64, got {labels.dtype}")
+        bsz, c = logits.shape
+        loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+        dl = torch.empty_like(logits)
+        with torch.cuda.device(logits.device):
+            _lib.check(lib.cgnn_cross_entropy_f32(_lib.ptr(logits), _lib.ptr(labels.contiguous()), bsz, c,
+                                                  _lib.ptr(loss), _lib.ptr(dl), _lib.stream_ptr()),
+                       "cgnn_cross_entropy_f32")
+        ctx.save_for_backward(dl)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return dl * g, None
+
+
+def cross_entropy(logits, labels) -> torch.Tensor:
+    return _CrossEntropy.apply(logits, labels)
+
+
+class CrossEntropyLoss(torch.nn.Module):
+    """torch.nn.CrossEntropyLoss() (default arguments: mean reduction, no weights, no smoothing)
+    for [B, C] logits on the GPU, as one HIP launch; what the reference's Trainer uses
+    (train.py:39)."""
+
+    def forward(self, logits, labels):
+        return cross_entropy(logits, labels)

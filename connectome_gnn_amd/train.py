@@ -15,6 +15,8 @@ from typing import Callable, Optional
 import torch
 import torch.nn as nn
 
+from . import ops
+
 
 class Trainer:
     def __init__(self, model: nn.Module, optimizer: torch.optim.Optimizer, device: str = "cuda",
@@ -22,7 +24,7 @@ class Trainer:
         self.model = model.to(device)
         self.optimizer = optimizer
         self.device = device
-        self.loss_fn = nn.CrossEntropyLoss()
+        self.loss_fn = ops.CrossEntropyLoss()       # == nn.CrossEntropyLoss(), one HIP launch
         self.grad_sync = grad_sync
 
     def train_step(self, batch) -> torch.Tensor:

@@ -438,6 +438,12 @@ int cgnn_head_bwd_f32(const float* dlogits, const float* P, const float* H1, con
                       int32_t B, int32_t H, int32_t H2, int32_t C, const float* W1, const float* W2,
                       float* dP, float* slab, void* stream);
 
+/* Mean cross-entropy of the step (torch.nn.CrossEntropyLoss defaults; reference train.py:39,49):
+ * loss[0] = mean_i(logsumexp(logits[i,:]) - logits[i, labels[i]]); dlogits [B,C] = its gradient
+ * for a unit upstream gradient, (softmax - onehot) / B.  labels int64 [B]. */
+int cgnn_cross_entropy_f32(const float* logits, const int64_t* labels, int32_t B, int32_t C,
+                           float* loss, float* dlogits, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

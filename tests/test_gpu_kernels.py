@@ -373,3 +373,49 @@ def test_bn_act_drop_dropout_contract():
     out2 = ops.bn_act_drop(y, mod, False, 0.3, True)
     assert not torch.equal(out2 != 0, out != 0)                  # fresh mask per call
     assert torch.isfinite(y.grad).all()
+
+
+@pytest.mark.parametrize("b,c", [(4096, 2), (7, 5), (1, 2), (513, 16)])
+def test_cross_entropy_matches_torch(b, c):
+    from connectome_gnn_amd import ops
+    g = torch.Generator().manual_seed(b + c)
+    lg = (torch.randn(b, c, generator=g) * 3).requires_grad_(True)
+    lab = torch.randint(0, c, (b,), generator=g)
+    want = torch.nn.functional.cross_entropy(lg, lab)
+    (want * 1.7).backward()
+    lgd = lg.detach().to(DEV).requires_grad_(True)
+    got = ops.CrossEntropyLoss()(lgd, lab.to(DEV))
+    (got * 1.7).backward()
+    torch.testing.assert_close(got.cpu(), want.detach(), rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(lgd.grad.cpu(), lg.grad, rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("h,c,p", [(64, 2, 0.0), (128, 3, 0.0), (32, 2, 0.0), (64, 2, 0.4)])
+def test_fused_head_matches_torch(h, c, p):
+    """cgnn_head_fwd/bwd against the torch modules of the reference's classifier (models.py:196-201)."""
+    import torch.nn as nn
+    from connectome_gnn_amd import ops
+    torch.manual_seed(h + c)
+    head = nn.Sequential(nn.Linear(h, h // 2), nn.ReLU(), nn.Dropout(p), nn.Linear(h // 2, c))
+    x = torch.randn(777, h)
+    cot = torch.randn(777, c)
+    assert ops.head_supported(head)
+    hd = nn.Sequential(nn.Linear(h, h // 2), nn.ReLU(), nn.Dropout(p), nn.Linear(h // 2, c)).to(DEV)
+    hd.load_state_dict(head.state_dict())
+    xd = x.to(DEV).requires_grad_(True)
+    out = ops.head(hd, xd, training=True)
+    (out * cot.to(DEV)).sum().backward()
+    if p == 0.0:
+        xc = x.clone().requires_grad_(True)
+        ref = head.train()(xc)
+        (ref * cot).sum().backward()
+        torch.testing.assert_close(out.cpu(), ref, **TOL)
+        torch.testing.assert_close(xd.grad.cpu(), xc.grad, rtol=1e-5, atol=1e-6)
+        for (k, a), (_, b_) in zip(hd.named_parameters(), head.named_parameters()):
+            torch.testing.assert_close(a.grad.cpu(), b_.grad, rtol=1e-5, atol=1e-5 * float(b_.grad.abs().max()) + 1e-7,
+                                       msg=lambda s_: f"{k}: {s_}")
+    else:
+        # dropout contract: eval == no dropout; train output finite, a fraction ~p of hidden units dropped
+        assert torch.isfinite(out).all() and torch.isfinite(xd.grad).all()
+        ev = ops.head(hd, xd.detach(), training=False)
+        torch.testing.assert_close(ev.cpu(), head.eval()(x), **TOL)
