@@ -99,20 +99,37 @@ __global__ void __launch_bounds__(L0THR, 5) k_l0_fwd(cgnn_tiles t, const float* 
     }
     __syncthreads();
     // 3. Y0 = P0 W0^T + b: thread (row rr + 16*it, columns 4j..4j+3)
-    for (int r = rr; r < n; r += L0THR / 16) {
+    // (two rows per pass share every W0^T read: this phase is LDS-bound)
+    constexpr int RS = L0THR / 16;                   // 24 row lanes
+    for (int r = rr; r < n; r += 2 * RS) {
+      const int r2 = r + RS;
+      const bool two = r2 < n;
       const float4 p0 = ld4(ps + r * FP), p1 = ld4(ps + r * FP + 4);
+      const float4 q0 = two ? ld4(ps + r2 * FP) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 q1 = two ? ld4(ps + r2 * FP + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
       const float pv[FP] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
-      float4 y = b4;
+      const float qv[FP] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+      float4 y = b4, z = b4;
 #pragma unroll
       for (int k = 0; k < FP; ++k) {
-        const float4 wk = ld4(wl + k * HID + 4 * j);
-        y.x = fmaf(pv[k], wk.x, y.x); y.y = fmaf(pv[k], wk.y, y.y);
-        y.z = fmaf(pv[k], wk.z, y.z); y.w = fmaf(pv[k], wk.w, y.w);
+        if (k < F0) {                                 // wave-uniform: columns >= F0 are zero
+          const float4 wk = ld4(wl + k * HID + 4 * j);
+          y.x = fmaf(pv[k], wk.x, y.x); y.y = fmaf(pv[k], wk.y, y.y);
+          y.z = fmaf(pv[k], wk.z, y.z); y.w = fmaf(pv[k], wk.w, y.w);
+          z.x = fmaf(qv[k], wk.x, z.x); z.y = fmaf(qv[k], wk.y, z.y);
+          z.z = fmaf(qv[k], wk.z, z.z); z.w = fmaf(qv[k], wk.w, z.w);
+        }
       }
       st4(Y + (int64_t)(base + r) * HID + 4 * j, y);
       s1[0] += y.x; s1[1] += y.y; s1[2] += y.z; s1[3] += y.w;
       s2[0] = fmaf(y.x, y.x, s2[0]); s2[1] = fmaf(y.y, y.y, s2[1]);
       s2[2] = fmaf(y.z, y.z, s2[2]); s2[3] = fmaf(y.w, y.w, s2[3]);
+      if (two) {
+        st4(Y + (int64_t)(base + r2) * HID + 4 * j, z);
+        s1[0] += z.x; s1[1] += z.y; s1[2] += z.z; s1[3] += z.w;
+        s2[0] = fmaf(z.x, z.x, s2[0]); s2[1] = fmaf(z.y, z.y, s2[1]);
+        s2[2] = fmaf(z.z, z.z, s2[2]); s2[3] = fmaf(z.w, z.w, s2[3]);
+      }
     }
     __syncthreads();
   }
