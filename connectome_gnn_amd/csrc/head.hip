@@ -208,7 +208,8 @@ bool head_ok(int H, int H2, int C) {
 int head_grid(int B, int H2) {
   const int RB = HTHR / H2;
   int g = (B + RB - 1) / RB;
-  const int cap = cgnn_fused_grid();
+  const int cap = 4 * cgnn_fused_grid();   // several short workgroups per CU: the kernels are chains
+                                           // of dependent loads, overlap comes from co-residency
   return g < 1 ? 1 : (g > cap ? cap : g);
 }
 

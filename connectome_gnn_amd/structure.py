@@ -214,6 +214,8 @@ class BatchStructure:
                                               _lib.ptr(rowptr), _lib.ptr(blk_off), _lib.ptr(scratch),
                                               _lib.stream_ptr()), "cgnn_bell_plan")
                 total = int(blk_off[-1])                 # sync: sizes the entry array
+                if total < 0 or total > 2 ** 31 - 17:
+                    raise ValueError("blocked-ELL of this batch exceeds 2^31 entries; use smaller batches")
                 ent = torch.empty(max(total, 1) * 8, dtype=torch.uint8, device=dev)
                 _lib.check(lib.cgnn_bell_fill(_lib.ptr(tptr), _lib.ptr(tile_blk), nt,
                                               _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(eid),
