@@ -77,8 +77,17 @@ def cpu_baseline(model: str, n: int, k: int, hidden: int, budget_s: float = 20.0
             break
     times.sort()
     med = times[len(times) // 2]
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     return {"value": sample / med, "unit": "graphs/s", "cores": torch.get_num_threads(),
-            "kind": "port",
+            "kind": "port", "cpu_model": cpu_model,
             "sample": f"oracle train step (dropout 0.3, Adam), batch {sample}x{n}-ROI, "
                       f"median of {len(times)} steps after 3 warm-up, collate excluded"}
 

@@ -382,17 +382,20 @@ def test_sage_edge_cases_empty_graphs_and_fallbacks():
         C.GraphSAGEConnectome(5, 32, impl="fused").to(DEV)(C.collate_graphs([g_ok]).to(DEV))
 
 
-def test_graphed_step_matches_eager_and_redraws_dropout():
+@pytest.mark.parametrize("kind", ["gcn", "sage"])
+def test_graphed_step_matches_eager_and_redraws_dropout(kind):
     """HIP-graph replay of the whole step == eager steps (dropout 0), and with dropout > 0 every
-    replay draws a fresh mask (the by-value seed is frozen in the graph; the device key is not)."""
+    replay draws a fresh mask (the by-value seed is frozen in the graph; the device key is not).
+    Both encoders (fused GCN, one-node GraphSAGE), the head kernel and the loss are inside the graph."""
     import connectome_gnn_amd as C
     from connectome_gnn_amd.graphed import GraphedTrainStep
     b = C.collate_graphs(C.generate_dataset(32, 84, 8, seed=6)).to(DEV)
     b.structure()
+    cls = C.GCNConnectome if kind == "gcn" else C.GraphSAGEConnectome
 
     def run(graph: bool, steps=4):
         torch.manual_seed(11)
-        m = C.GCNConnectome(5, 64, dropout=0.0).to(DEV).train()
+        m = cls(5, 64, dropout=0.0).to(DEV).train()
         opt = torch.optim.Adam(m.parameters(), lr=1e-2, capturable=True)
 
         def eager():
@@ -417,7 +420,7 @@ def test_graphed_step_matches_eager_and_redraws_dropout():
             torch.testing.assert_close(p, q, rtol=1e-4, atol=1e-5, msg=lambda s: f"{k}: {s}")
     # dropout: replays must differ from each other
     torch.manual_seed(1)
-    m = C.GCNConnectome(5, 64, dropout=0.5).to(DEV).train()
+    m = cls(5, 64, dropout=0.5).to(DEV).train()
     opt = torch.optim.SGD(m.parameters(), lr=0.0)               # frozen weights: only masks change
     st = GraphedTrainStep(m, opt, b, warmup=1)
     vals = {round(float(st()), 7) for _ in range(5)}
