@@ -210,15 +210,20 @@ class GCNConnectome(_ConnectomeModel):
 
     def _try_fused(self, batch, structure) -> bool:
         """Fused per-tile kernels (fused.py) when the shape is covered: hidden 64, <= 16 input
-        features, graphs of <= 384 nodes, block-diagonal edges."""
+        features, graphs of <= 384 nodes, block-diagonal edges; else the one-node wide encoder
+        (gcn_wide_path.py) for hidden 64/128/256 on such graphs; else the op-by-op path."""
         if self.impl == "layered":
             return False
-        from . import fused
-        return self._decide(fused.eligible(self, batch, structure))
+        from . import fused, gcn_wide_path
+        why = fused.eligible(self, batch, structure)
+        self._fused_kind = "tile"
+        if why is not None and gcn_wide_path.eligible(self, batch, structure) is None:
+            self._fused_kind, why = "wide", None
+        return self._decide(why)
 
     def _fused_encode(self, batch, structure):
-        from . import fused
-        return fused.encode(self, batch, structure)
+        from . import fused, gcn_wide_path
+        return (fused if self._fused_kind == "tile" else gcn_wide_path).encode(self, batch, structure)
 
 
 class GraphSAGEConnectome(_ConnectomeModel):

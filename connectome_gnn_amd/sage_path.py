@@ -64,8 +64,8 @@ def _agg_fwd(s: BatchStructure, ell, norm, x):
     return ops.aggregate_raw(s.rowptr_dst, s.col_dst, norm.w_dst, None, norm.den, None, x)
 
 
-def _linear_fwd_stats(lib, x1, x2, w, b, grid):
-    """relu([x1 | x2] W^T + b) and the per-workgroup (sum | sum of squares) slab of the result, or
+def _linear_fwd_stats(lib, x1, x2, w, b, grid, relu: bool = True):
+    """act([x1 | x2] W^T + b) and the per-workgroup (sum | sum of squares) slab of the result, or
     (None, None) when the shape is outside the weight-stationary kernel."""
     m, k1 = x1.shape
     k2 = 0 if x2 is None else x2.shape[1]
@@ -74,7 +74,8 @@ def _linear_fwd_stats(lib, x1, x2, w, b, grid):
     slab = torch.empty(grid, 2 * n, dtype=torch.float64, device=x1.device)
     rc = lib.cgnn_linear_fwd_stats_f32(
         _lib.ptr(x1), x1.stride(0), k1, _lib.ptr(x2), 0 if x2 is None else x2.stride(0), k2,
-        _lib.ptr(w), _lib.ptr(b), 1, _lib.ptr(y), y.stride(0), m, n, _lib.ptr(slab), _lib.stream_ptr())
+        _lib.ptr(w), _lib.ptr(b), int(relu), _lib.ptr(y), y.stride(0), m, n, _lib.ptr(slab),
+        _lib.stream_ptr())
     if rc == _lib.CGNN_EUNSUPPORTED:
         return None, None
     _lib.check(rc, "cgnn_linear_fwd_stats_f32")

@@ -463,3 +463,32 @@ def test_sage_one_node_encoder_matches_layered_and_is_deterministic():
     with torch.no_grad():
         e = m.encode(b)
     assert m.impl_used == "fused" and e.shape == (9, 64) and torch.isfinite(e).all()
+
+
+def test_gcn_wide_encoder_matches_layered():
+    """GCN hidden 128: the one-node wide encoder (gcn_wide_path.py) against the op-by-op path on the
+    same weights (dropout 0); hidden 64 with 20 input features (> the per-tile kernels' 16) takes
+    the wide encoder too."""
+    import connectome_gnn_amd as C
+    b = C.collate_graphs(C.generate_dataset(6, 84, 8, seed=5) + C.generate_dataset(3, 200, 10, seed=6)).to(DEV)
+    outs = {}
+    for impl in ("fused", "layered"):
+        torch.manual_seed(11)
+        m = C.GCNConnectome(5, 128, dropout=0.0, impl=impl).to(DEV).train()
+        lg = m(b)
+        torch.nn.functional.cross_entropy(lg, b.labels).backward()
+        assert m.impl_used == impl and (impl == "layered" or m._fused_kind == "wide")
+        outs[impl] = (lg.detach(), {k: p.grad.clone() for k, p in m.named_parameters()},
+                      {k: v.clone() for k, v in m.state_dict().items() if "running" in k})
+    torch.testing.assert_close(outs["fused"][0], outs["layered"][0], **TOL)
+    for k, g in outs["layered"][1].items():
+        torch.testing.assert_close(outs["fused"][1][k], g, rtol=1e-4, atol=1e-5 * float(g.abs().max()) + 1e-7,
+                                   msg=lambda s_: f"{k}: {s_}")
+    for k, v in outs["layered"][2].items():
+        torch.testing.assert_close(outs["fused"][2][k], v, **TOL)
+    wide_in = C.ConnectomeBatch(torch.randn(b.num_nodes, 20, device=DEV), b.edge_index, b.edge_weight,
+                                b.batch, b.labels, b.ptr)
+    m = C.GCNConnectome(20, 64, dropout=0.2).to(DEV).train()
+    m(wide_in).sum().backward()
+    assert m.impl_used == "fused" and m._fused_kind == "wide"
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters())
