@@ -316,6 +316,17 @@ int cgnn_linear_fwd_f32(const float* X1, int64_t ldx1, int32_t K1, const float* 
     CGNN_CHECK_LAUNCH();
     return CGNN_OK;
   }
+  if (N == 256 && M >= 4096 && (int64_t)128 * (K1 + K2) <= 32768) {
+    // two 128-column halves, each with its weight panel parked in LDS (gemm_ws.hip)
+    const int K = K1 + K2;
+    if (cgnn_ws_linear_fwd(X1, ldx1, K1, X2, ldx2, K2, W, bias, relu, Y, ldy, M, 128, nullptr,
+                           cgnn_stream(stream)) &&
+        cgnn_ws_linear_fwd(X1, ldx1, K1, X2, ldx2, K2, W + (int64_t)128 * K, bias ? bias + 128 : nullptr,
+                           relu, Y + 128, ldy, M, 128, nullptr, cgnn_stream(stream))) {
+      CGNN_CHECK_LAUNCH();
+      return CGNN_OK;
+    }
+  }
   dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
   k_linear_fwd<<<grid, 256, 0, cgnn_stream(stream)>>>(X1, ldx1, K1, X2, ldx2, K2, W, bias, relu, Y,
                                                       ldy, M, N);
@@ -348,6 +359,15 @@ int cgnn_linear_bwd_input_f32(const float* dY, int64_t lddy, const float* W, int
     CGNN_CHECK_LAUNCH();
     return CGNN_OK;
   }
+  if (K == 256 && M >= 4096 && (int64_t)N * 128 <= 32768) {
+    // two halves of 128 output columns, each with its [N x 128] weight panel in LDS
+    if (cgnn_ws_linear_bwd_input(dY, lddy, W, ldw, k0, dX, lddx, M, N, 128, cgnn_stream(stream)) &&
+        cgnn_ws_linear_bwd_input(dY, lddy, W, ldw, k0 + 128, dX + 128, lddx, M, N, 128,
+                                 cgnn_stream(stream))) {
+      CGNN_CHECK_LAUNCH();
+      return CGNN_OK;
+    }
+  }
   dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((K + BN - 1) / BN));
   k_linear_bwd_input<<<grid, 256, 0, cgnn_stream(stream)>>>(dY, lddy, W, ldw, k0, dX, lddx, M, N, K);
   CGNN_CHECK_LAUNCH();
@@ -358,7 +378,8 @@ int64_t cgnn_linear_bwd_weight_workspace_bytes(int64_t M, int32_t N, int32_t K) 
   if (M < 0 || N <= 0 || K <= 0) return CGNN_EINVAL;
   int64_t nchunks = (M + WCHUNK - 1) / WCHUNK;
   if (nchunks == 0) nchunks = 1;
-  const int64_t ws = cgnn_ws_bwd_weight_partials(M, N, K);
+  int64_t ws = cgnn_ws_bwd_weight_partials(M, N, K);
+  if (N == 256) ws = (cgnn_ws_bwd_weight_partials(M, 128, K) + 1) / 2;   // halves run one at a time
   if (ws > nchunks) nchunks = ws;
   return cgnn_align_up(nchunks * (int64_t)N * K * (int64_t)sizeof(float), 256);
 }
@@ -371,6 +392,13 @@ int cgnn_linear_bwd_weight_f32(const float* dY, int64_t lddy, const float* X, in
   if (!dW || !slab) return CGNN_EINVAL;
   if (M > 0 && (!dY || !X)) return CGNN_EINVAL;
   hipStream_t st = cgnn_stream(stream);
+  if (N == 256 && cgnn_ws_bwd_weight_partials(M, 128, K) > 0 && lddy % 4 == 0) {
+    // two halves of 128 output rows of dW through the weight-stationary kernel
+    const int rc = cgnn_linear_bwd_weight_f32(dY, lddy, X, ldx, dW, ldw, k0, M, 128, K, slab, stream);
+    if (rc != CGNN_OK) return rc;
+    return cgnn_linear_bwd_weight_f32(dY + 128, lddy, X, ldx, dW + (int64_t)128 * ldw, ldw, k0, M, 128, K,
+                                      slab, stream);
+  }
   int64_t nchunks = (M + WCHUNK - 1) / WCHUNK;
   const int tiles_n = (N + 63) / 64, tiles_k = (K + 63) / 64;
   if (cgnn_ws_linear_bwd_weight(dY, lddy, X, ldx, K, nullptr, 0, 0, static_cast<float*>(slab), M, N, st)) {
