@@ -419,3 +419,30 @@ def test_fused_head_matches_torch(h, c, p):
         assert torch.isfinite(out).all() and torch.isfinite(xd.grad).all()
         ev = ops.head(hd, xd.detach(), training=False)
         torch.testing.assert_close(ev.cpu(), head.eval()(x), **TOL)
+
+
+def test_config5_scatter_full_size_properties():
+    """BASELINE config 5's scatter at full size (64 x 1000-ROI, ~100 neighbours/node, hidden 256,
+    fp16 storage): the dense matrix-core form, the per-edge LDS form and the fp32 gather kernel
+    agree to fp16 resolution, and the operator is linear (A(ax + y) == a A(x) + A(y))."""
+    from connectome_gnn_amd import _lib, ops
+    from connectome_gnn_amd.resident import assemble_batch
+    from connectome_gnn_amd.synthetic import generate_packed
+    ds = generate_packed(64, 1000, 100, seed=42).to(DEV)
+    b = assemble_batch(ds, torch.arange(64))
+    s = b.structure()
+    n = s.gcn_norm()
+    grid = _lib.load().cgnn_fused_grid()
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(s.num_nodes, 256, device=DEV, generator=g)
+    y = torch.randn(s.num_nodes, 256, device=DEV, generator=g)
+    m = ops.dense_adj_f16(s, n.coef_dst, n.selfc)
+    dense = ops.dense_aggregate_f16_raw(s, m, x.half()).float()
+    tiled = ops.aggregate_tiled_f16_raw(s, s.fused_meta(1024, grid, 1.0), 0, x.half(), n.dis, n.dis, None).float()
+    exact = ops.aggregate_raw(s.rowptr_dst, s.col_dst, n.coef_dst, n.selfc, None, None, x.half().float())
+    scale = float(exact.abs().max())
+    torch.testing.assert_close(dense, exact, rtol=3e-3, atol=3e-3 * scale)
+    torch.testing.assert_close(tiled, exact, rtol=3e-3, atol=3e-3 * scale)
+    lin = ops.dense_aggregate_f16_raw(s, m, (0.5 * x + y).half()).float()
+    want = 0.5 * dense + ops.dense_aggregate_f16_raw(s, m, y.half()).float()
+    torch.testing.assert_close(lin, want, rtol=5e-3, atol=5e-3 * scale)

@@ -492,3 +492,30 @@ def test_gcn_wide_encoder_matches_layered():
     m(wide_in).sum().backward()
     assert m.impl_used == "fused" and m._fused_kind == "wide"
     assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+def test_sage_config3_full_size_properties():
+    """BASELINE config 3 at full size (512 x 360-ROI GraphSAGE, hidden 128) on the one-node
+    encoder: finite, and permuting the graphs of the batch permutes the embeddings (block-diagonal
+    independence) while the batch-wide BatchNorm statistics stay put; backward is finite and
+    deterministic run to run."""
+    import connectome_gnn_amd as C
+    from connectome_gnn_amd.resident import assemble_batch
+    from connectome_gnn_amd.synthetic import generate_packed
+    ds = generate_packed(512, 360, 14, seed=2).to(DEV)
+    ids = torch.arange(512)
+    perm = torch.randperm(512, generator=torch.Generator().manual_seed(0))
+    outs = []
+    for order in (ids, ids[perm], ids):
+        torch.manual_seed(1)
+        m = C.GraphSAGEConnectome(5, 128, dropout=0.0).to(DEV).train()
+        e = m.encode(assemble_batch(ds, order))
+        assert m.impl_used == "fused" and torch.isfinite(e).all()
+        e.square().sum().backward()
+        outs.append((e.detach(), m.batch_norms[2].running_mean.clone(),
+                     [p.grad.clone() for p in m.parameters() if p.grad is not None]))
+    torch.testing.assert_close(outs[1][0], outs[0][0][perm.to(DEV)], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(outs[1][1], outs[0][1], rtol=1e-4, atol=1e-6)
+    assert torch.equal(outs[2][0], outs[0][0])
+    assert all(torch.equal(a, c) for a, c in zip(outs[2][2], outs[0][2]))
+    assert all(torch.isfinite(g).all() for g in outs[0][2])
