@@ -191,6 +191,7 @@ int cgnn_dense_adj_f16(const int32_t* rowptr, const int32_t* col, const float* c
                        void* M, void* stream) {
   if (num_graphs < 0 || P <= 0 || P > D_MAXP || P % 64) return P > D_MAXP ? CGNN_EUNSUPPORTED : CGNN_EINVAL;
   if (num_graphs == 0) return CGNN_OK;
+  if (num_graphs > 65535) return CGNN_EUNSUPPORTED;          // grid.y of the builder
   if (!rowptr || !col || !coef || !gptr || !M) return CGNN_EINVAL;
   k_dense_adj<<<dim3((unsigned)P, (unsigned)num_graphs), 256, 0, cgnn_stream(stream)>>>(
       rowptr, col, coef, selfc, gptr, P, static_cast<__half*>(M));
