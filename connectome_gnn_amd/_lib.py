@@ -142,10 +142,32 @@ def ptr(t) -> int:
     return 0 if t is None else t.data_ptr()
 
 
-def stream_ptr() -> int:
-    """The HIP stream torch is currently enqueuing on (kernels join torch's ordering)."""
+class _NullCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL = _NullCtx()
+
+
+def device_guard(device):
+    """``with device_guard(dev):`` == ``with torch.cuda.device(dev):`` but free when `dev` already
+    is the current device (the context manager costs ~10 us per use on the launch path)."""
     import torch
-    return torch.cuda.current_stream().cuda_stream
+    idx = device.index if getattr(device, "index", None) is not None else torch.cuda.current_device()
+    if torch.cuda.current_device() == idx:
+        return _NULL
+    return torch.cuda.device(idx)
+
+
+def stream_ptr(device=None) -> int:
+    """The HIP stream torch is currently enqueuing on for `device` (default: the current device);
+    kernels join torch's ordering."""
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 # ---------------------------------------------------------------------------------------------

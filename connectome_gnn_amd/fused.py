@@ -92,13 +92,14 @@ class FusedGCNEncode(torch.autograd.Function):
         count_dev = None                           # device copy of the global row count (sync-BN)
         narrow0 = L >= 2 and x0.shape[1] <= 8      # layer-0 narrow form (fused_gcn_l0.hip)
         p0 = None
-        st = _lib.stream_ptr
+        _sp = _lib.stream_ptr(dev)          # one lookup per pass (torch.cuda.current_stream is ~10 us)
+        st = lambda: _sp
         rng = meta.get("rng_state")       # device uint32 words: set when the step is graph-captured
 
         def rng_ptr(i: int):
             return None if rng is None or p <= 0 else rng.data_ptr() + 4 * i
 
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             if rng is not None and p > 0:
                 _lib.check(lib.cgnn_rng_advance(_lib.ptr(rng), L + 1, st()), "cgnn_rng_advance")
             for l in range(L):
@@ -184,7 +185,8 @@ class FusedGCNEncode(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         f64 = dict(dtype=torch.float64, device=dev)
         tp = ctypes.byref(c.tiles)
-        st = _lib.stream_ptr
+        _sp = _lib.stream_ptr(dev)          # one lookup per pass (torch.cuda.current_stream is ~10 us)
+        st = lambda: _sp
         d_pooled = d_pooled.contiguous()
         s_slab = torch.empty(grid, 128, **f64)
         sums = torch.empty(128, **f64)
@@ -220,7 +222,7 @@ class FusedGCNEncode(torch.autograd.Function):
         # only supplies the BatchNorm-backward sums (dZ = NULL)
         pool_args = (_lib.ptr(d_pooled), _lib.ptr(s.node_graph), _lib.ptr(s.gptr), _lib.ptr(c.masks[-1]))
         none_args = (None, None, None, None)
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             _lib.check(lib.cgnn_gcn_fused_pool_bwd(
                 _lib.ptr(d_pooled), _lib.ptr(c.ys[-1]), _lib.ptr(c.bns[-1]), c.p,
                 _lib.ptr(c.masks[-1]), _lib.ptr(s.gptr), B, None, _lib.ptr(s_slab), st()),

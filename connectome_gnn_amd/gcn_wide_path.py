@@ -63,7 +63,8 @@ class GcnWideEncode(torch.autograd.Function):
         rng = cfg.get("rng_state")
         L = len(params) // 4
         dev = x0.device
-        st = _lib.stream_ptr
+        _sp = _lib.stream_ptr(dev)          # one lookup per pass (torch.cuda.current_stream is ~10 us)
+        st = lambda: _sp
         x = x0.contiguous()
         n_nodes = s.num_nodes
         grid = int(lib.cgnn_fused_grid())
@@ -74,7 +75,7 @@ class GcnWideEncode(torch.autograd.Function):
         sv.xs, sv.ys, sv.coefs, sv.masks, sv.ws = [], [], [], [], []
         sv.p0, sv.padded = None, False
         nrm = sv.norm
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             if rng is not None and p > 0:
                 _lib.check(lib.cgnn_rng_advance(_lib.ptr(rng), L + 1, st()), "cgnn_rng_advance")
             rows = int(lib.cgnn_bn_act_slab_rows(n_nodes))
@@ -141,12 +142,13 @@ class GcnWideEncode(torch.autograd.Function):
         sv: _Saved = ctx.sv
         s, L = sv.s, ctx.L
         dev = dP.device
-        st = _lib.stream_ptr
+        _sp = _lib.stream_ptr(dev)          # one lookup per pass (torch.cuda.current_stream is ~10 us)
+        st = lambda: _sp
         n_nodes = s.num_nodes
         dP = dP.contiguous()
         nrm = sv.norm
         grads: List[Optional[torch.Tensor]] = [None] * (4 * L)
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             dx = None                      # last layer: gradient rebuilt from dP inside the kernels
             rows = int(lib.cgnn_bn_act_slab_rows(n_nodes))
             for li in range(L - 1, -1, -1):

@@ -35,7 +35,7 @@ def aggregate_raw(rowptr, col, coef, selfc, rowdiv, bias, x, out=None) -> torch.
     lib = _lib.load()
     n, f = x.shape
     y = torch.empty_like(x) if out is None else out
-    with torch.cuda.device(x.device), _lib.timed("cgnn_aggregate_f32", f"F={f}"):
+    with _lib.device_guard(x.device), _lib.timed("cgnn_aggregate_f32", f"F={f}"):
         _lib.check(lib.cgnn_aggregate_f32(
             _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(coef), _lib.ptr(selfc), _lib.ptr(rowdiv),
             _lib.ptr(bias), _lib.ptr(x), x.stride(0), _lib.ptr(y), y.stride(0), n, f,
@@ -48,7 +48,7 @@ def colsum_raw(a: torch.Tensor) -> torch.Tensor:
     m, n = a.shape
     out = torch.empty(n, dtype=torch.float32, device=a.device)
     slab = _scratch(lib.cgnn_colsum_workspace_bytes(m, n), a.device)
-    with torch.cuda.device(a.device):
+    with _lib.device_guard(a.device):
         _lib.check(lib.cgnn_colsum_f32(_lib.ptr(a), a.stride(0), _lib.ptr(out), m, n,
                                        _lib.ptr(slab), _lib.stream_ptr()), "cgnn_colsum_f32")
     return out
@@ -62,7 +62,7 @@ def linear_fwd_raw(x1, x2, w, bias, relu: bool) -> torch.Tensor:
     if w.shape[1] != k1 + k2:
         raise ValueError(f"weight is {tuple(w.shape)}, inputs give K = {k1}+{k2}")
     y = torch.empty(m, n, dtype=torch.float32, device=x1.device)
-    with torch.cuda.device(x1.device):
+    with _lib.device_guard(x1.device):
         _lib.check(lib.cgnn_linear_fwd_f32(
             _lib.ptr(x1), x1.stride(0), k1, _lib.ptr(x2), 0 if x2 is None else x2.stride(0), k2,
             _lib.ptr(w), _lib.ptr(bias), int(relu), _lib.ptr(y), y.stride(0), m, n,
@@ -74,7 +74,7 @@ def linear_bwd_input_raw(dy, w, k0: int, k: int) -> torch.Tensor:
     lib = _lib.load()
     m, n = dy.shape
     dx = torch.empty(m, k, dtype=torch.float32, device=dy.device)
-    with torch.cuda.device(dy.device):
+    with _lib.device_guard(dy.device):
         _lib.check(lib.cgnn_linear_bwd_input_f32(
             _lib.ptr(dy), dy.stride(0), _lib.ptr(w), w.stride(0), k0, _lib.ptr(dx), dx.stride(0),
             m, n, k, _lib.stream_ptr()), "cgnn_linear_bwd_input_f32")
@@ -86,7 +86,7 @@ def linear_bwd_weight_raw(dy, x, dw, k0: int) -> None:
     m, n = dy.shape
     k = x.shape[1]
     slab = _scratch(lib.cgnn_linear_bwd_weight_workspace_bytes(m, n, k), dy.device)
-    with torch.cuda.device(dy.device):
+    with _lib.device_guard(dy.device):
         _lib.check(lib.cgnn_linear_bwd_weight_f32(
             _lib.ptr(dy), dy.stride(0), _lib.ptr(x), x.stride(0), _lib.ptr(dw), dw.stride(0), k0,
             m, n, k, _lib.ptr(slab), _lib.stream_ptr()), "cgnn_linear_bwd_weight_f32")
@@ -129,7 +129,7 @@ def aggregate_tiled_raw(structure, meta, flags: int, x, pre, post, bias, yadd=No
     n, f = x.shape
     y = torch.empty(n, f, dtype=torch.float32, device=x.device)
     tiles = structure.tiles_struct(meta)
-    with torch.cuda.device(x.device), _lib.timed("cgnn_aggregate_tiled_f32", f"F={f}"):
+    with _lib.device_guard(x.device), _lib.timed("cgnn_aggregate_tiled_f32", f"F={f}"):
         _lib.check(lib.cgnn_aggregate_tiled_f32(
             ctypes.byref(tiles), int(flags), _lib.ptr(x), x.stride(0), f, _lib.ptr(pre), _lib.ptr(post),
             _lib.ptr(bias), _lib.ptr(yadd), 0 if yadd is None else yadd.stride(0), _lib.ptr(y),
@@ -146,7 +146,7 @@ def aggregate_tiled_f16_raw(structure, meta, flags: int, x, pre, post, bias) -> 
     n, f = x.shape
     y = torch.empty(n, f, dtype=torch.float16, device=x.device)
     tiles = structure.tiles_struct(meta)
-    with torch.cuda.device(x.device), _lib.timed("cgnn_aggregate_tiled_f16", f"F={f}"):
+    with _lib.device_guard(x.device), _lib.timed("cgnn_aggregate_tiled_f16", f"F={f}"):
         _lib.check(lib.cgnn_aggregate_tiled_f16(
             ctypes.byref(tiles), int(flags), _lib.ptr(x), x.stride(0), f, _lib.ptr(pre), _lib.ptr(post),
             _lib.ptr(bias), _lib.ptr(y), y.stride(0), _lib.stream_ptr()), "cgnn_aggregate_tiled_f16")
@@ -160,7 +160,7 @@ def dense_adj_f16(structure, coef, selfc, transposed: bool = False) -> torch.Ten
     pitch = (s.max_nodes_per_graph + 63) // 64 * 64
     m = torch.empty(s.num_graphs, pitch, pitch, dtype=torch.float16, device=coef.device)
     rowptr, col = (s.rowptr_src, s.col_src) if transposed else (s.rowptr_dst, s.col_dst)
-    with torch.cuda.device(coef.device):
+    with _lib.device_guard(coef.device):
         _lib.check(lib.cgnn_dense_adj_f16(_lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(coef), _lib.ptr(selfc),
                                           _lib.ptr(s.gptr), s.num_graphs, pitch, _lib.ptr(m),
                                           _lib.stream_ptr()), "cgnn_dense_adj_f16")
@@ -175,7 +175,7 @@ def dense_aggregate_f16_raw(structure, m, x, bias=None) -> torch.Tensor:
         raise TypeError("x and m must be float16")
     n, f = x.shape
     y = torch.empty(n, f, dtype=torch.float16, device=x.device)
-    with torch.cuda.device(x.device), _lib.timed("cgnn_dense_aggregate_f16", f"F={f}"):
+    with _lib.device_guard(x.device), _lib.timed("cgnn_dense_aggregate_f16", f"F={f}"):
         _lib.check(lib.cgnn_dense_aggregate_f16(
             _lib.ptr(m), m.shape[1], _lib.ptr(structure.gptr), structure.num_graphs, _lib.ptr(x),
             x.stride(0), f, _lib.ptr(bias), _lib.ptr(y), y.stride(0), _lib.stream_ptr()),
@@ -267,7 +267,7 @@ class _PoolMean(torch.autograd.Function):
         x = _prep(x, "x")
         f = x.shape[1]
         p = torch.empty(num_graphs, f, dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with _lib.device_guard(x.device):
             _lib.check(lib.cgnn_pool_mean_fwd_f32(_lib.ptr(x), x.stride(0), _lib.ptr(gptr),
                                                   _lib.ptr(p), num_graphs, f, _lib.stream_ptr()),
                        "cgnn_pool_mean_fwd_f32")
@@ -280,7 +280,7 @@ class _PoolMean(torch.autograd.Function):
         dp = _prep(dp, "grad")
         n, f = ctx.shape
         dx = torch.empty(n, f, dtype=torch.float32, device=dp.device)
-        with torch.cuda.device(dp.device):
+        with _lib.device_guard(dp.device):
             _lib.check(lib.cgnn_pool_mean_bwd_f32(_lib.ptr(dp), _lib.ptr(ctx.gptr), _lib.ptr(dx),
                                                   dx.stride(0), dp.shape[0], f, _lib.stream_ptr()),
                        "cgnn_pool_mean_bwd_f32")
@@ -306,8 +306,9 @@ class _BnActDrop(torch.autograd.Function):
         x = torch.empty_like(y)
         mask = torch.empty(m * (n // 4), dtype=torch.uint8, device=dev) if p_eff > 0 else None
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p_eff > 0 else 0
-        st = _lib.stream_ptr
-        with torch.cuda.device(dev):
+        _sp = _lib.stream_ptr(dev)          # one lookup per pass (torch.cuda.current_stream is ~10 us)
+        st = lambda: _sp
+        with _lib.device_guard(dev):
             rows = int(lib.cgnn_bn_act_slab_rows(m))
             slab = torch.empty(rows, 2 * n, dtype=torch.float64, device=dev) if training else None
             if training:
@@ -336,10 +337,11 @@ class _BnActDrop(torch.autograd.Function):
         m, n = y.shape
         dev = y.device
         f32 = dict(dtype=torch.float32, device=dev)
-        st = _lib.stream_ptr
+        _sp = _lib.stream_ptr(dev)          # one lookup per pass (torch.cuda.current_stream is ~10 us)
+        st = lambda: _sp
         dgamma, dbeta, bwc = torch.empty(n, **f32), torch.empty(n, **f32), torch.empty(2 * n, **f32)
         dy = torch.empty_like(y)
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             rows = int(lib.cgnn_bn_act_slab_rows(m))
             slab = torch.empty(rows, 2 * n, dtype=torch.float64, device=dev)
             _lib.check(lib.cgnn_bn_act_bwd_stats(_lib.ptr(dx), _lib.ptr(y), _lib.ptr(mask), _lib.ptr(coef),
@@ -382,7 +384,7 @@ class _Head(torch.autograd.Function):
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p_eff > 0 else 0
         h1, fac = torch.empty(bsz, h2, **f32), torch.empty(bsz, h2, **f32)
         logits = torch.empty(bsz, c, **f32)
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             _lib.check(lib.cgnn_head_fwd_f32(_lib.ptr(p), bsz, h, h2, c, _lib.ptr(w1), _lib.ptr(b1),
                                              _lib.ptr(w2), _lib.ptr(b2), p_eff, seed,
                                              rng_word if p_eff > 0 else None, _lib.ptr(h1), _lib.ptr(fac),
@@ -399,7 +401,7 @@ class _Head(torch.autograd.Function):
         h2, c = w1.shape[0], w2.shape[0]
         dev = p.device
         wd = h2 * h + h2 + c * h2 + c
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             rows = int(lib.cgnn_head_grid(bsz, h2))
             slab = torch.empty(rows, wd, dtype=torch.float32, device=dev)
             dp = torch.empty_like(p)
@@ -445,7 +447,7 @@ class _CrossEntropy(torch.autograd.Function):
         bsz, c = logits.shape
         loss = torch.empty(1, dtype=torch.float32, device=logits.device)
         dl = torch.empty_like(logits)
-        with torch.cuda.device(logits.device):
+        with _lib.device_guard(logits.device):
             _lib.check(lib.cgnn_cross_entropy_f32(_lib.ptr(logits), _lib.ptr(labels.contiguous()), bsz, c,
                                                   _lib.ptr(loss), _lib.ptr(dl), _lib.stream_ptr()),
                        "cgnn_cross_entropy_f32")

@@ -95,7 +95,8 @@ class SageEncode(torch.autograd.Function):
         rng = cfg.get("rng_state")
         L = len(params) // 4
         dev = x0.device
-        st = _lib.stream_ptr
+        _sp = _lib.stream_ptr(dev)          # one lookup per pass (torch.cuda.current_stream is ~10 us)
+        st = lambda: _sp
         x = x0.contiguous()
         n_nodes = s.num_nodes
         sv = _Saved()
@@ -105,7 +106,7 @@ class SageEncode(torch.autograd.Function):
         sv.norm = s.sage_norm(backward_coef=False)
         sv.xs, sv.aggs, sv.zs, sv.coefs, sv.masks, sv.ws = [], [], [], [], [], []
         sv.xa0 = None
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             if rng is not None and p > 0:
                 _lib.check(lib.cgnn_rng_advance(_lib.ptr(rng), L + 1, st()), "cgnn_rng_advance")
             rows = int(lib.cgnn_bn_act_slab_rows(n_nodes))
@@ -178,11 +179,12 @@ class SageEncode(torch.autograd.Function):
         sv: _Saved = ctx.sv
         s, L = sv.s, ctx.L
         dev = dP.device
-        st = _lib.stream_ptr
+        _sp = _lib.stream_ptr(dev)          # one lookup per pass (torch.cuda.current_stream is ~10 us)
+        st = lambda: _sp
         n_nodes = s.num_nodes
         dP = dP.contiguous()
         grads: List[Optional[torch.Tensor]] = [None] * (4 * L)
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             dx = None                      # last layer: gradient rebuilt from dP inside the kernels
             rows = int(lib.cgnn_bn_act_slab_rows(n_nodes))
             for li in range(L - 1, -1, -1):

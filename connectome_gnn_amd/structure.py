@@ -103,7 +103,7 @@ class BatchStructure:
         node_graph = batch.batch.contiguous() if batch.batch is not None else None
         if node_graph is not None and (node_graph.dtype != torch.int64 or node_graph.numel() != nn_):
             raise ValueError("batch.batch must be int64 [num_nodes]")
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             _lib.check(lib.cgnn_csr_build(
                 _lib.ptr(ei), _lib.ptr(node_graph), nn_, ne,
                 _lib.ptr(s.rowptr_dst), _lib.ptr(s.eid_dst), _lib.ptr(s.col_dst),
@@ -131,7 +131,7 @@ class BatchStructure:
         f32 = dict(dtype=torch.float32, device=dev)
         n = GcnNorm(torch.empty(self.num_nodes, **f32), torch.empty(self.num_nodes, **f32),
                     torch.empty(self.num_edges, **f32), torch.empty(self.num_edges, **f32))
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             _lib.check(lib.cgnn_gcn_norm(
                 _lib.ptr(self._edge_index), _lib.ptr(self._edge_weight), self.num_nodes,
                 self.num_edges, _lib.ptr(self.rowptr_dst), _lib.ptr(self.eid_dst),
@@ -148,7 +148,7 @@ class BatchStructure:
         f32 = dict(dtype=torch.float32, device=dev)
         n = SageNorm(torch.empty(self.num_nodes, **f32), torch.empty(self.num_edges, **f32),
                      torch.empty(self.num_edges, **f32) if backward_coef else None)
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             _lib.check(lib.cgnn_sage_norm(
                 _lib.ptr(self._edge_index), _lib.ptr(self._edge_weight), self.num_nodes,
                 self.num_edges, _lib.ptr(self.rowptr_dst), _lib.ptr(self.eid_dst),
@@ -207,7 +207,7 @@ class BatchStructure:
         tile_blk = torch.from_numpy(tile_blk_h).to(dev)
         i32 = dict(dtype=torch.int32, device=dev)
         out = {}
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             for name, rowptr, col, eid in (("dst", self.rowptr_dst, self.col_dst, self.eid_dst),
                                            ("src", self.rowptr_src, self.col_src, self.eid_src)):
                 blk_off = torch.empty(nb + 1, **i32)
@@ -256,7 +256,7 @@ class BatchStructure:
         lib = _lib.load()
         dev = self.rowptr_dst.device
         dis = torch.empty(self.num_nodes, dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             _lib.check(lib.cgnn_gcn_dis(_lib.ptr(meta.w_src), _lib.ptr(self.rowptr_src),
                                         self.num_nodes, _lib.ptr(dis), _lib.stream_ptr()),
                        "cgnn_gcn_dis")
