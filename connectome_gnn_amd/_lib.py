@@ -41,6 +41,7 @@ PROTOTYPES = {
     "cgnn_build_target": (c_char_p, []),
     "cgnn_csr_workspace_bytes": (I64, [I64, I64]),
     "cgnn_csr_build": (c_int, [P, P, I64, I64, P, P, P, P, P, P, P, P, P]),
+    "cgnn_csr_build_grouped": (c_int, [P, P, P, I32, I64, I64, I32, I32, P, P, P, P, P, P, P, P]),
     "cgnn_gcn_norm": (c_int, [P, P, I64, I64, P, P, P, P, P, P, P, P, P]),
     "cgnn_sage_norm": (c_int, [P, P, I64, I64, P, P, P, P, P, P, P, P]),
     "cgnn_aggregate_f32": (c_int, [P, P, P, P, P, P, P, I64, P, I64, I64, I32, P]),

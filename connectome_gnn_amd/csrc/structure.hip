@@ -140,6 +140,133 @@ __global__ void k_sort_rows(const int32_t* __restrict__ rowptr, int32_t* eid,
   if ((threadIdx.x & 63) == 0 && deg > 0) atomicMax(max_deg, deg);
 }
 
+// ------------------------------------------------------------------ grouped (per-graph) build
+// When the edges of graph g are the contiguous run [eptr[g], eptr[g+1]) of the COO (what
+// collate_graphs / the resident assembler produce) the whole build of a graph -- count, scan,
+// fill, in-row ordering by edge id, neighbour ids, for BOTH orderings -- is done by one workgroup
+// in LDS: one pass over the int64 COO, coalesced int32 outputs, no global atomics.  Same output
+// bits as the generic builder above (tests compare them).
+//   LDS: cnt/cur for dst and src [4][nmax+1] int; edge slots of both orderings and local
+//        endpoints [4][emax] uint16 (graphs of <= 1024 nodes and < 65535 edges).
+__global__ void __launch_bounds__(256) k_csr_grouped(
+    const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
+    const int32_t* __restrict__ gptr, const int32_t* __restrict__ eptr, int num_graphs, int64_t nn,
+    int64_t ne, int nmax, int emax, int32_t* __restrict__ rowptr_dst, int32_t* __restrict__ eid_dst,
+    int32_t* __restrict__ col_dst, int32_t* __restrict__ rowptr_src, int32_t* __restrict__ eid_src,
+    int32_t* __restrict__ col_src, int32_t* __restrict__ flags) {
+  extern __shared__ int32_t lds[];
+  int32_t* cnt_d = lds;                       // [nmax+1] counts -> exclusive offsets
+  int32_t* cnt_s = cnt_d + (nmax + 1);
+  int32_t* cur_d = cnt_s + (nmax + 1);        // [nmax+1] fill cursors
+  int32_t* cur_s = cur_d + (nmax + 1);
+  uint16_t* slot_d = reinterpret_cast<uint16_t*>(cur_s + (nmax + 1));   // [emax] local edge index
+  uint16_t* slot_s = slot_d + emax;                                    //        per ordered slot
+  uint16_t* loc_s = slot_s + emax;            // [emax] local src of each edge
+  uint16_t* loc_d = loc_s + emax;
+  __shared__ int wave_tot[4];
+  __shared__ int blk_max[2];
+  for (int g = blockIdx.x; g < num_graphs; g += gridDim.x) {
+    const int nb = gptr[g], n = gptr[g + 1] - nb;
+    const int e0 = eptr[g], m = eptr[g + 1] - e0;
+    for (int i = threadIdx.x; i <= n; i += 256) cnt_d[i] = cnt_s[i] = 0;
+    if (threadIdx.x < 2) blk_max[threadIdx.x] = 0;
+    __syncthreads();
+    // 1. counts + local endpoints (invalid edges: flagged, the caller rebuilds generically)
+    for (int i = threadIdx.x; i < m; i += 256) {
+      const int64_t sg = src[e0 + i], dg = dst[e0 + i];
+      const bool in_range = sg >= 0 && sg < nn && dg >= 0 && dg < nn;
+      const bool local = in_range && sg >= nb && sg < nb + n && dg >= nb && dg < nb + n;
+      if (!local) {
+        atomicAdd(&flags[in_range ? 1 : 0], 1);
+        loc_s[i] = loc_d[i] = 0xFFFFu;
+        continue;
+      }
+      loc_s[i] = (uint16_t)(sg - nb);
+      loc_d[i] = (uint16_t)(dg - nb);
+      atomicAdd(&cnt_d[dg - nb], 1);
+      atomicAdd(&cnt_s[sg - nb], 1);
+    }
+    __syncthreads();
+    // 2. exclusive scans (n <= nmax <= 1024: 4 elements per thread), degree maxima
+    for (int which = 0; which < 2; ++which) {
+      int32_t* cnt = which ? cnt_s : cnt_d;
+      int32_t* cur = which ? cur_s : cur_d;
+      int v[4], sum = 0, mx = 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = 4 * threadIdx.x + u;
+        v[u] = i < n ? cnt[i] : 0;
+        mx = max(mx, v[u]);
+        sum += v[u];
+      }
+      int x = sum;
+      const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+      if (lane == 63) wave_tot[wid] = x;
+      if (lane == 0 && mx > 0) atomicMax(&blk_max[which], mx);
+      __syncthreads();
+      int base = x - sum;
+      for (int w = 0; w < wid; ++w) base += wave_tot[w];
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = 4 * threadIdx.x + u;
+        if (i < n) {
+          cnt[i] = base;
+          cur[i] = base;
+          (which ? rowptr_src : rowptr_dst)[nb + i] = e0 + base;
+        }
+        base += v[u];
+      }
+      __syncthreads();
+    }
+    if (g == num_graphs - 1 && threadIdx.x == 0) {
+      rowptr_dst[nn] = (int32_t)ne;
+      rowptr_src[nn] = (int32_t)ne;
+    }
+    if (threadIdx.x < 2 && blk_max[threadIdx.x] > 0) atomicMax(&flags[2 + threadIdx.x], blk_max[threadIdx.x]);
+    // 3. fill (arbitrary order inside a row) ...
+    for (int i = threadIdx.x; i < m; i += 256) {
+      if (loc_s[i] == 0xFFFFu) continue;
+      slot_d[atomicAdd(&cur_d[loc_d[i]], 1)] = (uint16_t)i;
+      slot_s[atomicAdd(&cur_s[loc_s[i]], 1)] = (uint16_t)i;
+    }
+    __syncthreads();
+    // 4. ... then restore COO order inside every row (rows are short: insertion sort)
+    for (int r = threadIdx.x; r < 2 * n; r += 256) {
+      const bool which = r >= n;
+      const int row = which ? r - n : r;
+      uint16_t* slot = which ? slot_s : slot_d;
+      const int b = (which ? cnt_s : cnt_d)[row], e = (which ? cur_s : cur_d)[row];
+      for (int i = b + 1; i < e; ++i) {
+        const uint16_t key = slot[i];
+        int j = i - 1;
+        while (j >= b && slot[j] > key) {
+          slot[j + 1] = slot[j];
+          --j;
+        }
+        slot[j + 1] = key;
+      }
+    }
+    __syncthreads();
+    // 5. coalesced outputs: global edge ids and neighbour ids of both orderings
+    for (int p = threadIdx.x; p < m; p += 256) {
+      const int a = slot_d[p], c = slot_s[p];
+      eid_dst[e0 + p] = e0 + a;
+      col_dst[e0 + p] = nb + loc_s[a];
+      eid_src[e0 + p] = e0 + c;
+      col_src[e0 + p] = nb + loc_d[c];
+    }
+    __syncthreads();
+  }
+}
+
 // GCN: deg (source side) + self loop, dis, selfc -- one thread per node, COO order sum.
 __global__ void k_gcn_deg(const float* __restrict__ w, const int32_t* __restrict__ rowptr_src,
                           const int32_t* __restrict__ eid_src, int64_t nn, float* dis,
@@ -338,6 +465,38 @@ int cgnn_csr_build(const int64_t* edge_index, const int64_t* node_graph, int64_t
       CGNN_CHECK_LAUNCH();
     }
   }
+  return CGNN_OK;
+}
+
+int cgnn_csr_build_grouped(const int64_t* edge_index, const int32_t* gptr, const int32_t* eptr,
+                           int32_t num_graphs, int64_t nn, int64_t ne, int32_t max_nodes,
+                           int32_t max_edges, int32_t* rowptr_dst, int32_t* eid_dst, int32_t* col_dst,
+                           int32_t* rowptr_src, int32_t* eid_src, int32_t* col_src, int32_t* flags,
+                           void* stream) {
+  if (nn < 0 || ne < 0 || nn >= INT32_MAX || ne >= INT32_MAX || num_graphs < 0 || max_nodes < 0 ||
+      max_edges < 0)
+    return CGNN_EINVAL;
+  if (!rowptr_dst || !rowptr_src || !flags || !gptr || !eptr) return CGNN_EINVAL;
+  if (ne > 0 && (!edge_index || !eid_dst || !col_dst || !eid_src || !col_src)) return CGNN_EINVAL;
+  const size_t lds = sizeof(int32_t) * 4 * ((size_t)max_nodes + 1) + sizeof(uint16_t) * 4 * (size_t)max_edges;
+  constexpr size_t kMaxLds = 128 * 1024;
+  if (max_nodes > 1024 || max_edges >= 65535 || lds > kMaxLds || num_graphs == 0) return CGNN_EUNSUPPORTED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_csr_grouped),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds) != hipSuccess)
+      return CGNN_ELAUNCH;
+    attr_set = true;
+  }
+  hipStream_t st = cgnn_stream(stream);
+  k_zero_i32<<<1, 64, 0, st>>>(flags, 4);
+  CGNN_CHECK_LAUNCH();
+  const int cus = cgnn_fused_grid();
+  const int grid = num_graphs < 8 * cus ? num_graphs : 8 * cus;
+  k_csr_grouped<<<grid, 256, lds, st>>>(edge_index, edge_index + ne, gptr, eptr, num_graphs, nn, ne,
+                                         max_nodes, max_edges, rowptr_dst, eid_dst, col_dst, rowptr_src,
+                                         eid_src, col_src, flags);
+  CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }
 

@@ -72,6 +72,9 @@ class ConnectomeBatch:
     labels: Optional[torch.Tensor]
     ptr: torch.Tensor
     _structure: object = field(default=None, init=False, repr=False, compare=False)
+    # host int64 [B+1]: edges of graph g are the COO run [_eptr[g], _eptr[g+1]) -- set by
+    # collate_graphs / the resident assembler, lets the structure be built per graph in LDS
+    _eptr: object = field(default=None, init=False, repr=False, compare=False)
 
     @property
     def num_graphs(self) -> int:
@@ -89,6 +92,7 @@ class ConnectomeBatch:
         # the cached structure stays valid if nothing moved
         if out.edge_index.data_ptr() == self.edge_index.data_ptr():
             out._structure = self._structure
+        out._eptr = self._eptr
         return out
 
     def structure(self):
@@ -112,7 +116,7 @@ def collate_graphs(graphs: Sequence[ConnectomeGraph]) -> ConnectomeBatch:
     batch_ids = torch.repeat_interleave(torch.arange(len(graphs), dtype=torch.long),
                                         torch.tensor(sizes, dtype=torch.long))
     labelled = [g.label for g in graphs if g.label is not None]
-    return ConnectomeBatch(
+    out = ConnectomeBatch(
         node_features=torch.cat([g.node_features for g in graphs], dim=0),
         edge_index=edge_index,
         edge_weight=torch.cat([g.edge_weight for g in graphs], dim=0),
@@ -120,6 +124,11 @@ def collate_graphs(graphs: Sequence[ConnectomeGraph]) -> ConnectomeBatch:
         labels=torch.stack(labelled) if labelled else None,
         ptr=ptr,
     )
+    eptr = torch.zeros(len(graphs) + 1, dtype=torch.long)
+    if graphs:
+        eptr[1:] = torch.cumsum(torch.tensor([g.num_edges for g in graphs], dtype=torch.long), 0)
+    out._eptr = eptr
+    return out
 
 
 class ConnectomeDataLoader:

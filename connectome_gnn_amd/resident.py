@@ -22,7 +22,7 @@ def assemble_batch(ds: PackedDataset, subject_ids: torch.Tensor) -> ConnectomeBa
     n, e = int(ds.x.shape[1]), int(ds.edge_local.shape[2])
     offs = torch.arange(b, device=dev, dtype=torch.long) * n
     edge_index = (ds.edge_local.index_select(0, ids) + offs.view(b, 1, 1)).permute(1, 0, 2)
-    return ConnectomeBatch(
+    out = ConnectomeBatch(
         node_features=ds.x.index_select(0, ids).reshape(b * n, -1),
         edge_index=edge_index.reshape(2, b * e).contiguous(),
         edge_weight=ds.edge_weight.index_select(0, ids).reshape(b * e),
@@ -30,6 +30,8 @@ def assemble_batch(ds: PackedDataset, subject_ids: torch.Tensor) -> ConnectomeBa
         labels=ds.labels.index_select(0, ids),
         ptr=torch.arange(b + 1, device=dev, dtype=torch.long) * n,
     )
+    out._eptr = torch.arange(b + 1, dtype=torch.long) * e          # host: e edges per graph
+    return out
 
 
 class ResidentDataLoader:

@@ -79,7 +79,7 @@ class BatchStructure:
         self._tiles = {}
 
     @staticmethod
-    def build(batch) -> "BatchStructure":
+    def build(batch, force_generic: bool = False) -> "BatchStructure":
         ei, ew = batch.edge_index, batch.edge_weight
         _require_device(ei, "batch.edge_index")
         if ei.dtype != torch.int64 or ei.dim() != 2 or ei.shape[0] != 2:
@@ -99,23 +99,42 @@ class BatchStructure:
         s.eid_dst, s.col_dst = torch.empty(ne, **i32), torch.empty(ne, **i32)
         s.eid_src, s.col_src = torch.empty(ne, **i32), torch.empty(ne, **i32)
         flags = torch.empty(4, **i32)
-        ws = torch.empty(int(lib.cgnn_csr_workspace_bytes(nn_, ne)), dtype=torch.uint8, device=dev)
         node_graph = batch.batch.contiguous() if batch.batch is not None else None
         if node_graph is not None and (node_graph.dtype != torch.int64 or node_graph.numel() != nn_):
             raise ValueError("batch.batch must be int64 [num_nodes]")
+        s._ptr_host = batch.ptr.detach().cpu().numpy().astype(np.int64)
+        sizes = np.diff(s._ptr_host)
+        s.max_nodes_per_graph = int(sizes.max()) if sizes.size else 0
         with _lib.device_guard(dev):
-            _lib.check(lib.cgnn_csr_build(
-                _lib.ptr(ei), _lib.ptr(node_graph), nn_, ne,
-                _lib.ptr(s.rowptr_dst), _lib.ptr(s.eid_dst), _lib.ptr(s.col_dst),
-                _lib.ptr(s.rowptr_src), _lib.ptr(s.eid_src), _lib.ptr(s.col_src),
-                _lib.ptr(flags), _lib.ptr(ws), _lib.stream_ptr()), "cgnn_csr_build")
             s.gptr = batch.ptr.to(device=dev, dtype=torch.int32)
             s.node_graph = (node_graph.to(torch.int32) if node_graph is not None
                             else torch.zeros(nn_, dtype=torch.int32, device=dev))
-            f = flags.tolist()                      # one sync per batch, at build time only
-            s._ptr_host = batch.ptr.detach().cpu().numpy().astype(np.int64)
-            sizes = np.diff(s._ptr_host)
-            s.max_nodes_per_graph = int(sizes.max()) if sizes.size else 0
+            f = None
+            eptr = getattr(batch, "_eptr", None)
+            if (not force_generic and eptr is not None and eptr.numel() == batch.num_graphs + 1
+                    and int(eptr[-1]) == ne and batch.num_graphs > 0):
+                # COO grouped by graph: whole graphs are built in LDS by one workgroup each
+                emax = int((eptr[1:] - eptr[:-1]).max())
+                rc = lib.cgnn_csr_build_grouped(
+                    _lib.ptr(ei), _lib.ptr(s.gptr), _lib.ptr(eptr.to(device=dev, dtype=torch.int32)),
+                    batch.num_graphs, nn_, ne, s.max_nodes_per_graph, emax,
+                    _lib.ptr(s.rowptr_dst), _lib.ptr(s.eid_dst), _lib.ptr(s.col_dst),
+                    _lib.ptr(s.rowptr_src), _lib.ptr(s.eid_src), _lib.ptr(s.col_src),
+                    _lib.ptr(flags), _lib.stream_ptr(dev))
+                if rc == _lib.CGNN_OK:
+                    f = flags.tolist()              # one sync per batch, at build time only
+                    if f[0] or f[1]:
+                        f = None                    # not grouped after all: generic build decides
+                elif rc != _lib.CGNN_EUNSUPPORTED:
+                    _lib.check(rc, "cgnn_csr_build_grouped")
+            if f is None:
+                ws = torch.empty(int(lib.cgnn_csr_workspace_bytes(nn_, ne)), dtype=torch.uint8, device=dev)
+                _lib.check(lib.cgnn_csr_build(
+                    _lib.ptr(ei), _lib.ptr(node_graph), nn_, ne,
+                    _lib.ptr(s.rowptr_dst), _lib.ptr(s.eid_dst), _lib.ptr(s.col_dst),
+                    _lib.ptr(s.rowptr_src), _lib.ptr(s.eid_src), _lib.ptr(s.col_src),
+                    _lib.ptr(flags), _lib.ptr(ws), _lib.stream_ptr(dev)), "cgnn_csr_build")
+                f = flags.tolist()                  # one sync per batch, at build time only
         if f[0]:
             # the reference would raise from scatter_add_/index (models.py:104,112)
             raise IndexError(f"{f[0]} edge(s) reference a node outside [0, {nn_})")

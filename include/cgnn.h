@@ -66,6 +66,20 @@ int cgnn_csr_build(const int64_t* edge_index, const int64_t* node_graph,
                    int32_t* rowptr_src, int32_t* eid_src, int32_t* col_src,
                    int32_t* flags, void* workspace, void* stream);
 
+/* Same outputs as cgnn_csr_build for batches whose COO is grouped by graph: the edges of graph g
+ * are exactly the run [eptr[g], eptr[g+1]) and both endpoints lie in [gptr[g], gptr[g+1]) -- what
+ * collate_graphs (graph.py:143-167) produces.  One workgroup builds a whole graph in LDS (single
+ * pass over the COO, no global atomics): ~10x faster than the generic build at 4096 x 360-ROI.
+ * gptr/eptr int32 [B+1]; max_nodes <= 1024, max_edges < 65535 and LDS = 16*(max_nodes+1) +
+ * 8*max_edges <= 128 KB, else CGNN_EUNSUPPORTED.  flags as cgnn_csr_build; if flags[0] or flags[1] is non-zero the input
+ * was not grouped/block-diagonal and the outputs are incomplete: rebuild with cgnn_csr_build. */
+int cgnn_csr_build_grouped(const int64_t* edge_index, const int32_t* gptr, const int32_t* eptr,
+                           int32_t num_graphs, int64_t num_nodes, int64_t num_edges,
+                           int32_t max_nodes, int32_t max_edges,
+                           int32_t* rowptr_dst, int32_t* eid_dst, int32_t* col_dst,
+                           int32_t* rowptr_src, int32_t* eid_src, int32_t* col_src,
+                           int32_t* flags, void* stream);
+
 /* GCN symmetric normalisation, models.py:94-108: self-loop weight 1 appended last,
  * deg[i] = sum_{e: src=i} w_e + 1 (SOURCE side), dis = (deg + 1e-8)^-1/2,
  * c_e = dis[src]*w_e*dis[dst].  Layer independent -> once per batch.

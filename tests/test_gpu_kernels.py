@@ -446,3 +446,38 @@ def test_config5_scatter_full_size_properties():
     lin = ops.dense_aggregate_f16_raw(s, m, (0.5 * x + y).half()).float()
     want = 0.5 * dense + ops.dense_aggregate_f16_raw(s, m, y.half()).float()
     torch.testing.assert_close(lin, want, rtol=5e-3, atol=5e-3 * scale)
+
+
+@pytest.mark.parametrize("sizes,deg", [([20, 35, 84, 3], 6), ([360] * 5, 14), ([1, 2, 7], 2),
+                                       ([1000, 12], 9), ([84] * 40, 8)])
+def test_csr_build_grouped_is_bit_identical_to_generic(sizes, deg):
+    """cgnn_csr_build_grouped (one workgroup per graph, in LDS) == cgnn_csr_build on grouped COOs
+    (duplicates, self-loops, isolated nodes, empty graphs); a COO that is not grouped falls back."""
+    import connectome_gnn_amd as C
+    from connectome_gnn_amd.structure import BatchStructure
+    ei, w, ptr, bid, nn_ = _rand_graph_batch(sizes, deg, 17)
+    b = _batch(ei, w, ptr, bid, nn_, 5).to(DEV)
+    counts = torch.bincount(bid[ei[0]], minlength=len(sizes)) if ei.shape[1] else torch.zeros(len(sizes), dtype=torch.long)
+    b._eptr = torch.cat([torch.zeros(1, dtype=torch.long), counts.cumsum(0)])
+    fast, slow = BatchStructure.build(b), BatchStructure.build(b, force_generic=True)
+    for name in ("rowptr_dst", "eid_dst", "col_dst", "rowptr_src", "eid_src", "col_src"):
+        assert torch.equal(getattr(fast, name), getattr(slow, name)), name
+    assert (fast.max_in_degree, fast.max_out_degree, fast.block_diagonal) == \
+           (slow.max_in_degree, slow.max_out_degree, slow.block_diagonal)
+    # collate_graphs and the resident assembler provide the grouping themselves
+    empty = C.ConnectomeGraph(torch.zeros(0, 5), torch.zeros(2, 0, dtype=torch.long), torch.zeros(0),
+                              torch.tensor(1))
+    gs = C.generate_dataset(6, 84, 8, seed=3)
+    cb = C.collate_graphs(gs[:2] + [empty] + gs[2:] + [empty]).to(DEV)
+    assert cb._eptr is not None
+    f2, s2 = BatchStructure.build(cb), BatchStructure.build(cb, force_generic=True)
+    assert torch.equal(f2.eid_dst, s2.eid_dst) and torch.equal(f2.col_src, s2.col_src)
+    # an edge that crosses graphs: flagged by the grouped kernel, rebuilt generically
+    if len(sizes) > 1 and sizes[0] > 0 and sizes[1] > 0 and ei.shape[1] > 0:
+        ei2 = ei.clone()
+        ei2[1, 0] = sizes[0]                       # first edge now ends in graph 1
+        b2 = _batch(ei2, w, ptr, bid, nn_, 5).to(DEV)
+        b2._eptr = b._eptr
+        s3 = BatchStructure.build(b2)
+        assert not s3.block_diagonal
+        assert torch.equal(s3.eid_dst, BatchStructure.build(b2, force_generic=True).eid_dst)
