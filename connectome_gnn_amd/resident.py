@@ -40,14 +40,20 @@ class ResidentDataLoader:
     rank's contiguous shard of every global batch (graph-sharded data parallelism)."""
 
     def __init__(self, dataset: PackedDataset, batch_size: int = 16, shuffle: bool = True,
-                 rank: int = 0, world_size: int = 1):
+                 rank: int = 0, world_size: int = 1, prefetch: bool = False, prepare=None):
+        """prefetch: assemble the NEXT batch and build its structure (CSR, and whatever
+        ``prepare(batch)`` builds, e.g. ``model.prepare_batch``) on a side stream while the caller
+        trains on the current one -- the builds read sizes back to the host, and on the training
+        stream those read-backs would wait for the whole previous step."""
         self.dataset, self.batch_size, self.shuffle = dataset, batch_size, shuffle
         self.rank, self.world_size = rank, world_size
+        self.prefetch, self.prepare = prefetch, prepare
+        self._side = None
 
     def __len__(self) -> int:
         return -(-self.dataset.num_subjects // self.batch_size)
 
-    def __iter__(self):
+    def _chunks(self):
         n = self.dataset.num_subjects
         order = torch.randperm(n) if self.shuffle else torch.arange(n)
         for lo in range(0, n, self.batch_size):
@@ -57,4 +63,45 @@ class ResidentDataLoader:
                     continue          # a tail smaller than the world: dropped on every rank
                 chunk = torch.tensor(shard_slice(chunk.tolist(), self.rank, self.world_size),
                                      dtype=torch.long)
-            yield assemble_batch(self.dataset, chunk)
+            yield chunk
+
+    def __iter__(self):
+        if not self.prefetch or self.dataset.x.device.type != "cuda":
+            for chunk in self._chunks():
+                b = assemble_batch(self.dataset, chunk)
+                if self.prepare is not None:
+                    self.prepare(b)
+                yield b
+            return
+        dev = self.dataset.x.device
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
+        side = self._side
+
+        def make(chunk, after):
+            # Everything of the batch is allocated, built and read back on the side stream.  Its
+            # memory is only ever recycled by a later side-stream allocation, which by then has
+            # waited (`after`) for the training stream to be done with the batch it came from.
+            if after is not None:
+                side.wait_event(after)
+            with torch.cuda.stream(side):
+                b = assemble_batch(self.dataset, chunk)
+                b.structure()
+                if self.prepare is not None:
+                    self.prepare(b)
+                ev = side.record_event()
+            return b, ev
+
+        main = torch.cuda.current_stream(dev)
+        chunks = list(self._chunks())
+        nxt = make(chunks[0], main.record_event()) if chunks else None
+        for i in range(len(chunks)):
+            cur, ev = nxt
+            main.wait_event(ev)
+            done_prev = main.record_event()        # all training work enqueued before batch i
+            nxt = None
+            yield cur
+            # the caller has now enqueued its step on batch i; build batch i+1 while it runs (the
+            # side stream only waits for the steps BEFORE it, whose batches' memory it may reuse)
+            if i + 1 < len(chunks):
+                nxt = make(chunks[i + 1], done_prev)

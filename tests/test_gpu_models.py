@@ -519,3 +519,28 @@ def test_sage_config3_full_size_properties():
     assert torch.equal(outs[2][0], outs[0][0])
     assert all(torch.equal(a, c) for a, c in zip(outs[2][2], outs[0][2]))
     assert all(torch.isfinite(g).all() for g in outs[0][2])
+
+
+def test_resident_loader_prefetch_is_equivalent():
+    """ResidentDataLoader(prefetch=True) builds the next batch (and its structure) on a side stream:
+    same batches in the same order, and the same training trajectory, as without prefetch."""
+    import connectome_gnn_amd as C
+    from connectome_gnn_amd.resident import ResidentDataLoader
+    from connectome_gnn_amd.synthetic import generate_packed
+    ds = generate_packed(96, 84, 8, seed=9).to(DEV)
+    runs = []
+    for pf in (False, True):
+        torch.manual_seed(4)
+        m = C.GCNConnectome(5, 64, dropout=0.0)
+        tr = C.Trainer(m, torch.optim.Adam(m.parameters(), lr=1e-2), device=DEV)
+        ld = ResidentDataLoader(ds, batch_size=20, shuffle=True, prefetch=pf, prepare=tr.model.prepare_batch)
+        torch.manual_seed(5)
+        first = [(b.labels.clone(), b.edge_index[:, :7].clone(), b.num_graphs) for b in ld]
+        torch.manual_seed(5)
+        losses = [tr.train_epoch(ld) for _ in range(3)]
+        runs.append((first, losses, [p.detach().clone() for p in m.parameters()]))
+    assert len(runs[0][0]) == len(runs[1][0]) == 5
+    for (la, ea, na), (lb, eb, nb) in zip(runs[0][0], runs[1][0]):
+        assert na == nb and torch.equal(la, lb) and torch.equal(ea, eb)
+    assert runs[0][1] == runs[1][1]
+    assert all(torch.equal(a, c) for a, c in zip(runs[0][2], runs[1][2]))
