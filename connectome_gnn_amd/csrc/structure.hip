@@ -359,16 +359,34 @@ __global__ void __launch_bounds__(256) k_bell_fill(
       beg = rowptr[base + r];
       deg = rowptr[base + r + 1] - beg;
     }
-    for (int s = 0; s < width; ++s) {
-      uint2 e = make_uint2(0u, 0u);             // padding: row 0 of the tile, weight +0
-      if (s < deg) {
-        e.x = (uint32_t)(col[beg + s] - base) * 256u;
-        e.y = __float_as_uint(w[eid[beg + s]]);
-      } else if (s == deg) {
-        e.x = (uint32_t)r * 256u;               // the appended self-loop (GCN: weight 1), last
-        e.y = __float_as_uint(self_weight);
+    // 8 steps at a time: all neighbour ids / edge ids first, then the weight gathers, then the
+    // stores (three dependent round trips per 8 entries instead of per entry)
+    for (int s0 = 0; s0 < width; s0 += 8) {
+      int cv[8], ev[8];
+      float wv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int s = s0 + u;
+        cv[u] = s < deg ? col[beg + s] : 0;
+        ev[u] = s < deg ? eid[beg + s] : -1;
       }
-      ent[(int64_t)off + 16 * s + i] = e;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) wv[u] = ev[u] >= 0 ? w[ev[u]] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int s = s0 + u;
+        if (s < width) {
+          uint2 e = make_uint2(0u, 0u);           // padding: row 0 of the tile, weight +0
+          if (s < deg) {
+            e.x = (uint32_t)(cv[u] - base) * 256u;
+            e.y = __float_as_uint(wv[u]);
+          } else if (s == deg) {
+            e.x = (uint32_t)r * 256u;             // the appended self-loop (GCN: weight 1), last
+            e.y = __float_as_uint(self_weight);
+          }
+          ent[(int64_t)off + 16 * s + i] = e;
+        }
+      }
     }
   }
 }

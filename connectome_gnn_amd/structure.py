@@ -234,8 +234,11 @@ class BatchStructure:
                 _lib.check(lib.cgnn_bell_plan(_lib.ptr(tptr), _lib.ptr(tile_blk), nt, nb,
                                               _lib.ptr(rowptr), _lib.ptr(blk_off), _lib.ptr(scratch),
                                               _lib.stream_ptr()), "cgnn_bell_plan")
-                total = int(blk_off[-1])                 # sync: sizes the entry array
-                if total < 0 or total > 2 ** 31 - 17:
+                # entries <= 16 * (max degree of the ordering + 1) per block: sized from the degree
+                # bound recorded at CSR build, so no read-back (and no stall of the stream) here
+                maxdeg = self.max_in_degree if name == "dst" else self.max_out_degree
+                total = nb * 16 * (int(maxdeg) + 1)
+                if total > 2 ** 31 - 17:
                     raise ValueError("blocked-ELL of this batch exceeds 2^31 entries; use smaller batches")
                 ent = torch.empty(max(total, 1) * 8, dtype=torch.uint8, device=dev)
                 _lib.check(lib.cgnn_bell_fill(_lib.ptr(tptr), _lib.ptr(tile_blk), nt,
