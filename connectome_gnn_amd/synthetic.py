@@ -154,6 +154,24 @@ class PackedDataset:
         return ConnectomeGraph(self.x[i], self.edge_local[i], self.edge_weight[i], self.labels[i],
                                f"sub-{i:04d}")
 
+    @staticmethod
+    def from_graphs(graphs) -> "PackedDataset":
+        """Pack a list of ConnectomeGraphs (e.g. the reference's ``generate_dataset`` output) that
+        all have the same number of nodes and edges and carry labels: the dataset can then live
+        in HBM and be batched by ``resident.ResidentDataLoader`` without host work."""
+        if not graphs:
+            raise ValueError("empty dataset")
+        n, e = graphs[0].num_nodes, graphs[0].num_edges
+        for g in graphs:
+            if g.num_nodes != n or g.num_edges != e:
+                raise ValueError("PackedDataset needs graphs of one size (nodes and edges)")
+            if g.label is None:
+                raise ValueError("PackedDataset needs labelled graphs")
+        return PackedDataset(torch.stack([g.node_features for g in graphs]),
+                             torch.stack([g.edge_index for g in graphs]),
+                             torch.stack([g.edge_weight for g in graphs]),
+                             torch.stack([torch.as_tensor(g.label, dtype=torch.long).reshape(()) for g in graphs]))
+
 
 def generate_packed(num_subjects: int, num_regions: int = NUM_REGIONS, k: int = 8,
                     beta: float = 0.15, trait_idx: int = 0, seed: int = 42) -> PackedDataset:

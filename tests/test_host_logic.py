@@ -236,3 +236,20 @@ def test_state_dict_keys_and_param_counts():
         assert all(torch.equal(sd[k], init[k]) for k in init)      # same init stream (a7/a9)
         m = cls(5, 32)
         m.load_state_dict(init)                                     # reference checkpoint loads
+
+
+def test_packed_dataset_from_graphs_round_trip():
+    """PackedDataset.from_graphs: the reference-style list of graphs packed for the resident loader."""
+    import pytest
+    import torch
+    import connectome_gnn_amd as C
+    from connectome_gnn_amd.synthetic import PackedDataset
+    gs = C.generate_dataset(5, 20, 4, seed=3)
+    ds = PackedDataset.from_graphs(gs)
+    assert ds.num_subjects == 5
+    for i, g in enumerate(gs):
+        h = ds.graph(i)
+        assert torch.equal(h.node_features, g.node_features) and torch.equal(h.edge_index, g.edge_index)
+        assert torch.equal(h.edge_weight, g.edge_weight) and int(h.label) == int(g.label)
+    with pytest.raises(ValueError):
+        PackedDataset.from_graphs(gs + C.generate_dataset(1, 21, 4, seed=1))
