@@ -67,11 +67,11 @@ PROTOTYPES = {
     "cgnn_bn_act_width_ok": (c_int, [I32]),
     "cgnn_bn_act_slab_rows": (I64, [I64]),
     "cgnn_bn_act_fwd_stats": (c_int, [P, I64, I32, P, P]),
-    "cgnn_bn_act_finalize": (c_int, [P, I32, I32, F64, I32, P, P, P, P, F32, F32, P, P, P]),
+    "cgnn_bn_act_finalize": (c_int, [P, I32, I32, F64, P, I32, P, P, P, P, F32, F32, P, P, P]),
     "cgnn_bn_act_fwd_apply": (c_int, [P, P, I32, F32, U64, P, P, P, I64, I32, P]),
     "cgnn_bn_act_pool_fwd": (c_int, [P, P, I32, F32, U64, P, P, P, I32, P, I32, P]),
     "cgnn_bn_act_bwd_stats": (c_int, [P, P, P, P, I32, F32, I64, I32, P, P, P, P, P]),
-    "cgnn_bn_act_bwd_finalize": (c_int, [P, I32, I32, F64, I32, P, P, P, P]),
+    "cgnn_bn_act_bwd_finalize": (c_int, [P, I32, I32, F64, P, I32, P, P, P, P]),
     "cgnn_bn_act_apply_blocks": (I64, [I64, I32]),
     "cgnn_bn_act_bwd_apply": (c_int, [P, P, P, P, P, I32, F32, I32, P, P, I64, I32, P, P, P, P]),
     # fused per-tile GCN path

@@ -133,11 +133,13 @@ __device__ __forceinline__ double block_sum256(double v, double* sh) {
 
 // one block per channel
 __global__ void __launch_bounds__(256) k_bn_fwd_finalize_n(
-    const double* __restrict__ slab, int rows, int N, double count, int training,
+    const double* __restrict__ slab, int rows, int N, double count_host,
+    const double* __restrict__ count_dev, int training,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean,
     float* __restrict__ rvar, float momentum, float eps, long long* __restrict__ tracked,
     float* __restrict__ coef) {
   __shared__ double sh[4];
+  const double count = count_dev ? count_dev[0] : count_host;
   const int c = blockIdx.x;
   float mean, var;
   if (training) {
@@ -173,11 +175,13 @@ __global__ void __launch_bounds__(256) k_bn_fwd_finalize_n(
 }
 
 __global__ void __launch_bounds__(256) k_bn_bwd_finalize_n(const double* __restrict__ slab, int rows,
-                                                           int N, double count, int zero_coef,
-                                                           float* __restrict__ dgamma,
+                                                           int N, double count_host,
+                                                           const double* __restrict__ count_dev,
+                                                           int zero_coef, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta,
                                                            float* __restrict__ bwc) {
   __shared__ double sh[4];
+  const double count = count_dev ? count_dev[0] : count_host;
   const int c = blockIdx.x;
   double a1 = 0.0, a2 = 0.0;
   for (int r = threadIdx.x; r < rows; r += 256) {
@@ -341,14 +345,15 @@ int cgnn_bn_act_fwd_stats(const float* Y, int64_t M, int32_t N, double* slab, vo
   return CGNN_OK;
 }
 
-int cgnn_bn_act_finalize(const double* slab, int32_t rows, int32_t N, double count, int32_t training,
+int cgnn_bn_act_finalize(const double* slab, int32_t rows, int32_t N, double count,
+                         const double* count_dev, int32_t training,
                          const float* gamma, const float* beta, float* running_mean,
                          float* running_var, float momentum, float eps,
                          int64_t* num_batches_tracked, float* coef, void* stream) {
   if (!width_ok(N) || !gamma || !beta || !running_mean || !running_var || !coef) return CGNN_EINVAL;
-  if (training && (!slab || rows <= 0 || count <= 0.0)) return CGNN_EINVAL;
+  if (training && (!slab || rows <= 0 || (!count_dev && count <= 0.0))) return CGNN_EINVAL;
   k_bn_fwd_finalize_n<<<N, 256, 0, cgnn_stream(stream)>>>(
-      slab, rows, N, count, training, gamma, beta, running_mean, running_var, momentum, eps,
+      slab, rows, N, count, count_dev, training, gamma, beta, running_mean, running_var, momentum, eps,
       reinterpret_cast<long long*>(num_batches_tracked), coef);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
@@ -405,9 +410,12 @@ int cgnn_bn_act_bwd_stats(const float* dX, const float* Y, const uint8_t* mask, 
 }
 
 int cgnn_bn_act_bwd_finalize(const double* slab, int32_t rows, int32_t N, double count,
-                             int32_t zero_coef, float* dgamma, float* dbeta, float* bwc, void* stream) {
-  if (!width_ok(N) || !slab || rows <= 0 || count <= 0.0 || !dgamma || !dbeta || !bwc) return CGNN_EINVAL;
-  k_bn_bwd_finalize_n<<<N, 256, 0, cgnn_stream(stream)>>>(slab, rows, N, count, zero_coef, dgamma, dbeta, bwc);
+                             const double* count_dev, int32_t zero_coef, float* dgamma, float* dbeta,
+                             float* bwc, void* stream) {
+  if (!width_ok(N) || !slab || rows <= 0 || (!count_dev && count <= 0.0) || !dgamma || !dbeta || !bwc)
+    return CGNN_EINVAL;
+  k_bn_bwd_finalize_n<<<N, 256, 0, cgnn_stream(stream)>>>(slab, rows, N, count, count_dev, zero_coef, dgamma,
+                                                          dbeta, bwc);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }

@@ -24,7 +24,8 @@ from typing import List, Optional
 import torch
 
 from . import _lib, ops
-from .sage_path import PAD_K, PAD_MIN_ROWS, TILE_ROWS, _f32, _linear_fwd_stats
+from .sage_path import (PAD_K, PAD_MIN_ROWS, TILE_ROWS, _f32, _linear_fwd_stats, bn_backward_coefs,
+                        bn_forward_coef, bn_modules_ok, sync_group_of)
 from .structure import BatchStructure
 
 
@@ -39,15 +40,14 @@ def eligible(model, batch, structure: BatchStructure) -> Optional[str]:
         return "graphs do not fit an LDS tile (or edges cross graph boundaries)"
     if batch.node_features.requires_grad:
         return "node_features require grad"
-    for bn in model.batch_norms:
-        if type(bn) is not torch.nn.BatchNorm1d or not (bn.affine and bn.track_running_stats) \
-                or bn.momentum is None:
-            return "BatchNorm is not a plain affine nn.BatchNorm1d with running stats"
+    if not bn_modules_ok(model):
+        return "BatchNorm is not a plain affine BatchNorm1d / SyncBatchNorm with running stats"
     return None
 
 
 class _Saved:
-    __slots__ = ("s", "ell", "norm", "xs", "ys", "coefs", "masks", "p", "training", "ws", "p0", "padded")
+    __slots__ = ("s", "ell", "norm", "xs", "ys", "coefs", "masks", "p", "training", "ws", "p0", "padded",
+                 "sync_group", "count_block")
 
 
 class GcnWideEncode(torch.autograd.Function):
@@ -74,6 +74,7 @@ class GcnWideEncode(torch.autograd.Function):
         sv.norm = s.gcn_norm()
         sv.xs, sv.ys, sv.coefs, sv.masks, sv.ws = [], [], [], [], []
         sv.p0, sv.padded = None, False
+        sv.sync_group, sv.count_block = cfg.get("sync_group"), None
         nrm = sv.norm
         with _lib.device_guard(dev):
             if rng is not None and p > 0:
@@ -109,14 +110,9 @@ class GcnWideEncode(torch.autograd.Function):
                     srows = rows
                     _lib.check(lib.cgnn_bn_act_fwd_stats(_lib.ptr(y), n_nodes, hid, _lib.ptr(slab), st()),
                                "cgnn_bn_act_fwd_stats")
-                bn = bns_mod[li]
-                coef = _f32(dev, 4 * hid)
-                _lib.check(lib.cgnn_bn_act_finalize(
-                    _lib.ptr(slab), srows, hid, float(max(n_nodes, 1)), int(training), _lib.ptr(gamma),
-                    _lib.ptr(beta), _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var),
-                    float(bn.momentum), float(bn.eps),
-                    _lib.ptr(bn.num_batches_tracked) if training else None, _lib.ptr(coef), st()),
-                    "cgnn_bn_act_finalize")
+                coef, blk = bn_forward_coef(lib, slab, srows, hid, n_nodes, training, gamma, beta,
+                                            bns_mod[li], sv.sync_group, st(), dev)
+                sv.count_block = blk if blk is not None else sv.count_block
                 mask = torch.empty(n_nodes * (hid // 4), dtype=torch.uint8, device=dev) if p > 0 else None
                 seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0
                 rw = None if (rng is None or p <= 0) else rng.data_ptr() + 4 * li
@@ -155,16 +151,13 @@ class GcnWideEncode(torch.autograd.Function):
                 x, y, coef, mask, w = sv.xs[li], sv.ys[li], sv.coefs[li], sv.masks[li], sv.ws[li]
                 hid, fin = w.shape[0], x.shape[1]
                 slab = torch.empty(rows, 2 * hid, dtype=torch.float64, device=dev)
-                dgamma, dbeta, bwc = _f32(dev, hid), _f32(dev, hid), _f32(dev, 2 * hid)
                 pool = (_lib.ptr(dP), _lib.ptr(s.node_graph), _lib.ptr(s.gptr)) if li == L - 1 \
                     else (None, None, None)
                 _lib.check(lib.cgnn_bn_act_bwd_stats(_lib.ptr(dx), _lib.ptr(y), _lib.ptr(mask),
                                                      _lib.ptr(coef), 1, sv.p, n_nodes, hid,
                                                      _lib.ptr(slab), *pool, st()), "cgnn_bn_act_bwd_stats")
-                _lib.check(lib.cgnn_bn_act_bwd_finalize(_lib.ptr(slab), rows, hid,
-                                                        float(max(n_nodes, 1)), int(not sv.training),
-                                                        _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(bwc),
-                                                        st()), "cgnn_bn_act_bwd_finalize")
+                dgamma, dbeta, bwc = bn_backward_coefs(lib, slab, rows, hid, n_nodes, sv.training,
+                                                       sv.sync_group, sv.count_block, st(), dev)
                 cs_rows = int(lib.cgnn_bn_act_apply_blocks(n_nodes, hid))
                 cs_slab = torch.empty(cs_rows, hid, dtype=torch.float64, device=dev)
                 dy = torch.empty_like(y)
@@ -200,5 +193,6 @@ def encode(model, batch, structure: BatchStructure) -> torch.Tensor:
     for conv, bn in zip(model.convs, model.batch_norms):
         params += [conv.linear.weight, conv.bias, bn.weight, bn.bias]
     cfg = {"structure": structure, "batch_norms": list(model.batch_norms), "training": model.training,
-           "dropout": float(model.dropout), "rng_state": getattr(model, "rng_device_state", None)}
+           "dropout": float(model.dropout), "rng_state": getattr(model, "rng_device_state", None),
+           "sync_group": sync_group_of(model)}
     return GcnWideEncode.apply(batch.node_features, cfg, *params)

@@ -315,7 +315,7 @@ class _BnActDrop(torch.autograd.Function):
                 _lib.check(lib.cgnn_bn_act_fwd_stats(_lib.ptr(y), m, n, _lib.ptr(slab), st()),
                            "cgnn_bn_act_fwd_stats")
             _lib.check(lib.cgnn_bn_act_finalize(
-                _lib.ptr(slab), rows, n, float(max(m, 1)), int(training), _lib.ptr(gamma.contiguous()),
+                _lib.ptr(slab), rows, n, float(max(m, 1)), None, int(training), _lib.ptr(gamma.contiguous()),
                 _lib.ptr(beta.contiguous()), _lib.ptr(bn_mod.running_mean), _lib.ptr(bn_mod.running_var),
                 float(bn_mod.momentum), float(bn_mod.eps),
                 _lib.ptr(bn_mod.num_batches_tracked) if training else None, _lib.ptr(coef), st()),
@@ -348,7 +348,7 @@ class _BnActDrop(torch.autograd.Function):
                                                  int(relu), p_eff, m, n, _lib.ptr(slab), None, None, None,
                                                  st()),
                        "cgnn_bn_act_bwd_stats")
-            _lib.check(lib.cgnn_bn_act_bwd_finalize(_lib.ptr(slab), rows, n, float(max(m, 1)),
+            _lib.check(lib.cgnn_bn_act_bwd_finalize(_lib.ptr(slab), rows, n, float(max(m, 1)), None,
                                                     int(not training), _lib.ptr(dgamma), _lib.ptr(dbeta),
                                                     _lib.ptr(bwc), st()), "cgnn_bn_act_bwd_finalize")
             _lib.check(lib.cgnn_bn_act_bwd_apply(_lib.ptr(dx), _lib.ptr(y), _lib.ptr(mask), _lib.ptr(coef),

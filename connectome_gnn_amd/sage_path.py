@@ -38,15 +38,14 @@ def eligible(model, batch, structure: BatchStructure) -> Optional[str]:
         return "graphs do not fit an LDS tile (or edges cross graph boundaries)"
     if batch.node_features.requires_grad:
         return "node_features require grad"
-    for bn in model.batch_norms:
-        if type(bn) is not torch.nn.BatchNorm1d or not (bn.affine and bn.track_running_stats) \
-                or bn.momentum is None:
-            return "BatchNorm is not a plain affine nn.BatchNorm1d with running stats"
+    if not bn_modules_ok(model):
+        return "BatchNorm is not a plain affine BatchNorm1d / SyncBatchNorm with running stats"
     return None
 
 
 class _Saved:
-    __slots__ = ("s", "ell", "norm", "xs", "aggs", "zs", "coefs", "masks", "p", "training", "ws", "xa0")
+    __slots__ = ("s", "ell", "norm", "xs", "aggs", "zs", "coefs", "masks", "p", "training", "ws", "xa0",
+                 "sync_group", "count_block")
 
 
 PAD_K = 32          # layer 0: [x0 | agg(x0) | 0] packed to one 32-wide panel
@@ -62,6 +61,69 @@ def _agg_fwd(s: BatchStructure, ell, norm, x):
     if s.tiled_ok(x.shape[1]):
         return ops.aggregate_tiled_raw(s, ell, ops.AGG_POST_DIV, x, None, norm.den, None)
     return ops.aggregate_raw(s.rowptr_dst, s.col_dst, norm.w_dst, None, norm.den, None, x)
+
+
+def sync_group_of(model):
+    """The process group of the model's SyncBatchNorm layers when full-batch statistics across
+    ranks are in effect (training, world size > 1), else None."""
+    import torch.distributed as dist
+    group = None
+    for bn in model.batch_norms:
+        if isinstance(bn, torch.nn.SyncBatchNorm) and model.training and dist.is_initialized() \
+                and dist.get_world_size(bn.process_group) > 1:
+            group = bn.process_group if bn.process_group is not None else dist.group.WORLD
+    return group
+
+
+def bn_modules_ok(model) -> bool:
+    """Plain affine BatchNorm1d / SyncBatchNorm with running statistics and a fixed momentum."""
+    for bn in model.batch_norms:
+        if type(bn) not in (torch.nn.BatchNorm1d, torch.nn.SyncBatchNorm) \
+                or not (bn.affine and bn.track_running_stats) or bn.momentum is None:
+            return False
+    return True
+
+
+def bn_forward_coef(lib, slab, srows, hid, n_nodes, training, gamma, beta, bn, sync_group, sp, dev):
+    """BatchNorm coefficient block [a | b | mean | invstd] from the statistics slab (running stats in
+    eval mode).  With a sync group the per-rank sums and row count are all-reduced first (one fp64
+    block of 2H+1 words; the count never returns to the host).  Returns (coef, count_block)."""
+    import torch.distributed as dist
+    coef = _f32(dev, 4 * hid)
+    count_dev, block = None, None
+    if training and sync_group is not None:
+        block = torch.empty(2 * hid + 1, dtype=torch.float64, device=dev)
+        torch.sum(slab[:srows], dim=0, out=block[:2 * hid])
+        block[2 * hid:] = float(n_nodes)
+        dist.all_reduce(block, op=dist.ReduceOp.SUM, group=sync_group)
+        slab, srows, count_dev = block, 1, block.data_ptr() + 8 * 2 * hid
+    _lib.check(lib.cgnn_bn_act_finalize(
+        _lib.ptr(slab), srows, hid, float(max(n_nodes, 1)), count_dev, int(training), _lib.ptr(gamma),
+        _lib.ptr(beta), _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var), float(bn.momentum),
+        float(bn.eps), _lib.ptr(bn.num_batches_tracked) if training else None, _lib.ptr(coef), sp),
+        "cgnn_bn_act_finalize")
+    return coef, block
+
+
+def bn_backward_coefs(lib, slab, rows, hid, n_nodes, training, sync_group, count_block, sp, dev):
+    """(dgamma, dbeta, bwc = c1|c2) from the backward statistics slab.  With a sync group the sums
+    are all-reduced for c1|c2 while dgamma/dbeta stay the rank-local sums (the gradient all-reduce
+    averages them), exactly like torch's SyncBatchNorm."""
+    import torch.distributed as dist
+    dgamma, dbeta, bwc = _f32(dev, hid), _f32(dev, hid), _f32(dev, 2 * hid)
+    if sync_group is None or count_block is None:
+        _lib.check(lib.cgnn_bn_act_bwd_finalize(_lib.ptr(slab), rows, hid, float(max(n_nodes, 1)), None,
+                                                int(not training), _lib.ptr(dgamma), _lib.ptr(dbeta),
+                                                _lib.ptr(bwc), sp), "cgnn_bn_act_bwd_finalize")
+        return dgamma, dbeta, bwc
+    sums = torch.sum(slab[:rows], dim=0)                       # fp64 [2H] = sum dZ | sum dZ*xhat
+    local_dbeta, local_dgamma = sums[:hid].float(), sums[hid:].float()
+    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=sync_group)
+    _lib.check(lib.cgnn_bn_act_bwd_finalize(_lib.ptr(sums), 1, hid, 0.0,
+                                            count_block.data_ptr() + 8 * 2 * hid, int(not training),
+                                            _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(bwc), sp),
+               "cgnn_bn_act_bwd_finalize")
+    return local_dgamma, local_dbeta, bwc
 
 
 def _linear_fwd_stats(lib, x1, x2, w, b, grid, relu: bool = True):
@@ -106,6 +168,7 @@ class SageEncode(torch.autograd.Function):
         sv.norm = s.sage_norm(backward_coef=False)
         sv.xs, sv.aggs, sv.zs, sv.coefs, sv.masks, sv.ws = [], [], [], [], [], []
         sv.xa0 = None
+        sv.sync_group, sv.count_block = cfg.get("sync_group"), None
         with _lib.device_guard(dev):
             if rng is not None and p > 0:
                 _lib.check(lib.cgnn_rng_advance(_lib.ptr(rng), L + 1, st()), "cgnn_rng_advance")
@@ -143,14 +206,9 @@ class SageEncode(torch.autograd.Function):
                         srows = rows
                         _lib.check(lib.cgnn_bn_act_fwd_stats(_lib.ptr(z), n_nodes, hid, _lib.ptr(slab), st()),
                                    "cgnn_bn_act_fwd_stats")
-                bn = bns_mod[li]
-                coef = _f32(dev, 4 * hid)
-                _lib.check(lib.cgnn_bn_act_finalize(
-                    _lib.ptr(slab), srows, hid, float(max(n_nodes, 1)), int(training), _lib.ptr(gamma),
-                    _lib.ptr(beta), _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var),
-                    float(bn.momentum), float(bn.eps),
-                    _lib.ptr(bn.num_batches_tracked) if training else None, _lib.ptr(coef), st()),
-                    "cgnn_bn_act_finalize")
+                coef, blk = bn_forward_coef(lib, slab, srows, hid, n_nodes, training, gamma, beta,
+                                            bns_mod[li], sv.sync_group, st(), dev)
+                sv.count_block = blk if blk is not None else sv.count_block
                 mask = torch.empty(n_nodes * (hid // 4), dtype=torch.uint8, device=dev) if p > 0 else None
                 seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0
                 rw = None if (rng is None or p <= 0) else rng.data_ptr() + 4 * li
@@ -193,16 +251,13 @@ class SageEncode(torch.autograd.Function):
                 hid, fin = w.shape[0], x.shape[1]
                 # ---- BatchNorm + dropout backward, ReLU' of the layer and db in two passes
                 slab = torch.empty(rows, 2 * hid, dtype=torch.float64, device=dev)
-                dgamma, dbeta, bwc = _f32(dev, hid), _f32(dev, hid), _f32(dev, 2 * hid)
                 pool = (_lib.ptr(dP), _lib.ptr(s.node_graph), _lib.ptr(s.gptr)) if li == L - 1 \
                     else (None, None, None)
                 _lib.check(lib.cgnn_bn_act_bwd_stats(_lib.ptr(dx), _lib.ptr(z), _lib.ptr(mask),
                                                      _lib.ptr(coef), 0, sv.p, n_nodes, hid,
                                                      _lib.ptr(slab), *pool, st()), "cgnn_bn_act_bwd_stats")
-                _lib.check(lib.cgnn_bn_act_bwd_finalize(_lib.ptr(slab), rows, hid,
-                                                        float(max(n_nodes, 1)), int(not sv.training),
-                                                        _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(bwc),
-                                                        st()), "cgnn_bn_act_bwd_finalize")
+                dgamma, dbeta, bwc = bn_backward_coefs(lib, slab, rows, hid, n_nodes, sv.training,
+                                                       sv.sync_group, sv.count_block, st(), dev)
                 cs_rows = int(lib.cgnn_bn_act_apply_blocks(n_nodes, hid))
                 cs_slab = torch.empty(cs_rows, hid, dtype=torch.float64, device=dev)
                 dpre = torch.empty_like(z)
@@ -242,5 +297,6 @@ def encode(model, batch, structure: BatchStructure) -> torch.Tensor:
     for conv, bn in zip(model.convs, model.batch_norms):
         params += [conv.linear.weight, conv.linear.bias, bn.weight, bn.bias]
     cfg = {"structure": structure, "batch_norms": list(model.batch_norms), "training": model.training,
-           "dropout": float(model.dropout), "rng_state": getattr(model, "rng_device_state", None)}
+           "dropout": float(model.dropout), "rng_state": getattr(model, "rng_device_state", None),
+           "sync_group": sync_group_of(model)}
     return SageEncode.apply(batch.node_features, cfg, *params)

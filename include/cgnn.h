@@ -401,7 +401,11 @@ int cgnn_slab_reduce_f64(const double* slab, int32_t rows, int32_t width, float*
 int cgnn_bn_act_width_ok(int32_t N);
 int64_t cgnn_bn_act_slab_rows(int64_t M);
 int cgnn_bn_act_fwd_stats(const float* Y, int64_t M, int32_t N, double* slab, void* stream);
-int cgnn_bn_act_finalize(const double* slab, int32_t rows, int32_t N, double count, int32_t training,
+/* count_dev (nullable): the row count read from device memory instead of `count` -- under
+ * full-batch BatchNorm across ranks the caller all-reduces [sum | sumsq | rows] and passes the
+ * reduced block as a 1-row slab with count_dev = &block[2N]; nothing returns to the host. */
+int cgnn_bn_act_finalize(const double* slab, int32_t rows, int32_t N, double count,
+                         const double* count_dev, int32_t training,
                          const float* gamma, const float* beta, float* running_mean,
                          float* running_var, float momentum, float eps,
                          int64_t* num_batches_tracked, float* coef, void* stream);
@@ -420,8 +424,8 @@ int cgnn_bn_act_bwd_stats(const float* dX, const float* Y, const uint8_t* mask, 
                           const float* dP, const int32_t* node_graph, const int32_t* gptr,
                           void* stream);
 int cgnn_bn_act_bwd_finalize(const double* slab, int32_t rows, int32_t N, double count,
-                             int32_t zero_coef, float* dgamma, float* dbeta, float* bwc,
-                             void* stream);
+                             const double* count_dev, int32_t zero_coef, float* dgamma,
+                             float* dbeta, float* bwc, void* stream);
 /* relu_in != 0: Y is itself the output of a ReLU (SAGELayer, models.py:152): dY is additionally
  * masked by Y > 0, i.e. it is the gradient of the layer's pre-activation.  colsum_slab (nullable):
  * fp64 [cgnn_bn_act_apply_blocks(M, N)][N] per-block column sums of dY (the bias gradient),

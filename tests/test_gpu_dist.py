@@ -20,7 +20,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q):
+def _make(kind):
+    import connectome_gnn_amd as C
+    cls, hidden = {"gcn64": (C.GCNConnectome, 64), "gcn128": (C.GCNConnectome, 128),
+                   "sage64": (C.GraphSAGEConnectome, 64)}[kind]
+    return cls(5, hidden, dropout=0.0)
+
+
+def _worker(rank, world, port, q, kind="gcn64"):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK="0")
@@ -33,7 +40,7 @@ def _worker(rank, world, port, q):
         torch.cuda.set_device(0)
         graphs = C.generate_dataset(8, 84, 8, seed=21)
         torch.manual_seed(5)
-        model = C.GCNConnectome(5, 64, dropout=0.0).to("cuda").train()
+        model = _make(kind).to("cuda").train()
         cdist.broadcast_parameters(model)
         model = cdist.convert_sync_batchnorm(model)
         sync = cdist.GradSync(model.parameters())
@@ -62,11 +69,13 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_sync_bn_equals_single_process_full_batch():
+@pytest.mark.parametrize("kind", ["gcn64", "gcn128", "sage64"])
+def test_two_rank_sync_bn_equals_single_process_full_batch(kind):
+    """All three one-node encoders (per-tile GCN, wide GCN, GraphSAGE) under SyncBatchNorm."""
     import connectome_gnn_amd as C
     graphs = C.generate_dataset(8, 84, 8, seed=21)
     torch.manual_seed(5)
-    ref = C.GCNConnectome(5, 64, dropout=0.0).to("cuda").train()
+    ref = _make(kind).to("cuda").train()
     full = C.collate_graphs(graphs).to("cuda")
     lg = ref(full)
     torch.nn.functional.cross_entropy(lg, full.labels).backward()
@@ -74,7 +83,7 @@ def test_two_rank_sync_bn_equals_single_process_full_batch():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, kind)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=240) for _ in procs)
