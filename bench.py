@@ -232,14 +232,17 @@ def main() -> None:
         # HBM bytes per launch of that kernel from the PMC passes kept under profiles/ (collected
         # offline with rocprofv3 --pmc on this same command; null for other workloads)
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_fused_pmc_traffic.json")
-        if impl_used == "fused" and os.path.exists(pmc) and bsz == 4096:
-            doc = json.load(open(pmc))
-            if doc.get("workload") == args.workload:
-                # the timed launches are one of each backward variant per step -> their mean
-                v = [doc["kernels"].get(k, {}).get("hbm_bytes_per_launch")
-                     for k in ("k_gcn_bwd<384, false, false>", "k_gcn_bwd<384, false, true>")]
-                if all(v):
+        pmc_files = {"cfg4-headline-gcn-4096x360-h64": ("r01_fused_pmc_traffic.json", 4096,
+                                                         ("k_gcn_bwd<384, false, false>", "k_gcn_bwd<384, false, true>")),
+                     "cfg3-sage-512x360-h128": ("r01_cfg3_pmc_traffic.json", 512, ("k_agg_tiled",))}
+        if args.workload in pmc_files and impl_used == "fused":
+            fname, pmc_bsz, keys = pmc_files[args.workload]
+            pmc = os.path.join(ROOT, "profiles", fname)
+            if os.path.exists(pmc) and bsz == pmc_bsz:
+                doc = json.load(open(pmc))
+                # mean over the kernel variants that the timed launches consist of
+                v = [doc["kernels"].get(k, {}).get("hbm_bytes_per_launch") for k in keys]
+                if doc.get("workload") == args.workload and all(v):
                     traffic = sum(v) / len(v)
         out = {
             "metric": "training graphs/sec, 3-layer GCN, batch=4096x360-ROI connectomes"
