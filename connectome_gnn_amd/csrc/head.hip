@@ -104,6 +104,14 @@ __global__ void __launch_bounds__(HTHR) k_head_bwd(
   const int j = threadIdx.x % H2, rr = threadIdx.x / H2;
   for (int r0 = blockIdx.x * RB; r0 < B; r0 += gridDim.x * RB) {
     __syncthreads();
+    // every global load of this row group is issued before the first barrier (the kernel is a
+    // chain of dependent round trips otherwise)
+    const int rmine = r0 + rr;
+    float fv = 0.f, hv = 0.f;
+    if (rr < RB && rmine < B) {
+      fv = fac[(int64_t)rmine * H2 + j];
+      hv = H1[(int64_t)rmine * H2 + j];
+    }
     for (int i = threadIdx.x; i < RB * H; i += HTHR) {
       const int r = r0 + i / H;
       pl[i] = r < B ? P[(int64_t)r * H + i % H] : 0.f;
@@ -114,12 +122,10 @@ __global__ void __launch_bounds__(HTHR) k_head_bwd(
     }
     __syncthreads();
     if (rr < RB) {
-      const int r = r0 + rr;
-      float d = 0.f, hv = 0.f;
-      if (r < B) {
+      float d = 0.f;
+      if (rmine < B) {
         for (int c = 0; c < C; ++c) d = fmaf(dl[rr * C + c], W2[c * H2 + j], d);
-        d *= fac[(int64_t)r * H2 + j];
-        hv = H1[(int64_t)r * H2 + j];
+        d *= fv;
       }
       dh[rr * H2 + j] = d;
       hl[rr * H2 + j] = hv;
