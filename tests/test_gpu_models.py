@@ -544,3 +544,61 @@ def test_resident_loader_prefetch_is_equivalent():
         assert na == nb and torch.equal(la, lb) and torch.equal(ea, eb)
     assert runs[0][1] == runs[1][1]
     assert all(torch.equal(a, c) for a, c in zip(runs[0][2], runs[1][2]))
+
+
+@pytest.mark.parametrize("trial", range(10))
+def test_models_random_batches_vs_oracle(trial):
+    """Random ragged batches (graphs of 1..384 nodes, mixed degrees, both models, hidden 64/128)
+    against the oracle: logits within 1e-5 of the scale; every gradient within 1e-5 of its
+    tensor's scale of the fp32 oracle, or at least as close to the oracle evaluated in fp64 as the
+    fp32 oracle itself (degenerate graphs make BatchNorm ill-conditioned in any fp32 arithmetic)."""
+    import random
+    import connectome_gnn_amd as C
+    rnd = random.Random(1000 + trial)
+    kind = rnd.choice(["gcn", "sage"])
+    hidden = rnd.choice([64, 128])
+    graphs = []
+    for g in range(rnd.randint(2, 10)):
+        n = rnd.choice([1, 2, 3, 17, 40, 84, 100, 200, 360, 384])
+        if n <= 3:
+            ei = torch.tensor([[0], [n - 1]], dtype=torch.long) if n > 1 else torch.zeros(2, 0, dtype=torch.long)
+            gen = torch.Generator().manual_seed(trial * 100 + g)
+            graphs.append(C.ConnectomeGraph(torch.randn(n, 5, generator=gen), ei,
+                                            torch.rand(ei.shape[1], generator=gen) + 0.1, torch.tensor(g % 2)))
+        else:
+            k = min(rnd.choice([2, 4, 6, 8, 14]), max(2, (n - 1) // 2 * 2))
+            graphs.append(C.generate_connectome(n, k, seed=trial * 100 + g))
+    b = C.collate_graphs(graphs)
+    torch.manual_seed(trial)
+    m = _model(kind, 5, hidden, dropout=0.0)
+
+    def oracle(dt):
+        torch.set_default_dtype(dt)
+        try:
+            st = O.require_grad({k_: (v.clone().to(dt) if v.is_floating_point() else v.clone())
+                                 for k_, v in m.state_dict().items()})
+            ob = O.OBatch(b.node_features.to(dt), b.edge_index, b.edge_weight.to(dt), b.batch, b.labels, b.ptr)
+            lo = O.FORWARD[kind](st, ob, 0.0, True)
+            torch.nn.functional.cross_entropy(lo, ob.labels).backward()
+        finally:
+            torch.set_default_dtype(torch.float32)
+        return lo.detach(), {k_: v.grad for k_, v in st.items() if v.grad is not None}
+
+    lo, g32 = oracle(torch.float32)
+    lo64, g64 = oracle(torch.float64)
+    m = m.to(DEV).train()
+    bd = b.to(DEV)
+    lg = m(bd)
+    torch.nn.functional.cross_entropy(lg, bd.labels).backward()
+    assert m.impl_used == "fused"
+    scale = float(lo.abs().max()) + 1e-6
+    err_l = float((lg.detach().cpu() - lo).abs().max())
+    assert err_l <= 1e-5 * scale + 1e-6 or \
+        float((lg.detach().cpu().double() - lo64).abs().max()) <= float((lo.double() - lo64).abs().max()) + 1e-9
+    for k_, p in m.named_parameters():
+        w, got = g32[k_], p.grad.cpu()
+        if float((got - w).abs().max()) <= 1e-5 * float(w.abs().max()) + 2e-6:
+            continue
+        err_gpu = float((got.double() - g64[k_]).abs().max())
+        err_cpu = float((w.double() - g64[k_]).abs().max())
+        assert err_gpu <= 2 * err_cpu + 1e-7, f"{k_}: GPU {err_gpu:.2e} vs fp32 oracle {err_cpu:.2e} from fp64"
