@@ -172,6 +172,45 @@ def stream_ptr(device=None) -> int:
 
 
 # ---------------------------------------------------------------------------------------------
+# Dropout seeds.  The mask kernels are counter-based hashes keyed by a 62-bit seed per launch.
+# A seed is (seed, offset) of the device's default torch CUDA generator, whose offset is then
+# advanced -- what torch's own CUDA dropout consumes.  So ``torch.manual_seed(s)`` makes the
+# dropout draw reproducible, and the global CPU generator, from which the loaders' shuffles draw
+# (graph.py, reference graph.py:192-194), is never touched: it stays in lockstep across
+# data-parallel ranks whatever execution path each rank's shard takes.  While a stream is being
+# captured the generator may not be queried; the seed (frozen into the graph anyway, fresh masks
+# per replay come from the device key word, graphed.py) then comes from a private CPU generator.
+# ---------------------------------------------------------------------------------------------
+_capture_gen = None
+
+
+def _mix64(x: int) -> int:
+    x &= 0xFFFFFFFFFFFFFFFF
+    x ^= x >> 30
+    x = (x * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    x ^= x >> 27
+    x = (x * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return x ^ (x >> 31)
+
+
+def next_seed(device=None) -> int:
+    import torch
+    global _capture_gen
+    if torch.cuda.is_current_stream_capturing():
+        if _capture_gen is None:
+            _capture_gen = torch.Generator()
+            _capture_gen.manual_seed(_mix64(torch.initial_seed()) >> 1)
+        return int(torch.randint(0, 2 ** 62, (1,), generator=_capture_gen).item())
+    idx = getattr(device, "index", None)
+    if idx is None:
+        idx = torch.cuda.current_device()
+    gen = torch.cuda.default_generators[idx]
+    off = gen.get_offset()
+    gen.set_offset(off + 4)                       # philox offsets advance in multiples of 4
+    return _mix64(_mix64(gen.initial_seed()) + off) >> 2
+
+
+# ---------------------------------------------------------------------------------------------
 # Optional per-kernel timing for bench.py's roofline line: HIP events recorded on the stream
 # the kernel is launched on, around selected C-ABI calls.  Off (zero overhead) by default.
 # ---------------------------------------------------------------------------------------------

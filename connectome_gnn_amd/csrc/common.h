@@ -13,6 +13,15 @@
 
 static inline hipStream_t cgnn_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Per-device lazily-initialised state (function attributes, CU counts) is indexed by the current
+// device ordinal: one process may drive several GPUs.
+#define CGNN_MAX_DEVICES 64
+static inline int cgnn_device_ordinal() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= CGNN_MAX_DEVICES) return 0;
+  return d;
+}
+
 static inline int64_t cgnn_align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
 // Wave-uniform value made provably uniform for the compiler (-> SGPR, scalar loads).

@@ -208,7 +208,8 @@ int cgnn_dense_aggregate_f16(const void* M, int32_t P, const int32_t* gptr, int3
   if (num_graphs == 0) return CGNN_OK;
   if (!M || !gptr || !X || !Y) return CGNN_EINVAL;
   const size_t lds = (size_t)64 * d_kp(P) * sizeof(__half);
-  static bool attr_set = false;
+  static bool attr_set_dev[CGNN_MAX_DEVICES] = {};
+  bool& attr_set = attr_set_dev[cgnn_device_ordinal()];
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_dense_agg),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 64 * d_kp(D_MAXP) * 2) != hipSuccess)

@@ -42,7 +42,9 @@ DropCfg make_drop(float p, uint64_t seed, int* use_drop) {
   double thr = (double)p * 65536.0 + 0.5;
   if (thr > 65535.0) thr = 65535.0;
   d.thr16 = (uint32_t)thr;
-  d.scale = p > 0.f ? (float)(1.0 / (1.0 - (double)d.thr16 / 65536.0)) : 1.0f;
+  // the reference's scale, 1/(1-p) (aten::native_dropout), not 1/(realised keep rate): with
+  // replayed keep bits the arithmetic then matches the oracle to rounding
+  d.scale = p > 0.f ? (float)(1.0 / (1.0 - (double)p)) : 1.0f;
   d.key0 = (uint32_t)(seed & 0xFFFFFFFFu) * 0x9E3779B9u + 0x85EBCA6Bu;
   d.key1 = (uint32_t)(seed >> 32) ^ 0xC2B2AE35u;
   d.dev_key = nullptr;

@@ -960,17 +960,17 @@ __global__ void __launch_bounds__(256) k_dw_db_reduce(const float* __restrict__ 
   }
 }
 
-int g_grid_cache = 0;
+int g_grid_cache[CGNN_MAX_DEVICES] = {};
 
 int fused_grid() {
-  if (g_grid_cache == 0) {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 256;
+  const int dev = cgnn_device_ordinal();
+  if (g_grid_cache[dev] == 0) {
+    int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
       return 256;
-    g_grid_cache = cus;
+    g_grid_cache[dev] = cus;
   }
-  return g_grid_cache;
+  return g_grid_cache[dev];
 }
 
 DropCfg make_drop(float p, uint64_t seed, int* use_drop) {
@@ -979,7 +979,9 @@ DropCfg make_drop(float p, uint64_t seed, int* use_drop) {
   double thr = (double)p * 65536.0 + 0.5;
   if (thr > 65535.0) thr = 65535.0;
   d.thr16 = (uint32_t)thr;
-  d.scale = p > 0.f ? (float)(1.0 / (1.0 - (double)d.thr16 / 65536.0)) : 1.0f;
+  // the reference's scale, 1/(1-p) (aten::native_dropout), not 1/(realised keep rate): with
+  // replayed keep bits the arithmetic then matches the oracle to rounding
+  d.scale = p > 0.f ? (float)(1.0 / (1.0 - (double)p)) : 1.0f;
   d.key0 = (uint32_t)(seed & 0xFFFFFFFFu) * 0x9E3779B9u + 0x85EBCA6Bu;
   d.key1 = (uint32_t)(seed >> 32) ^ 0xC2B2AE35u;
   d.dev_key = nullptr;

@@ -174,36 +174,67 @@ __global__ void __launch_bounds__(HTHR) k_head_bwd(
 // ----------------------------------------------------------- mean cross-entropy over the batch
 // loss = mean_i ( logsumexp(logits[i,:]) - logits[i, label_i] )   (torch CrossEntropyLoss defaults,
 // reference train.py:39,49); also leaves dlogits for a unit upstream gradient:
-// (softmax(logits[i,:]) - onehot(label_i)) / B.  One workgroup; rows summed in fp64, fixed order.
+// (softmax(logits[i,:]) - onehot(label_i)) / V.  torch's defaults include ignore_index = -100:
+// such rows add nothing, get a zero gradient, and V counts the other rows (V = 0 -> NaN like
+// torch).  Any other label outside [0, C) makes torch raise; a kernel cannot, so the loss and
+// that row's gradient become NaN -- loud, and visible at the epoch's single read-back.
+// One workgroup; rows summed in fp64, fixed order.
 constexpr int CETHR = 1024;
+constexpr int CE_IGNORE = -100;
 
 __global__ void __launch_bounds__(CETHR) k_ce_fwd(const float* __restrict__ logits,
                                                   const int64_t* __restrict__ labels, int B, int C,
                                                   float* __restrict__ loss,
                                                   float* __restrict__ dlogits) {
   __shared__ double red[CETHR];
+  __shared__ int cnt[CETHR];
   double acc = 0.0;
-  const float invb = 1.0f / (float)B;
+  int valid = 0, bad = 0;
   for (int i = threadIdx.x; i < B; i += CETHR) {
+    const int64_t lab = labels[i];
+    if (lab == CE_IGNORE) continue;
+    if (lab < 0 || lab >= C) { bad = 1; continue; }
     const float* row = logits + (int64_t)i * C;
     float m = row[0];
     for (int c = 1; c < C; ++c) m = fmaxf(m, row[c]);
     float se = 0.f;
     for (int c = 0; c < C; ++c) se += expf(row[c] - m);
-    const float lse = m + logf(se);
-    const int lab = (int)labels[i];
-    const bool ok = lab >= 0 && lab < C;
-    acc += ok ? (double)(lse - row[lab]) : 0.0;
-    for (int c = 0; c < C; ++c)
-      dlogits[(int64_t)i * C + c] = (expf(row[c] - lse) - ((ok && c == lab) ? 1.f : 0.f)) * invb;
+    acc += (double)(m + logf(se) - row[lab]);
+    ++valid;
   }
   red[threadIdx.x] = acc;
+  cnt[threadIdx.x] = valid | (bad << 30);
   __syncthreads();
   for (int s = CETHR / 2; s > 0; s >>= 1) {
-    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    if (threadIdx.x < s) {
+      red[threadIdx.x] += red[threadIdx.x + s];
+      const int a = cnt[threadIdx.x], b = cnt[threadIdx.x + s];
+      cnt[threadIdx.x] = ((a & 0x3FFFFFFF) + (b & 0x3FFFFFFF)) | ((a | b) & (1 << 30));
+    }
     __syncthreads();
   }
-  if (threadIdx.x == 0) loss[0] = (float)(red[0] / (double)B);
+  const int total = cnt[0] & 0x3FFFFFFF;
+  const bool any_bad = (cnt[0] >> 30) & 1;
+  const float nanv = __int_as_float(0x7FC00000);
+  if (threadIdx.x == 0) loss[0] = any_bad ? nanv : (float)(red[0] / (double)total);
+  const float invv = 1.0f / (float)total;
+  for (int i = threadIdx.x; i < B; i += CETHR) {
+    const int64_t lab = labels[i];
+    const float* row = logits + (int64_t)i * C;
+    float* drow = dlogits + (int64_t)i * C;
+    if (lab == CE_IGNORE) {
+      for (int c = 0; c < C; ++c) drow[c] = 0.f;
+    } else if (lab < 0 || lab >= C) {
+      for (int c = 0; c < C; ++c) drow[c] = nanv;
+    } else {
+      float m = row[0];
+      for (int c = 1; c < C; ++c) m = fmaxf(m, row[c]);
+      float se = 0.f;
+      for (int c = 0; c < C; ++c) se += expf(row[c] - m);
+      const float lse = m + logf(se);
+      for (int c = 0; c < C; ++c) drow[c] = (expf(row[c] - lse) - (c == (int)lab ? 1.f : 0.f)) * invv;
+    }
+  }
 }
 
 bool head_ok(int H, int H2, int C) {
@@ -238,7 +269,7 @@ int cgnn_head_fwd_f32(const float* P, int32_t B, int32_t H, int32_t H2, int32_t 
   double thr = (double)p_drop * 65536.0 + 0.5;
   if (thr > 65535.0) thr = 65535.0;
   d.thr16 = (uint32_t)thr;
-  d.scale = p_drop > 0.f ? (float)(1.0 / (1.0 - (double)d.thr16 / 65536.0)) : 1.0f;
+  d.scale = p_drop > 0.f ? (float)(1.0 / (1.0 - (double)p_drop)) : 1.0f;   // reference: 1/(1-p)
   d.key0 = (uint32_t)(seed & 0xFFFFFFFFu) * 0x9E3779B9u + 0x7F4A7C15u;
   d.key1 = (uint32_t)(seed >> 32) ^ 0x94D049BBu;
   d.dev_key = seed_dev;

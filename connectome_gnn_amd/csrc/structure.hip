@@ -499,7 +499,8 @@ int cgnn_csr_build_grouped(const int64_t* edge_index, const int32_t* gptr, const
   const size_t lds = sizeof(int32_t) * 4 * ((size_t)max_nodes + 1) + sizeof(uint16_t) * 4 * (size_t)max_edges;
   constexpr size_t kMaxLds = 128 * 1024;
   if (max_nodes > 1024 || max_edges >= 65535 || lds > kMaxLds || num_graphs == 0) return CGNN_EUNSUPPORTED;
-  static bool attr_set = false;
+  static bool attr_set_dev[CGNN_MAX_DEVICES] = {};
+  bool& attr_set = attr_set_dev[cgnn_device_ordinal()];
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_csr_grouped),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds) != hipSuccess)

@@ -45,6 +45,12 @@ class GradSync:
     gradient_as_bucket_view), so a step costs one memset (``zero_grad``), backward accumulating
     in place, and one all-reduce -- no flatten/unflatten copy kernels.  Use
     ``sync.zero_grad()`` instead of ``optimizer.zero_grad()`` (which would drop the views).
+
+    Unequal shards (a global batch that does not divide by the world size -- every partial tail
+    of the sharded loaders): ``sync(local_graphs=n_r)`` turns the update into the exact
+    global-batch gradient  sum_r n_r g_r / sum_r n_r.  The count rides in one extra word at the
+    end of the flat buffer, so it is still a single collective and nothing returns to the host
+    (the whole step stays capturable in a HIP graph).
     """
 
     def __init__(self, params: Iterable[torch.nn.Parameter], group=None):
@@ -52,7 +58,9 @@ class GradSync:
         self.group = group
         n = sum(p.numel() for p in self.params)
         ref = self.params[0]
-        self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
+        self.numel = n
+        self._buf = torch.zeros(n + 1, dtype=ref.dtype, device=ref.device)   # [grads | graph count]
+        self.flat = self._buf[:n]
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._avg = dist.is_initialized() and dist.get_backend(group) == "nccl"   # RCCL has AVG
         self._attach()
@@ -76,8 +84,9 @@ class GradSync:
             off += n
 
     def __call__(self, local_graphs: Optional[int] = None, global_graphs: Optional[int] = None):
-        """Call between ``loss.backward()`` and ``optimizer.step()``.
-        With unequal shards pass this rank's and the global graph counts."""
+        """Call between ``loss.backward()`` and ``optimizer.step()``.  ``local_graphs``: this
+        rank's graph count when shards may be unequal (``global_graphs`` is accepted for
+        compatibility and ignored: the total is summed by the same all-reduce)."""
         if self.world == 1:
             return
         off = 0
@@ -88,14 +97,35 @@ class GradSync:
                 self.flat[off:off + n].copy_(g.reshape(-1))
                 p.grad = self.flat[off:off + n].view_as(p)
             off += n
-        if local_graphs is not None and global_graphs:
-            self.flat.mul_(float(local_graphs) / float(global_graphs))
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        if local_graphs is not None:
+            self.flat.mul_(float(local_graphs))
+            self._buf[self.numel:].fill_(float(local_graphs))
+            dist.all_reduce(self._buf, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat.div_(self._buf[self.numel:])
         elif self._avg:
             dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group)
         else:
             self.flat.mul_(1.0 / self.world)
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+
+
+def agree(flag: bool, device, group=None) -> bool:
+    """True iff ``flag`` is True on EVERY rank (one tiny all-reduce + read-back; callers cache the
+    answer per batch).  Used to keep all ranks on the same execution path: under sync-BN the
+    fused and the layered encoders issue different collectives, and a mismatch would hang."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return flag
+    dev = device if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t.item()))
+
+
+def reduce_sums(values: torch.Tensor, group=None) -> torch.Tensor:
+    """Sum a small tally vector over ranks (loss / hit / graph counts of an epoch)."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(values, op=dist.ReduceOp.SUM, group=group)
+    return values
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> None:

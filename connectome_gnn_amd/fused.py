@@ -122,7 +122,7 @@ class FusedGCNEncode(torch.autograd.Function):
                             _lib.ptr(stat_slab), st()), "cgnn_gcn_fused_fwd_first")
                 else:
                     mask = torch.empty(nn_ * 16, dtype=torch.uint8, device=dev) if p > 0 else None
-                    seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0
+                    seed = _lib.next_seed(dev) if p > 0 else 0
                     with _lib.timed("cgnn_gcn_fused_fwd"):
                         _lib.check(lib.cgnn_gcn_fused_fwd(
                             tp, _lib.ptr(ys[-1]), _lib.ptr(bns[-1]), p, seed, rng_ptr(l), _lib.ptr(mask),
@@ -159,7 +159,7 @@ class FusedGCNEncode(torch.autograd.Function):
                 ys.append(y)
                 bns.append(bn)
             mask = torch.empty(nn_ * 16, dtype=torch.uint8, device=dev) if p > 0 else None
-            seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0
+            seed = _lib.next_seed(dev) if p > 0 else 0
             pooled = torch.empty(B, HID, **f32)
             _lib.check(lib.cgnn_gcn_fused_pool_fwd(
                 _lib.ptr(ys[-1]), _lib.ptr(bns[-1]), p, seed, rng_ptr(L), _lib.ptr(mask), _lib.ptr(s.gptr), B,
@@ -170,6 +170,8 @@ class FusedGCNEncode(torch.autograd.Function):
         c.ys, c.bns, c.masks, c.p, c.x0, c.f0, c.p0 = ys, bns, masks, p, x0, x0.shape[1], p0
         c.count, c.sync_group, c.num_layers, c.training = count, sync_group, L, training
         c.count_dev = count_dev
+        if meta.get("record") is not None:
+            meta["record"]["layers"] = list(masks)
         ctx.c = c
         ctx.save_for_backward(*params)
         return pooled
@@ -284,5 +286,5 @@ def encode(model, batch, structure: BatchStructure) -> torch.Tensor:
             sync_group = bn.process_group if bn.process_group is not None else dist.group.WORLD
     meta = {"structure": structure, "batch_norms": list(model.batch_norms),
             "training": model.training, "dropout": float(model.dropout), "sync_group": sync_group,
-            "rng_state": getattr(model, "rng_device_state", None)}
+            "rng_state": getattr(model, "rng_device_state", None), "record": model._dropout_record()}
     return FusedGCNEncode.apply(batch.node_features, meta, *params)

@@ -114,7 +114,7 @@ class GcnWideEncode(torch.autograd.Function):
                                             bns_mod[li], sv.sync_group, st(), dev)
                 sv.count_block = blk if blk is not None else sv.count_block
                 mask = torch.empty(n_nodes * (hid // 4), dtype=torch.uint8, device=dev) if p > 0 else None
-                seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0
+                seed = _lib.next_seed(dev) if p > 0 else 0
                 rw = None if (rng is None or p <= 0) else rng.data_ptr() + 4 * li
                 sv.xs.append(x); sv.ys.append(y); sv.coefs.append(coef); sv.masks.append(mask); sv.ws.append(w)
                 if li == L - 1:
@@ -128,6 +128,8 @@ class GcnWideEncode(torch.autograd.Function):
                                                      _lib.ptr(mask), _lib.ptr(xn), n_nodes, hid, st()),
                            "cgnn_bn_act_fwd_apply")
                 x = xn
+        if cfg.get("record") is not None:
+            cfg["record"]["layers"] = list(sv.masks)
         ctx.sv = sv
         ctx.L = L
         return pooled
@@ -194,5 +196,5 @@ def encode(model, batch, structure: BatchStructure) -> torch.Tensor:
         params += [conv.linear.weight, conv.bias, bn.weight, bn.bias]
     cfg = {"structure": structure, "batch_norms": list(model.batch_norms), "training": model.training,
            "dropout": float(model.dropout), "rng_state": getattr(model, "rng_device_state", None),
-           "sync_group": sync_group_of(model)}
+           "sync_group": sync_group_of(model), "record": model._dropout_record()}
     return GcnWideEncode.apply(batch.node_features, cfg, *params)

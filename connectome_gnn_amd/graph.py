@@ -72,6 +72,7 @@ class ConnectomeBatch:
     labels: Optional[torch.Tensor]
     ptr: torch.Tensor
     _structure: object = field(default=None, init=False, repr=False, compare=False)
+    _structure_key: object = field(default=None, init=False, repr=False, compare=False)
     # host int64 [B+1]: edges of graph g are the COO run [_eptr[g], _eptr[g+1]) -- set by
     # collate_graphs / the resident assembler, lets the structure be built per graph in LDS
     _eptr: object = field(default=None, init=False, repr=False, compare=False)
@@ -91,15 +92,33 @@ class ConnectomeBatch:
                               self.ptr.to(device))
         # the cached structure stays valid if nothing moved
         if out.edge_index.data_ptr() == self.edge_index.data_ptr():
-            out._structure = self._structure
+            out._structure, out._structure_key = self._structure, self._structure_key
         out._eptr = self._eptr
         return out
 
+    def _edge_key(self):
+        """Identity + in-place version of the edge tensors the cached structure was built from."""
+        ei, ew = self.edge_index, self.edge_weight
+        return (ei.data_ptr(), ei._version, tuple(ei.shape), ew.data_ptr(), ew._version)
+
+    def invalidate(self) -> None:
+        """Drop the cached device structure (call after changing edges through ``.data`` or other
+        routes that bypass torch's version counter)."""
+        self._structure = self._structure_key = None
+
     def structure(self):
-        """Device CSR of this batch (built once, by HIP kernels; see structure.py)."""
-        if self._structure is None:
+        """Device CSR / blocked-ELL of this batch, built once by HIP kernels (structure.py) and
+        cached.  The cache bakes in the edge list AND the edge weights; it is keyed on the edge
+        tensors' storage and in-place version counters, so reassigning ``edge_index`` /
+        ``edge_weight`` or mutating them in place (edge dropout, augmentation) rebuilds it --
+        the reference re-derives everything on every call (models.py:90-108)."""
+        key = self._edge_key()
+        if self._structure is None or self._structure_key != key:
             from .structure import BatchStructure
+            if self._structure is not None:
+                self._eptr = None            # the per-graph edge offsets described the old COO
             self._structure = BatchStructure.build(self)
+            self._structure_key = key
         return self._structure
 
 

@@ -128,6 +128,11 @@ class _ConnectomeModel(nn.Module):
         self.impl = impl              # execution path; not part of the reference API/state_dict
         self.impl_used = None
         self.rng_device_state = None  # uint32 device words for graph-captured dropout (graphed.py)
+        # parity hook: when True, every training forward leaves the dropout keep decisions it drew
+        # in ``last_dropout`` ({"layers": [uint8 keep bits per layer], "head_factor": [B,H/2]}), so a
+        # test can replay the same masks through the CPU oracle (tests/test_gpu_models.py)
+        self.record_dropout = False
+        self.last_dropout = None
         widths = [in_channels] + [hidden_dim] * num_layers
         self.convs = nn.ModuleList(self._layer_cls(a, b) for a, b in zip(widths, widths[1:]))
         self.batch_norms = nn.ModuleList(nn.BatchNorm1d(hidden_dim) for _ in range(num_layers))
@@ -139,9 +144,35 @@ class _ConnectomeModel(nn.Module):
     def _post(self, x):
         raise NotImplementedError
 
+    def _dropout_record(self):
+        """Fresh record dict for this forward when ``record_dropout`` is on, else None."""
+        if not (self.record_dropout and self.training and self.dropout > 0):
+            return None
+        if self.last_dropout is None or "layers" in self.last_dropout:
+            self.last_dropout = {}
+        return self.last_dropout
+
+    def _validate(self, batch: ConnectomeBatch) -> None:
+        """The fused encoders hand raw device pointers to the kernels, so what the reference's
+        F.linear would reject (models.py:111,151: fp16/fp64 tensors, a feature width that is not
+        in_channels) is rejected here, before any path is chosen."""
+        x = batch.node_features
+        _require_device(x, "batch.node_features")
+        if x.dtype != torch.float32:
+            raise TypeError(f"batch.node_features must be float32 (the reference is fp32-only), got {x.dtype}")
+        for name, prm in self.named_parameters():
+            if prm.dtype != torch.float32:
+                raise TypeError(f"parameter {name} must be float32, got {prm.dtype}")
+            if not prm.is_cuda:
+                _require_device(prm, f"parameter {name}")
+        fin = self.convs[0].linear.weight.shape[1] // (1 if self._relu_after_bn else 2)
+        if x.dim() != 2 or x.shape[1] != fin:
+            raise ValueError(f"batch.node_features must be [num_nodes, {fin}] (in_channels), got "
+                             f"{tuple(x.shape)}")
+
     def encode(self, batch: ConnectomeBatch) -> torch.Tensor:
         """Graph embeddings [B, hidden] (reference models.py:203-211 / 256-262)."""
-        _require_device(batch.node_features, "batch.node_features")
+        self._validate(batch)
         s = batch.structure()
         if self._try_fused(batch, s):
             self.impl_used = "fused"
@@ -154,12 +185,13 @@ class _ConnectomeModel(nn.Module):
             from . import _lib
             _lib.check(_lib.load().cgnn_rng_advance(_lib.ptr(rng), len(self.convs) + 1,
                                                     _lib.stream_ptr()), "cgnn_rng_advance")
+        rec = self._dropout_record()
         for li, (conv, bn) in enumerate(zip(self.convs, self.batch_norms)):
             x = conv(x, batch.edge_index, batch.edge_weight, structure=s, norm=norm)
             if ops.bn_act_drop_supported(bn, x.shape[1]):
                 # BatchNorm (+ReLU) + dropout in two streaming HIP passes each way
                 x = ops.bn_act_drop(x, bn, self._relu_after_bn, self.dropout, self.training,
-                                    None if rng is None else rng.data_ptr() + 4 * li)
+                                    None if rng is None else rng.data_ptr() + 4 * li, rec)
             else:                     # SyncBatchNorm / odd widths: torch ops
                 x = self._post(bn(x))
                 x = F.dropout(x, p=self.dropout, training=self.training)
@@ -172,7 +204,16 @@ class _ConnectomeModel(nn.Module):
             # Linear -> ReLU -> Dropout -> Linear on [B, hidden] in one HIP kernel each way
             rng = getattr(self, "rng_device_state", None)
             word = None if rng is None else rng.data_ptr() + 4 * len(self.convs)
-            return ops.head(self.classifier, pooled, self.training, word)
+            rec = self.last_dropout if (self.record_dropout and self.training) else None
+            return ops.head(self.classifier, pooled, self.training, word, rec)
+        if self.record_dropout and self.training and self.last_dropout is not None \
+                and self.dropout > 0 and len(self.classifier) == 4:
+            # parity hook for heads outside head.hip's widths (torch modules): same record format
+            l1, act, drop, l2 = self.classifier
+            h = act(l1(pooled))
+            y = drop(h)
+            self.last_dropout["head_factor"] = ((y != 0) & (h > 0)).float() / (1.0 - drop.p)
+            return l2(y)
         return self.classifier(pooled)
 
     def prepare_batch(self, batch: ConnectomeBatch) -> None:

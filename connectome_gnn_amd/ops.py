@@ -295,7 +295,7 @@ class _BnActDrop(torch.autograd.Function):
     """X' = dropout(act(BatchNorm1d(Y))) in two streaming passes each way (elementwise.hip)."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, bn_mod, relu, p, training, rng_word=None):
+    def forward(ctx, y, gamma, beta, bn_mod, relu, p, training, rng_word=None, record=None):
         lib = _lib.load()
         y = _prep(y, "y")
         m, n = y.shape
@@ -305,7 +305,7 @@ class _BnActDrop(torch.autograd.Function):
         coef = torch.empty(4 * n, **f32)
         x = torch.empty_like(y)
         mask = torch.empty(m * (n // 4), dtype=torch.uint8, device=dev) if p_eff > 0 else None
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p_eff > 0 else 0
+        seed = _lib.next_seed(dev) if p_eff > 0 else 0
         _sp = _lib.stream_ptr(dev)          # one lookup per pass (torch.cuda.current_stream is ~10 us)
         st = lambda: _sp
         with _lib.device_guard(dev):
@@ -324,6 +324,8 @@ class _BnActDrop(torch.autograd.Function):
                                                  rng_word if p_eff > 0 else None,
                                                  _lib.ptr(mask), _lib.ptr(x), m, n, st()),
                        "cgnn_bn_act_fwd_apply")
+        if record is not None:
+            record.setdefault("layers", []).append(mask)
         ctx.save_for_backward(y, coef, mask)
         ctx.cfg = (bool(relu), p_eff, bool(training))
         return x
@@ -355,7 +357,7 @@ class _BnActDrop(torch.autograd.Function):
                                                  _lib.ptr(bwc), int(relu), p_eff, 0, None, _lib.ptr(dy), m, n,
                                                  None, None, None, st()),
                        "cgnn_bn_act_bwd_apply")
-        return dy, dgamma, dbeta, None, None, None, None, None
+        return dy, dgamma, dbeta, None, None, None, None, None, None
 
 
 def bn_act_drop_supported(bn_mod, width: int) -> bool:
@@ -364,16 +366,17 @@ def bn_act_drop_supported(bn_mod, width: int) -> bool:
             and bn_mod.momentum is not None and bool(_lib.load().cgnn_bn_act_width_ok(width)))
 
 
-def bn_act_drop(y, bn_mod, relu: bool, p: float, training: bool, rng_word=None) -> torch.Tensor:
-    """rng_word: device address of a uint32 that a captured cgnn_rng_advance refreshes (graph replay)."""
-    return _BnActDrop.apply(y, bn_mod.weight, bn_mod.bias, bn_mod, relu, p, training, rng_word)
+def bn_act_drop(y, bn_mod, relu: bool, p: float, training: bool, rng_word=None, record=None) -> torch.Tensor:
+    """rng_word: device address of a uint32 that a captured cgnn_rng_advance refreshes (graph replay);
+    record: dict that receives the keep-bit array of this launch (parity tests)."""
+    return _BnActDrop.apply(y, bn_mod.weight, bn_mod.bias, bn_mod, relu, p, training, rng_word, record)
 
 
 class _Head(torch.autograd.Function):
     """logits = Linear2(dropout(relu(Linear1(P)))) in one HIP kernel each way (csrc/head.hip)."""
 
     @staticmethod
-    def forward(ctx, p, w1, b1, w2, b2, p_drop, training, rng_word):
+    def forward(ctx, p, w1, b1, w2, b2, p_drop, training, rng_word, record=None):
         lib = _lib.load()
         p, w1, b1, w2, b2 = (_prep(t, "head tensor") for t in (p, w1, b1, w2, b2))
         bsz, h = p.shape
@@ -381,7 +384,7 @@ class _Head(torch.autograd.Function):
         dev = p.device
         f32 = dict(dtype=torch.float32, device=dev)
         p_eff = float(p_drop) if training else 0.0
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p_eff > 0 else 0
+        seed = _lib.next_seed(dev) if p_eff > 0 else 0
         h1, fac = torch.empty(bsz, h2, **f32), torch.empty(bsz, h2, **f32)
         logits = torch.empty(bsz, c, **f32)
         with _lib.device_guard(dev):
@@ -389,6 +392,8 @@ class _Head(torch.autograd.Function):
                                              _lib.ptr(w2), _lib.ptr(b2), p_eff, seed,
                                              rng_word if p_eff > 0 else None, _lib.ptr(h1), _lib.ptr(fac),
                                              _lib.ptr(logits), _lib.stream_ptr()), "cgnn_head_fwd_f32")
+        if record is not None:
+            record["head_factor"] = fac          # relu'(z) * keep / (1 - p) per hidden unit
         ctx.save_for_backward(p, w1, w2, h1, fac)
         return logits
 
@@ -413,7 +418,7 @@ class _Head(torch.autograd.Function):
                                                 _lib.stream_ptr()), "cgnn_slab_reduce_f32")
         o1, o2, o3 = h2 * h, h2 * h + h2, h2 * h + h2 + c * h2
         return (dp, flat[:o1].view(h2, h), flat[o1:o2], flat[o2:o3].view(c, h2), flat[o3:],
-                None, None, None)
+                None, None, None, None)
 
 
 def head_supported(classifier) -> bool:
@@ -429,9 +434,17 @@ def head_supported(classifier) -> bool:
     return bool(_lib.load().cgnn_head_supported(l1.in_features, l1.out_features, l2.out_features))
 
 
-def head(classifier, pooled, training: bool, rng_word=None) -> torch.Tensor:
+def head(classifier, pooled, training: bool, rng_word=None, record=None) -> torch.Tensor:
     l1, _, drop, l2 = classifier
-    return _Head.apply(pooled, l1.weight, l1.bias, l2.weight, l2.bias, drop.p, training, rng_word)
+    return _Head.apply(pooled, l1.weight, l1.bias, l2.weight, l2.bias, drop.p, training, rng_word, record)
+
+
+def unpack_keep_bits(mask: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
+    """Keep-bit bytes of the dropout kernels -> float {0,1} [rows, cols].  Layout (every mask
+    kernel of the library): byte ``row * cols/4 + chunk``, bit i <-> column ``4*chunk + i``."""
+    m = mask.view(rows, cols // 4, 1).to(torch.int32)
+    bits = (m >> torch.arange(4, device=mask.device, dtype=torch.int32).view(1, 1, 4)) & 1
+    return bits.reshape(rows, cols).to(torch.float32)
 
 
 class _CrossEntropy(torch.autograd.Function):
@@ -467,7 +480,9 @@ def cross_entropy(logits, labels) -> torch.Tensor:
 class CrossEntropyLoss(torch.nn.Module):
     """torch.nn.CrossEntropyLoss() (default arguments: mean reduction, no weights, no smoothing)
     for [B, C] logits on the GPU, as one HIP launch; what the reference's Trainer uses
-    (train.py:39)."""
+    (train.py:39).  ``ignore_index = -100`` rows behave as in torch (no loss, zero gradient, not
+    counted).  One deviation: a label outside [0, C) other than -100 makes torch raise; here the
+    loss becomes NaN instead (raising would need a device-to-host sync on every step)."""
 
     def forward(self, logits, labels):
         return cross_entropy(logits, labels)

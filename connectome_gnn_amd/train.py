@@ -11,7 +11,11 @@ different is how the host and the GPU are kept apart:
   * the criterion is the one-launch HIP cross-entropy (``ops.CrossEntropyLoss``), numerically
     ``torch.nn.CrossEntropyLoss()`` with default arguments;
   * the default device is "cuda" (this package has no CPU path);
-  * data-parallel use: ``grad_sync`` (see dist.GradSync) runs between backward and the step.
+  * data-parallel use: ``grad_sync`` (see dist.GradSync) runs between backward and the step,
+    weighted by this rank's graph count so that unequal shards (partial tails) still give the
+    global-batch gradient; epoch tallies (loss, hits, graphs) are summed over ranks before they
+    are read, so ``history`` and the early-stopping decision are identical on every rank (a rank
+    that stopped alone would leave the others hanging in their next all-reduce).
 """
 from __future__ import annotations
 
@@ -20,6 +24,7 @@ from typing import Callable, Dict, List, Optional
 import torch
 import torch.nn as nn
 
+from . import dist as cdist
 from . import ops
 
 
@@ -63,12 +68,31 @@ class _BestWeights:
 
 class Trainer:
     def __init__(self, model: nn.Module, optimizer: torch.optim.Optimizer, device: str = "cuda",
-                 grad_sync: Optional[Callable[[], None]] = None):
+                 grad_sync: Optional[Callable[[], None]] = None, loss_fn: Optional[nn.Module] = None):
         self.device = device
         self.model = model.to(device)
         self.optimizer = optimizer
-        self.loss_fn = ops.CrossEntropyLoss()
+        self.loss_fn = loss_fn if loss_fn is not None else ops.CrossEntropyLoss()
         self.grad_sync = grad_sync
+
+    def _data_parallel(self) -> bool:
+        return self.grad_sync is not None and torch.distributed.is_initialized() \
+            and torch.distributed.get_world_size(getattr(self.grad_sync, "group", None)) > 1
+
+    def _global_tallies(self, loader, *tallies: "_DeviceTally"):
+        """Per-epoch sums as host floats + the graph count, identical on every rank: summed over
+        ranks when the loader hands each rank its own shard, rank 0's values otherwise."""
+        vals = [t.total if t.total is not None else torch.zeros((), device=self.device) for t in tallies]
+        vec = torch.stack([v.detach().double().reshape(()) for v in vals]
+                          + [torch.tensor(float(tallies[0].graphs), dtype=torch.float64, device=vals[0].device)])
+        if self._data_parallel():
+            group = getattr(self.grad_sync, "group", None)
+            if getattr(loader, "world_size", 1) > 1:
+                vec = cdist.reduce_sums(vec, group)
+            else:
+                torch.distributed.broadcast(vec, src=0, group=group)
+        host = vec.tolist()                                    # the one read-back of the epoch
+        return host[:-1], int(round(host[-1]))
 
     # ------------------------------------------------------------------------------ training
     def train_step(self, batch) -> torch.Tensor:
@@ -80,7 +104,9 @@ class Trainer:
             self.optimizer.zero_grad()
         loss = self.loss_fn(self.model(batch), batch.labels)
         loss.backward()
-        if self.grad_sync is not None:
+        if isinstance(self.grad_sync, cdist.GradSync):
+            self.grad_sync(local_graphs=batch.num_graphs)     # exact with unequal shards
+        elif self.grad_sync is not None:
             self.grad_sync()
         self.optimizer.step()
         return loss.detach()
@@ -92,7 +118,8 @@ class Trainer:
         for batch in loader:
             graphs = batch.num_graphs
             tally.add(self.train_step(batch) * graphs, graphs)
-        return tally.read() / max(tally.graphs, 1)
+        (loss_sum,), seen = self._global_tallies(loader, tally)
+        return loss_sum / max(seen, 1)
 
     # ---------------------------------------------------------------------------- evaluation
     @torch.no_grad()
@@ -106,9 +133,9 @@ class Trainer:
             logits = self.model(batch)
             losses.add(self.loss_fn(logits, batch.labels) * graphs, graphs)
             hits.add((logits.argmax(dim=1) == batch.labels).sum())
-        seen = losses.graphs
-        correct = int(hits.read())
-        return {"accuracy": correct / max(seen, 1), "loss": losses.read() / max(seen, 1),
+        (loss_sum, hit_sum), seen = self._global_tallies(loader, losses, hits)
+        correct = int(round(hit_sum))
+        return {"accuracy": correct / max(seen, 1), "loss": loss_sum / max(seen, 1),
                 "correct": correct, "total": seen}
 
     # ----------------------------------------------------------------------------------- fit

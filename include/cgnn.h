@@ -458,7 +458,10 @@ int cgnn_head_bwd_f32(const float* dlogits, const float* P, const float* H1, con
 
 /* Mean cross-entropy of the step (torch.nn.CrossEntropyLoss defaults; reference train.py:39,49):
  * loss[0] = mean_i(logsumexp(logits[i,:]) - logits[i, labels[i]]); dlogits [B,C] = its gradient
- * for a unit upstream gradient, (softmax - onehot) / B.  labels int64 [B]. */
+ * for a unit upstream gradient, (softmax - onehot) / V.  labels int64 [B].  Rows labelled -100
+ * (torch's default ignore_index) contribute nothing, get a zero gradient and are left out of
+ * the row count V; any other label outside [0, C) -- where torch raises -- turns the loss and
+ * that row's gradient into NaN (a kernel cannot raise; the NaN surfaces at the next read-back). */
 int cgnn_cross_entropy_f32(const float* logits, const int64_t* labels, int32_t B, int32_t C,
                            float* loss, float* dlogits, void* stream);
 

@@ -132,39 +132,64 @@ def _num_layers(state: State) -> int:
     return 1 + max(int(k.split(".")[1]) for k in state if k.startswith("convs."))
 
 
-def _classifier(h, state: State, p: float, training: bool):
+def _dropout(x, p: float, training: bool, keep: Optional[torch.Tensor] = None):
+    """F.dropout (models.py:199,210,261).  With ``keep`` (a {0,1} tensor shaped like x) the Bernoulli
+    draw is replaced by the given decisions and the arithmetic is aten::native_dropout's:
+    noise = keep / (1 - p), out = x * noise.  That is how the dropout-on mode is pinned: the HIP
+    path's own keep bits are replayed here, so everything but the random draw is compared."""
+    if keep is None:
+        return F.dropout(x, p, training)
+    if not training or p == 0.0:
+        return x
+    return x * (keep.to(x.dtype) / (1.0 - p))
+
+
+def _keep(masks: Optional[dict], key: str, i: Optional[int] = None):
+    if masks is None:
+        return None
+    return masks[key] if i is None else masks[key][i]
+
+
+def _classifier(h, state: State, p: float, training: bool, keep=None):
     h = F.relu(F.linear(h, state["classifier.0.weight"], state["classifier.0.bias"]))
-    h = F.dropout(h, p, training)
+    h = _dropout(h, p, training, keep)
     return F.linear(h, state["classifier.3.weight"], state["classifier.3.bias"])  # :196-201
 
 
-def gcn_encode(state: State, b: OBatch, dropout: float = 0.3, training: bool = False):
+def gcn_encode(state: State, b: OBatch, dropout: float = 0.3, training: bool = False,
+               masks: Optional[dict] = None):
+    """masks (optional): {"layers": [keep [Nn,H]] per layer, "head": keep [B,H/2]}, see _dropout."""
     x = b.node_features
     for i in range(_num_layers(state)):                         # :206-210
         x = gcn_layer(x, b.edge_index, b.edge_weight,
                       state[f"convs.{i}.linear.weight"], state[f"convs.{i}.bias"])
         x = _bn(x, state, i, training)
         x = F.relu(x)
-        x = F.dropout(x, dropout, training)
+        x = _dropout(x, dropout, training, _keep(masks, "layers", i))
     return graph_mean_pool(x, b.batch, b.num_graphs)            # :211
 
 
-def gcn_forward(state: State, b: OBatch, dropout: float = 0.3, training: bool = False):
-    return _classifier(gcn_encode(state, b, dropout, training), state, dropout, training)
+def gcn_forward(state: State, b: OBatch, dropout: float = 0.3, training: bool = False,
+                masks: Optional[dict] = None):
+    return _classifier(gcn_encode(state, b, dropout, training, masks), state, dropout, training,
+                       _keep(masks, "head"))
 
 
-def sage_encode(state: State, b: OBatch, dropout: float = 0.3, training: bool = False):
+def sage_encode(state: State, b: OBatch, dropout: float = 0.3, training: bool = False,
+                masks: Optional[dict] = None):
     x = b.node_features
     for i in range(_num_layers(state)):                         # :258-261 (no ReLU after BN)
         x = sage_layer(x, b.edge_index, b.edge_weight,
                        state[f"convs.{i}.linear.weight"], state[f"convs.{i}.linear.bias"])
         x = _bn(x, state, i, training)
-        x = F.dropout(x, dropout, training)
+        x = _dropout(x, dropout, training, _keep(masks, "layers", i))
     return graph_mean_pool(x, b.batch, b.num_graphs)            # :262
 
 
-def sage_forward(state: State, b: OBatch, dropout: float = 0.3, training: bool = False):
-    return _classifier(sage_encode(state, b, dropout, training), state, dropout, training)
+def sage_forward(state: State, b: OBatch, dropout: float = 0.3, training: bool = False,
+                 masks: Optional[dict] = None):
+    return _classifier(sage_encode(state, b, dropout, training, masks), state, dropout, training,
+                       _keep(masks, "head"))
 
 
 FORWARD = {"gcn": gcn_forward, "sage": sage_forward}

@@ -25,3 +25,17 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """Always show how many gradient comparisons the fp64 arbiter decided (tests/parity.py)."""
+    try:
+        from tests import parity as P
+    except Exception:      # pragma: no cover
+        return
+    if P.ARBITER["checked"]:
+        terminalreporter.write_line(
+            f"[parity] gradient tensors checked: {P.ARBITER['checked']}; decided by the fp64 arbiter: "
+            f"{P.ARBITER['fp64']} (of which by the fp32 noise floor: {P.ARBITER['floor']})")
+        for line in P.ARBITER["names"]:
+            terminalreporter.write_line(f"   arbiter: {line}")

@@ -390,6 +390,26 @@ def test_cross_entropy_matches_torch(b, c):
     torch.testing.assert_close(lgd.grad.cpu(), lg.grad, rtol=1e-5, atol=1e-8)
 
 
+def test_cross_entropy_ignore_index_and_bad_labels():
+    """torch defaults include ignore_index=-100: zero gradient, divided by the valid count.  Any
+    other out-of-range label (torch raises) gives a NaN loss here."""
+    from connectome_gnn_amd import ops
+    g = torch.Generator().manual_seed(0)
+    lg = torch.randn(37, 3, generator=g).requires_grad_(True)
+    lab = torch.randint(0, 3, (37,), generator=g)
+    lab[[0, 5, 36]] = -100
+    want = torch.nn.functional.cross_entropy(lg, lab)
+    want.backward()
+    lgd = lg.detach().to(DEV).requires_grad_(True)
+    got = ops.CrossEntropyLoss()(lgd, lab.to(DEV))
+    got.backward()
+    torch.testing.assert_close(got.cpu(), want.detach(), rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(lgd.grad.cpu(), lg.grad, rtol=1e-5, atol=1e-8)
+    assert float(lgd.grad[0].abs().sum()) == 0.0
+    lab[3] = 7
+    assert torch.isnan(ops.CrossEntropyLoss()(lgd, lab.to(DEV)))
+
+
 @pytest.mark.parametrize("h,c,p", [(64, 2, 0.0), (128, 3, 0.0), (32, 2, 0.0), (64, 2, 0.4)])
 def test_fused_head_matches_torch(h, c, p):
     """cgnn_head_fwd/bwd against the torch modules of the reference's classifier (models.py:196-201)."""

@@ -126,3 +126,41 @@ def test_g7_trainer_trajectory(kind):
         torch.testing.assert_close(st[k].detach(), v, rtol=1e-4, atol=slack, msg=lambda m: f"{k}: {m}")
     ev = O.evaluate(kind, st, batches(gs[30:]))
     assert ev["correct"] == int(d[f"{kind}_eval__correct"]) and ev["total"] == 10
+
+
+def test_oracle_replayed_dropout_equals_native_dropout():
+    """The oracle's mask-replay mode (used to pin the GPU's dropout-on step) is bit-identical to
+    F.dropout -- what the reference calls at models.py:199,210,261 -- given the same keep decisions,
+    in forward and backward."""
+    import torch.nn.functional as F
+    torch.manual_seed(3)
+    x = torch.randn(500, 64, requires_grad=True)
+    torch.manual_seed(9)
+    y = F.dropout(x, 0.3, True)
+    y.sum().backward()
+    keep = (y != 0).float()
+    x2 = x.detach().clone().requires_grad_(True)
+    z = O._dropout(x2, 0.3, True, keep)
+    z.sum().backward()
+    assert torch.equal(y, z) and torch.equal(x.grad, x2.grad)
+    assert O._dropout(x2, 0.3, False, keep) is x2
+
+
+def test_parity_noise_floor_views_are_the_same_problem():
+    """tests/parity.py rule (3) re-runs the oracle on other presentation orders of a batch
+    (graphs reversed / COO edge order reversed): in float64 loss and parameter gradients agree to
+    rounding, i.e. the views are the same mathematical problem and differ only in fp32 summation
+    order."""
+    import connectome_gnn_amd as C
+    from tests import parity as P
+    b = C.collate_graphs(C.generate_dataset(5, 20, 4, seed=1) + C.generate_dataset(2, 30, 6, seed=2))
+    torch.manual_seed(0)
+    sd = O.init_sage_state(5, 16)
+    masks = {"layers": [(torch.rand(b.num_nodes, 16) > 0.3).float() for _ in range(3)],
+             "head": (torch.rand(7, 8) > 0.3).float()}
+    _, l0, g0, _ = P.oracle_run("sage", sd, b, 0.3, True, masks, dtype=torch.float64)
+    for rg, re_ in ((True, False), (False, True), (True, True)):
+        v = P._View(b, rg, re_)
+        _, l1, g1, _ = P.oracle_run("sage", sd, v, 0.3, True, v.masks(masks), dtype=torch.float64)
+        assert abs(float(l0 - l1)) < 1e-14
+        assert max(float((g0[k] - g1[k]).abs().max()) for k in g0) < 1e-14

@@ -1,0 +1,16 @@
+"""Runs last (file order): how often did the fp64 arbiter of tests/parity.py decide a gradient
+comparison in this session?  Printed, and bounded, so the escape hatch cannot become the norm."""
+import pytest
+
+from tests import parity as P
+
+
+@pytest.mark.gpu
+def test_fp64_arbiter_tally():
+    checked, fp64 = P.ARBITER["checked"], P.ARBITER["fp64"]
+    print(f"\n[parity] gradient tensors checked: {checked}; decided by the fp64 arbiter: {fp64} "
+          f"(of which by the fp32 noise floor: {P.ARBITER['floor']})")
+    for line in P.ARBITER["names"]:
+        print("   arbiter:", line)
+    if checked >= 100:       # only meaningful when the model tests ran in this process
+        assert fp64 <= 0.05 * checked, f"fp64 arbiter decided {fp64} of {checked} gradient tensors"
