@@ -9,10 +9,17 @@ A "step" is one full training step of the reference's loop (train.py:46-51): zer
 forward (normalisation + 3 layers + pool + head), CrossEntropy, backward, gradient all-reduce
 (N > 1), Adam(lr 1e-3, wd 1e-4) -- on a batch that is already resident in HBM with its CSR
 structure built (the reference's collate is outside its step as well).
-Default workload = BASELINE.json's headline: 3-layer GCN, hidden 64, 4096 graphs x 360 ROI
-(Watts-Strogatz k=14, beta 0.15) per GPU, fp32, dropout 0.3.  Weak scaling: every rank trains
-on its own 4096-graph shard of a global batch of N*4096 (graphs shard with no data-path
-collective; one gradient all-reduce per step).
+Default workload = BASELINE.json's headline: 3-layer GCN, hidden 64, a global batch of 4096
+graphs x 360 ROI (Watts-Strogatz k=14, beta 0.15), fp32, dropout 0.3.
+
+Multi-GPU (graphs shard by rank with no data-path collective; ONE gradient all-reduce per step):
+  --scaling strong (default; BASELINE config 4 / SURVEY 8d-e): the global batch stays 4096 and
+                   each of the N ranks trains on its contiguous run of 4096/N graphs;
+  --scaling weak   every rank trains on its own 4096-graph shard (global batch N*4096).
+`python bench.py --gpus N` launches its own N workers (torch.distributed.run as a child process,
+before anything touches the GPU); under the driver's torchrun it just joins the group.
+--launch auto replays a HIP graph of the step when the per-rank shard is small enough to be
+host-bound (< 2048 graphs), else launches eagerly.
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel of the step, timed live
 with HIP events on its own stream; `cpu_baseline` is the oracle (a port of the reference's
@@ -92,6 +99,53 @@ def cpu_baseline(model: str, n: int, k: int, hidden: int, budget_s: float = 20.0
                       f"median of {len(times)} steps after 3 warm-up, collate excluded"}
 
 
+PMC_FILES = {   # workload -> (file under profiles/, batch it was taken at, kernel names averaged)
+    "cfg4-headline-gcn-4096x360-h64": ("r01_fused_pmc_traffic.json", 4096,
+                                       ("k_gcn_bwd<384, false, false>", "k_gcn_bwd<384, false, true>")),
+    "cfg3-sage-512x360-h128": ("r01_cfg3_pmc_traffic.json", 512, ("k_agg_tiled",)),
+}
+
+
+def end_to_end(C, ds, model, opt, bsz: int, epochs: int = 6) -> dict:
+    """Fresh-batch throughput: Trainer.train_epoch over a ResidentDataLoader
+    that re-shuffles every epoch, so on-device assembly, the CSR / blocked-ELL builds of every
+    batch AND the step are inside the clock.  The resident set is this bench's synthetic shard
+    tiled to 4 batches per epoch; the next batch is built on a side stream (prefetch)."""
+    from connectome_gnn_amd.resident import ResidentDataLoader
+    from connectome_gnn_amd.synthetic import PackedDataset
+    rep = lambda t: t.repeat(4, *([1] * (t.dim() - 1)))
+    big = PackedDataset(rep(ds.x), rep(ds.edge_local), rep(ds.edge_weight), rep(ds.labels))
+    tr = C.Trainer(model, opt, device=str(ds.x.device))
+    ld = ResidentDataLoader(big, batch_size=bsz, shuffle=True, prefetch=True, prepare=model.prepare_batch)
+    tr.train_epoch(ld)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(epochs):
+        tr.train_epoch(ld)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    steps = epochs * len(ld)
+    return {"graphs_per_s": steps * bsz / dt, "ms_per_step": dt / steps * 1e3, "steps": steps,
+            "what": "assemble + CSR/blocked-ELL build + step per fresh shuffled batch, prefetch on a "
+                    "side stream, Trainer.train_epoch API, eager launches"}
+
+
+def spawn_workers(n: int) -> int:
+    """`python bench.py --gpus N` outside torchrun: start N ranks as a CHILD torch.distributed.run
+    (never an exec: this process may not be replaced once anything has initialised the GPU, and
+    here nothing has) and hand its exit code back."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,13 +157,24 @@ def main() -> None:
     ap.add_argument("--nbuf", type=int, default=2, help="distinct resident batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-bn", action="store_true", help="full-batch BN statistics across ranks")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay a HIP graph of the whole step (single rank; kernel timing then comes "
-                         "from a short eager pass after the timed region)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="strong: global batch fixed, split over ranks; weak: fixed batch per rank")
+    ap.add_argument("--launch", default="auto", choices=["auto", "eager", "graph"],
+                    help="graph: replay a HIP graph of the whole step (kernel timing then comes from a "
+                         "short eager pass after the timed region); auto: graph below 2048 graphs/rank")
+    ap.add_argument("--graph", action="store_true", help="same as --launch graph")
+    ap.add_argument("--collectives", default="split", choices=["split", "captured"],
+                    help="graph launch at N > 1: all-reduce between two graphs, or captured inside one")
+    ap.add_argument("--no-end-to-end", action="store_true",
+                    help="skip the fresh-batch (assemble + structure build + step) measurement")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--one-device", action="store_true",
                     help="rehearsal only: every rank on cuda:0 (use with --backend gloo)")
     args = ap.parse_args()
+    if args.graph:
+        args.launch = "graph"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_workers(args.gpus))      # nothing has touched the GPU yet
 
     import connectome_gnn_amd as C
     from connectome_gnn_amd import _lib, dist as cdist
@@ -126,8 +191,22 @@ def main() -> None:
     wl = dict(WORKLOADS[args.workload])
     if args.batch:
         wl["batch"] = args.batch
-    model_kind, n, k, hidden, bsz = wl["model"], wl["n"], wl["k"], wl["hidden"], wl["batch"]
+    model_kind, n, k, hidden, gbatch = wl["model"], wl["n"], wl["k"], wl["hidden"], wl["batch"]
     e = n * k
+    if args.scaling == "strong":
+        # contiguous runs of the global batch; sizes differ by at most one graph
+        from connectome_gnn_amd.graph import shard_slice
+        bsz = len(shard_slice(list(range(gbatch)), rank, world))
+        global_batch = gbatch
+        if bsz == 0:
+            raise SystemExit(f"global batch {gbatch} < world size {world}")
+    else:
+        bsz, global_batch = gbatch, gbatch * world
+    equal_shards = args.scaling == "weak" or gbatch % world == 0
+    launch = args.launch
+    if launch == "auto":
+        launch = "graph" if bsz < 2048 else "eager"
+    use_graph = launch == "graph"
 
     # ---- data: this rank's shard of the synthetic dataset, resident in HBM ------------------
     ds = generate_packed(bsz, n, k, seed=42 + rank).to(dev)
@@ -147,16 +226,19 @@ def main() -> None:
         if args.sync_bn:
             model = cdist.convert_sync_batchnorm(model)
     sync = cdist.GradSync(model.parameters()) if world > 1 else None
-    if args.graph and world > 1:
-        raise SystemExit("--graph is single-rank only")
+    collectives = args.collectives
+    if use_graph and world > 1 and args.sync_bn:
+        collectives = "captured"          # sync-BN exchanges sit inside forward/backward
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4, fused=True,
-                           capturable=bool(args.graph))
+                           capturable=use_graph)
     from connectome_gnn_amd import ops as cops
     loss_fn = cops.CrossEntropyLoss()        # the Trainer's criterion: CrossEntropyLoss defaults
     graphed = None
-    if args.graph:
+    local_graphs = None if equal_shards else bsz
+    if use_graph:
         from connectome_gnn_amd.graphed import GraphedTrainStep
-        graphed = [GraphedTrainStep(model, opt, b, loss_fn) for b in batches]
+        graphed = [GraphedTrainStep(model, opt, b, loss_fn, grad_sync=sync, collectives=collectives,
+                                    local_graphs=local_graphs) for b in batches]
 
     def step(i: int):
         if graphed is not None:
@@ -172,7 +254,7 @@ def main() -> None:
         loss = loss_fn(model(b), b.labels)
         loss.backward()
         if sync is not None:
-            sync()
+            sync(local_graphs=local_graphs)
         opt.step()
         return loss
 
@@ -222,21 +304,20 @@ def main() -> None:
     final_loss = float(loss.detach())
 
     if rank == 0:
-        graphs_per_s = world * bsz * args.steps / dt
+        graphs_per_s = global_batch * args.steps / dt
         bpg = algorithmic_bytes_per_graph(model_kind, n, e, hidden)
         kms = timer.ms(dom)
         nn_, ee = bsz * n, bsz * e
         dom_bytes = dom_bytes_fn(nn_, ee)
         avg_ms = sum(kms) / max(len(kms), 1)
         achieved = dom_bytes / (avg_ms * 1e-3) / 1e9 if kms else 0.0
-        # HBM bytes per launch of that kernel from the PMC passes kept under profiles/ (collected
-        # offline with rocprofv3 --pmc on this same command; null for other workloads)
-        traffic = None
-        pmc_files = {"cfg4-headline-gcn-4096x360-h64": ("r01_fused_pmc_traffic.json", 4096,
-                                                         ("k_gcn_bwd<384, false, false>", "k_gcn_bwd<384, false, true>")),
-                     "cfg3-sage-512x360-h128": ("r01_cfg3_pmc_traffic.json", 512, ("k_agg_tiled",))}
-        if args.workload in pmc_files and impl_used == "fused":
-            fname, pmc_bsz, keys = pmc_files[args.workload]
+        # HBM bytes per launch of that kernel: NOT measured in this run -- read from the PMC passes
+        # kept under profiles/ (collected offline with rocprofv3 --pmc on this same command, FETCH
+        # and WRITE in separate passes, corrected as MI355X_MICROARCH.md prescribes); null when no
+        # pass exists for this workload / batch.  `traffic_source` names the file.
+        traffic, traffic_source = None, None
+        if impl_used == "fused" and args.workload in PMC_FILES:
+            fname, pmc_bsz, keys = PMC_FILES[args.workload]
             pmc = os.path.join(ROOT, "profiles", fname)
             if os.path.exists(pmc) and bsz == pmc_bsz:
                 doc = json.load(open(pmc))
@@ -244,18 +325,20 @@ def main() -> None:
                 v = [doc["kernels"].get(k, {}).get("hbm_bytes_per_launch") for k in keys]
                 if doc.get("workload") == args.workload and all(v):
                     traffic = sum(v) / len(v)
+                    traffic_source = f"profiles/{fname} (offline rocprofv3 --pmc passes, not this run)"
         out = {
             "metric": "training graphs/sec, 3-layer GCN, batch=4096x360-ROI connectomes"
             if args.workload.startswith("cfg4") else f"training graphs/sec, {args.workload}",
             "value": graphs_per_s, "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": args.workload, "model": model_kind, "rois": n, "ws_k": k,
                        "edges_per_graph": e, "hidden": hidden, "layers": 3,
-                       "graphs_per_gpu": bsz, "global_batch": world * bsz, "dropout": 0.3,
+                       "graphs_per_gpu": bsz, "global_batch": global_batch, "dropout": 0.3,
                        "optimizer": "Adam lr1e-3 wd1e-4", "impl": impl_used,
-                       "launch": "hip-graph replay" if graphed is not None else "eager",
+                       "launch": ("hip-graph replay" + (f" ({collectives} all-reduce)" if world > 1 else ""))
+                       if graphed is not None else "eager",
                        "bn": "sync" if (world > 1 and args.sync_bn) else "per-rank",
                        "parallelism": f"graph-sharded dp{world}"},
             "step_algorithmic": {"bytes_per_graph": bpg,
@@ -264,9 +347,12 @@ def main() -> None:
             "roofline": {"bound": "hbm", "kernel": dom, "launches_timed": len(kms),
                          "avg_ms": avg_ms, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": dom_bytes},
             "final_loss": final_loss,
         }
+        if world == 1 and not args.no_end_to_end and n <= 384:
+            out["end_to_end"] = end_to_end(C, ds, model, opt, bsz)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model_kind, n, k, hidden)
         print(json.dumps(out), flush=True)

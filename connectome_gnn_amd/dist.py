@@ -109,16 +109,21 @@ class GradSync:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
 
 
-def agree(flag: bool, device, group=None) -> bool:
-    """True iff ``flag`` is True on EVERY rank (one tiny all-reduce + read-back; callers cache the
+def agree_min(code: int, device, group=None) -> int:
+    """The smallest ``code`` over all ranks (one tiny all-reduce + read-back; callers cache the
     answer per batch).  Used to keep all ranks on the same execution path: under sync-BN the
     fused and the layered encoders issue different collectives, and a mismatch would hang."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return flag
+        return int(code)
     dev = device if dist.get_backend(group) == "nccl" else "cpu"
-    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+    t = torch.tensor([int(code)], dtype=torch.int32, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
-    return bool(int(t.item()))
+    return int(t.item())
+
+
+def agree(flag: bool, device, group=None) -> bool:
+    """True iff ``flag`` is True on EVERY rank."""
+    return bool(agree_min(1 if flag else 0, device, group))
 
 
 def reduce_sums(values: torch.Tensor, group=None) -> torch.Tensor:

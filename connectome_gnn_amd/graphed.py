@@ -1,7 +1,8 @@
 """HIP-graph capture of one whole training step (Trainer-compatible fast loop).
 
 A step of the fused path is ~45 kernel launches; at small batches (BASELINE config 2: 512
-84-ROI graphs) the GPU work is ~0.15 ms but issuing it from Python costs ~1 ms.  Capturing
+84-ROI graphs, or one rank's 512-graph shard of the 4096-graph headline batch at 8 GPUs) the
+GPU work is a few hundred microseconds but issuing it from Python costs ~1 ms.  Capturing
 zero_grad + forward + loss + backward + optimizer step once per resident batch and replaying
 it turns the host cost into one hipGraphLaunch.
 
@@ -15,6 +16,18 @@ What makes the step capturable:
   * BatchNorm's ``num_batches_tracked`` is bumped on the device by the finalise kernel.
 The batch must be resident with its structure (CSR / blocked-ELL) already built: structure
 building reads sizes back to the host and stays outside the graph, like collate.
+
+Data parallel (``grad_sync`` = dist.GradSync): gradients are views of one flat buffer that lives
+outside the graph's pool, so the step is cut at its single exchange point into
+
+    graph A: memset(flat) + forward + loss + backward      -> hipGraphLaunch
+    all-reduce(flat)                                        -> one RCCL launch, same stream
+    graph B: fused Adam                                     -> hipGraphLaunch
+
+i.e. three launches per step and no capture of a collective (``collectives="split"``, the
+default: it depends on nothing but stream ordering).  ``collectives="captured"`` records the
+all-reduce -- and the sync-BN sum exchanges, which sit INSIDE forward/backward and therefore need
+it -- into a single graph through torch's capturable NCCL/RCCL process group.
 """
 from __future__ import annotations
 
@@ -30,15 +43,23 @@ class GraphedTrainStep:
 
     def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer, batch,
                  loss_fn: Optional[Callable] = None, grad_sync: Optional[Callable[[], None]] = None,
-                 warmup: int = 3):
-        if grad_sync is not None:
-            raise NotImplementedError("graph capture with a gradient all-reduce is not wired yet; "
-                                      "use the eager step for multi-rank training")
+                 warmup: int = 3, collectives: str = "split", local_graphs: Optional[int] = None):
+        """local_graphs: with dist.GradSync and shards that may be unequal, this rank's graph count
+        (the update is then the exact global-batch gradient, see dist.GradSync)."""
+        if collectives not in ("split", "captured"):
+            raise ValueError("collectives must be 'split' or 'captured'")
         dev = batch.node_features.device
         self.model, self.optimizer, self.batch = model, optimizer, batch
         self.loss_fn = loss_fn or torch.nn.CrossEntropyLoss()
+        self.grad_sync = grad_sync
+        self._weighted = hasattr(grad_sync, "numel")       # dist.GradSync: exact with unequal shards
+        self._local_graphs = None if local_graphs is None else int(local_graphs)
         if warmup < 1:
             raise ValueError("warmup >= 1: the optimizer state must exist before capture")
+        split = grad_sync is not None and collectives == "split"
+        if split and self._has_sync_bn():
+            raise ValueError("SyncBatchNorm exchanges statistics inside forward/backward: a captured "
+                             "step needs collectives='captured' (or use per-rank BatchNorm)")
         model.prepare_batch(batch)                          # host syncs happen here, not in capture
         if getattr(model, "rng_device_state", None) is None:
             model.rng_device_state = torch.randint(0, 2 ** 31 - 1, (16,), dtype=torch.int32, device=dev)
@@ -46,20 +67,53 @@ class GraphedTrainStep:
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):                       # warm-up off the capture stream
             for _ in range(warmup):
-                self._eager()
+                self._fwd_bwd()
+                self._exchange()
+                self.optimizer.step()
         torch.cuda.current_stream(dev).wait_stream(side)
+        self._zero()
         self.graph = torch.cuda.CUDAGraph()
-        optimizer.zero_grad(set_to_none=True)
-        with torch.cuda.graph(self.graph):
-            self.loss = self._eager()
+        self.graph_tail = None
+        if split:
+            with torch.cuda.graph(self.graph):
+                self.loss = self._fwd_bwd()
+            self.graph_tail = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_tail, pool=self.graph.pool()):
+                self.optimizer.step()
+        else:
+            with torch.cuda.graph(self.graph):
+                self.loss = self._fwd_bwd()
+                self._exchange()
+                self.optimizer.step()
 
-    def _eager(self) -> torch.Tensor:
-        self.optimizer.zero_grad(set_to_none=True)
+    def _has_sync_bn(self) -> bool:
+        import torch.distributed as dist
+        return dist.is_initialized() and dist.get_world_size() > 1 and any(
+            isinstance(m, torch.nn.SyncBatchNorm) for m in self.model.modules())
+
+    def _zero(self) -> None:
+        if hasattr(self.grad_sync, "zero_grad"):
+            self.grad_sync.zero_grad()                      # one memset; .grad stay views of flat
+        else:
+            self.optimizer.zero_grad(set_to_none=True)
+
+    def _fwd_bwd(self) -> torch.Tensor:
+        self._zero()
         loss = self.loss_fn(self.model(self.batch), self.batch.labels)
         loss.backward()
-        self.optimizer.step()
         return loss.detach()
+
+    def _exchange(self) -> None:
+        if self.grad_sync is None:
+            return
+        if self._weighted and self._local_graphs is not None:
+            self.grad_sync(local_graphs=self._local_graphs)
+        else:
+            self.grad_sync()
 
     def __call__(self) -> torch.Tensor:
         self.graph.replay()
+        if self.graph_tail is not None:
+            self._exchange()
+            self.graph_tail.replay()
         return self.loss

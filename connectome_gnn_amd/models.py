@@ -174,7 +174,7 @@ class _ConnectomeModel(nn.Module):
         """Graph embeddings [B, hidden] (reference models.py:203-211 / 256-262)."""
         self._validate(batch)
         s = batch.structure()
-        if self._try_fused(batch, s):
+        if self._agreed_fused(batch, s):
             self.impl_used = "fused"
             return self._fused_encode(batch, s)
         self.impl_used = "layered"
@@ -227,6 +227,30 @@ class _ConnectomeModel(nn.Module):
 
     def _try_fused(self, batch, structure) -> bool:
         return False
+
+    def _agreed_fused(self, batch, structure) -> bool:
+        """``_try_fused`` -- and, while training with SyncBatchNorm across ranks, the same answer
+        on every rank: the choice depends on the local shard (graph sizes, block-diagonality),
+        and the fused encoders exchange their BatchNorm sums with a different collective than
+        torch's SyncBatchNorm on the layered path, so mixed paths would hang.  One tiny
+        all-reduce(MIN) per batch, cached on the batch's structure."""
+        ok = self._try_fused(batch, structure)
+        import torch.distributed as dist
+        if not (self.training and dist.is_initialized() and dist.get_world_size() > 1
+                and any(isinstance(bn, nn.SyncBatchNorm) for bn in self.batch_norms)):
+            return ok
+        key = (type(self).__name__, self.impl, id(self))
+        cache = structure.__dict__.setdefault("_path_agreement", {})
+        if key not in cache:
+            from . import dist as cdist
+            code = 0 if not ok else (2 if getattr(self, "_fused_kind", "tile") == "tile" else 1)
+            cache[key] = cdist.agree_min(code, batch.node_features.device)
+        agreed = cache[key]
+        if ok and agreed == 0:
+            return False
+        if ok and agreed == 1:
+            self._fused_kind = "wide"
+        return ok
 
     def _fused_encode(self, batch, structure) -> torch.Tensor:
         raise NotImplementedError

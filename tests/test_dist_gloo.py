@@ -117,3 +117,94 @@ def test_data_parallel_host_path_world2():
     for p in procs:
         p.join(30)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+class _PoolLinear(torch.nn.Module):
+    """CPU stand-in for a connectome model (the package has no CPU message-passing path): mean of
+    the node features per graph -> Linear.  Enough to drive Trainer's data-parallel host logic."""
+
+    def __init__(self):
+        super().__init__()
+        self.lin = torch.nn.Linear(5, 2)
+
+    def forward(self, batch):
+        sums = torch.zeros(batch.num_graphs, 5).index_add_(0, batch.batch, batch.node_features)
+        return self.lin(sums / (batch.ptr[1:] - batch.ptr[:-1]).clamp(min=1).unsqueeze(1))
+
+
+def _trainer_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import connectome_gnn_amd as C
+    from connectome_gnn_amd import dist as cdist
+    try:
+        cdist.init_from_env(backend="gloo")
+        torch.set_num_threads(1)
+        graphs = C.generate_dataset(23, 12, 4, seed=5)
+        train, val = graphs[:15], graphs[15:]
+
+        def run(r, w, sync_cls):
+            torch.manual_seed(1)
+            model = _PoolLinear()
+            opt = torch.optim.SGD(model.parameters(), lr=0.5)
+            sync = sync_cls(model.parameters()) if sync_cls else None
+            tr = C.Trainer(model, opt, device="cpu", grad_sync=sync, loss_fn=torch.nn.CrossEntropyLoss())
+            # batch_size 5 over 2 ranks: shards of 3 + 2 graphs in every batch; val 8 graphs -> 3 + 2, 2 + 1
+            hist = tr.fit(C.ConnectomeDataLoader(train, batch_size=5, shuffle=False, rank=r, world_size=w),
+                          C.ConnectomeDataLoader(val, batch_size=5, shuffle=False, rank=r, world_size=w),
+                          num_epochs=40, patience=2, verbose=False)
+            return hist, [p.detach().clone() for p in model.parameters()], tr.evaluate(
+                C.ConnectomeDataLoader(val, batch_size=5, shuffle=False, rank=r, world_size=w))
+
+        hist, params, ev = run(rank, world, cdist.GradSync)
+        # every rank saw the same curves, stopped at the same epoch and holds the same weights
+        mine = torch.tensor(hist["val_loss"] + [float(len(hist["val_loss"]))], dtype=torch.float64)
+        both = [torch.zeros_like(mine) for _ in range(world)]
+        # lengths are equal iff the ranks stopped together; all_gather would hang/raise otherwise
+        dist.all_gather(both, mine)
+        assert torch.equal(both[0], both[1])
+        for p in params:
+            g = [torch.zeros_like(p) for _ in range(world)]
+            dist.all_gather(g, p)
+            assert torch.equal(g[0], g[1])
+        assert ev["total"] == 8                               # global count, not this rank's shard
+        # ... and they are the single-process run on the unsharded batches: unequal shards are
+        # weighted by their graph counts, so the update is the global-batch gradient
+        torch.distributed.barrier()
+        ref_hist, ref_params, ref_ev = run(0, 1, None)
+        assert len(ref_hist["val_loss"]) == len(hist["val_loss"]) < 40      # early stop happened
+        torch.testing.assert_close(torch.tensor(hist["train_loss"]), torch.tensor(ref_hist["train_loss"]),
+                                   rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(torch.tensor(hist["val_loss"]), torch.tensor(ref_hist["val_loss"]),
+                                   rtol=1e-5, atol=1e-6)
+        for a, b_ in zip(params, ref_params):
+            torch.testing.assert_close(a, b_, rtol=1e-4, atol=1e-6)
+        assert ev["correct"] == ref_ev["correct"]
+        # path agreement helper: False anywhere -> False everywhere
+        assert cdist.agree(True, "cpu") is True
+        assert cdist.agree(rank == 0, "cpu") is False
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_trainer_data_parallel_unequal_shards_and_early_stop_world2():
+    """Trainer weights gradients by graph count (partial/odd batches), reduces its epoch
+    tallies over ranks before reading them, so every rank early-stops at the same epoch, restores
+    the same weights, and the trajectory equals the single-process run."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_trainer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=150) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res

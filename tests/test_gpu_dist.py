@@ -1,7 +1,10 @@
-"""N > 1 parity on the GPU box: two processes share the one GPU and talk over gloo (RCCL refuses
-two ranks on one device; the collectives' semantics are the same).  With SyncBatchNorm the
-graph-sharded run must reproduce the single-process full-batch run: logits of each shard, the
-averaged gradients and the BatchNorm running statistics."""
+"""N > 1 parity on the GPU box.  On a one-GPU box two processes share the GPU and talk over gloo
+(RCCL refuses two ranks on one device; the collectives' semantics are the same); where two
+devices are visible the same test also runs over backend "nccl" (= RCCL, ReduceOp.AVG) with one
+rank per device.  With SyncBatchNorm the graph-sharded run must reproduce the single-process
+full-batch run: logits of each shard, the averaged gradients and the BatchNorm running
+statistics.  Also: bench.py's self-launching strong-scaling + HIP-graph mode, rehearsed on two
+ranks."""
 import os
 import socket
 import sys
@@ -27,17 +30,18 @@ def _make(kind):
     return cls(5, hidden, dropout=0.0)
 
 
-def _worker(rank, world, port, q, kind="gcn64"):
+def _worker(rank, world, port, q, kind="gcn64", backend="gloo"):
     sys.path.insert(0, ROOT)
+    local = rank if backend == "nccl" else 0
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
-                      WORLD_SIZE=str(world), LOCAL_RANK="0")
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(local), HSA_ENABLE_IPC_MODE_LEGACY="0")
     try:
         import torch.distributed as dist
         import connectome_gnn_amd as C
         from connectome_gnn_amd import dist as cdist
         from connectome_gnn_amd.graph import shard_slice
-        cdist.init_from_env(backend="gloo")
-        torch.cuda.set_device(0)
+        cdist.init_from_env(backend=backend)
+        torch.cuda.set_device(local)
         graphs = C.generate_dataset(8, 84, 8, seed=21)
         torch.manual_seed(5)
         model = _make(kind).to("cuda").train()
@@ -69,9 +73,12 @@ def _worker(rank, world, port, q, kind="gcn64"):
 
 
 @pytest.mark.timeout(300)
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
 @pytest.mark.parametrize("kind", ["gcn64", "gcn128", "sage64"])
-def test_two_rank_sync_bn_equals_single_process_full_batch(kind):
+def test_two_rank_sync_bn_equals_single_process_full_batch(kind, backend):
     """All three one-node encoders (per-tile GCN, wide GCN, GraphSAGE) under SyncBatchNorm."""
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL needs one device per rank: fewer than 2 GPUs visible")
     import connectome_gnn_amd as C
     graphs = C.generate_dataset(8, 84, 8, seed=21)
     torch.manual_seed(5)
@@ -83,7 +90,7 @@ def test_two_rank_sync_bn_equals_single_process_full_batch(kind):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, kind)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, kind, backend)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=240) for _ in procs)
@@ -101,3 +108,29 @@ def test_two_rank_sync_bn_equals_single_process_full_batch(kind):
                                        atol=2e-6 + 1e-5 * float(w.abs().max()), msg=lambda s: f"{k}: {s}")
     torch.testing.assert_close(T(res[0]["rm"]), ref.batch_norms[2].running_mean.cpu(), rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(T(res[0]["rv"]), ref.batch_norms[2].running_var.cpu(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("mode", ["strong-graph-split", "strong-eager", "weak-graph-split"])
+def test_bench_self_launch_two_ranks(mode):
+    """`python bench.py --gpus 2` (no torchrun around it) starts its own two ranks, cuts the global
+    batch in two (strong) or keeps it per rank (weak), replays the step as HIP graphs with the
+    gradient all-reduce between them, and rank 0 prints the JSON line.  Rehearsal on one device
+    over gloo (--one-device); on a multi-GPU node the same command runs over RCCL."""
+    import json
+    import subprocess
+    scaling, launch = mode.split("-")[0], mode.split("-")[1]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+           "--workload", "cfg2-gcn-512x84-h64", "--batch", "64", "--scaling", scaling, "--launch", launch,
+           "--no-cpu-baseline", "--one-device", "--backend", "gloo"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=540, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == scaling
+    assert out["config"]["global_batch"] == (64 if scaling == "strong" else 128)
+    assert out["config"]["graphs_per_gpu"] == (32 if scaling == "strong" else 64)
+    assert out["config"]["launch"].startswith("hip-graph" if launch == "graph" else "eager")
+    assert out["value"] > 0 and out["final_loss"] == out["final_loss"]      # finite, not NaN
