@@ -110,7 +110,7 @@ __device__ __forceinline__ float4 act4(const float4& y, const float4& a, const f
 
 // Reduce per-lane fp64 column partials (lane (q,j): columns 4j..4j+3) over the workgroup and
 // write slab_row[0..63] (= s1) and slab_row[64..127] (= s2).  `red` >= 8*128 doubles of LDS.
-template <typename T>
+template <typename T, int NW = 8>
 __device__ __forceinline__ void reduce_stats(T (&s1)[4], T (&s2)[4], double* red,
                                              double* __restrict__ slab_row) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, j = lane & 15;
@@ -131,7 +131,7 @@ __device__ __forceinline__ void reduce_stats(T (&s1)[4], T (&s2)[4], double* red
   if (threadIdx.x < 128) {
     double t = 0.0;
 #pragma unroll
-    for (int w = 0; w < NWAVE; ++w) t += red[w * 128 + threadIdx.x];
+    for (int w = 0; w < NW; ++w) t += red[w * 128 + threadIdx.x];
     slab_row[threadIdx.x] = t;
   }
   __syncthreads();
@@ -368,6 +368,181 @@ __global__ void __launch_bounds__(NTHR) k_gcn_fwd(
   }
   if (stat_slab)
     reduce_stats(s1, s2, reinterpret_cast<double*>(tile), stat_slab + (int64_t)blockIdx.x * 128);
+}
+
+// ==========================================================================================
+// forward, projection first (layers l > 0)
+// ==========================================================================================
+// Y = A_hat (X W^T) + b  -- the reference's own order (models.py:111-114) -- with
+// X = drop(relu(BatchNorm(Y_prev))) rebuilt on the fly.  Twelve waves (3 per SIMD) share one tile:
+//
+//   phase A  each wave takes 16-row blocks of Y_prev straight into MATRIX-CORE operand layout
+//            (lane (q, j): row j of the block, columns 16c + 4q .. +3 for c = 0..3, i.e. the
+//            reduction index is permuted so that every operand is a 16-byte access; the rows
+//            were requested a whole phase B earlier), applies BatchNorm + ReLU + dropout and the
+//            dis[row] pre-scaling in registers, multiplies by W^T (LDS) with 64
+//            v_mfma_f32_16x16x4_f32 and stores dis * T into the LDS tile.  No staging buffer,
+//            no wave barriers: the only LDS writes are the T rows themselves.
+//   phase B  blocked-ELL aggregation out of the tile (agg_block.h); the finished rows leave
+//            straight from the aggregation registers: * dis[row], + bias, 16-byte stores, fp64
+//            BatchNorm statistics.
+//
+// Compared with aggregate-then-project this drops the per-block transposition through LDS and
+// the register footprint of the projection from phase B, which is what lets a third wave per
+// SIMD fit (168 VGPRs): the phases are bound by LDS/issue latency, not by any pipe's peak rate.
+constexpr int PF_NW = 12;
+constexpr int PF_NTHR = PF_NW * 64;          // 768
+#ifndef CGNN_PF_G
+#define CGNN_PF_G 2
+#endif
+
+template <int MAXR>
+__global__ void __launch_bounds__(PF_NTHR) k_gcn_fwd_pf(
+    cgnn_tiles t, const float* __restrict__ Xin, const float* __restrict__ bn_prev, DropCfg drop_in,
+    int use_drop, uint8_t* __restrict__ mask_out, const float* __restrict__ W,
+    const float* __restrict__ bias, float* __restrict__ Y, double* __restrict__ stat_slab) {
+  const DropCfg drop = drop_resolve(drop_in);
+  __shared__ __attribute__((aligned(16))) float tile[MAXR * HID];
+  __shared__ __attribute__((aligned(16))) float Wt[HID * HID];
+  __shared__ __attribute__((aligned(16))) float bnab[2 * HID];
+  __shared__ float disl[MAXR];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, j = lane & 15;
+  const uint4* ent = static_cast<const uint4*>(t.ent_dst);
+  constexpr int BPW = (MAXR / 16 + PF_NW - 1) / PF_NW;        // blocks per wave and tile (2)
+
+  for (int i = threadIdx.x; i < HID * HID; i += PF_NTHR) Wt[(i & 63) * HID + (i >> 6)] = W[i];
+  for (int i = threadIdx.x; i < 2 * HID; i += PF_NTHR) bnab[i] = bn_prev[i];
+  const float4 bias4 = ld4(bias + 4 * j);
+  double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+
+  // operand rows of the NEXT tile: block u of this wave, row j, columns 16c + 4q .. +3
+  float4 px[BPW][4];
+  float pd[BPW];
+  // block u of tile `tid`: issued right after the previous tile's block u has been consumed, so
+  // the loads are in flight through the rest of phase A AND all of phase B (HBM never idles)
+  auto request_block = [&](int tid, int u) {
+    const int nb2 = t.tile_ptr[tid], nn2 = t.tile_ptr[tid + 1] - nb2;
+    const int row = 16 * (wave + PF_NW * u) + j;
+    pd[u] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) px[u][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < nn2) {
+      const float* src = Xin + (int64_t)(nb2 + row) * HID + 4 * q;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) px[u][c] = ld4(src + 16 * c);
+      pd[u] = t.dis[nb2 + row];
+    }
+  };
+  auto request = [&](int tid) {
+#pragma unroll
+    for (int u = 0; u < BPW; ++u) request_block(tid, u);
+  };
+  if ((int)blockIdx.x < t.num_tiles) request(blockIdx.x);
+  __syncthreads();                       // Wt / bnab visible
+
+  for (int tid = blockIdx.x; tid < t.num_tiles; tid += gridDim.x) {
+    const int base = t.tile_ptr[tid];
+    const int n = t.tile_ptr[tid + 1] - base;
+    const int nblk = (n + 15) >> 4;
+    const int gb0 = t.tile_blk[tid];
+    int boff[BPW], bwid[BPW];
+#pragma unroll
+    for (int k = 0; k < BPW; ++k) {
+      boff[k] = bwid[k] = 0;
+      const int bb = cgnn_uniform(wave) + PF_NW * k;
+      if (bb < nblk) {
+        boff[k] = t.blk_off_dst[gb0 + bb];
+        bwid[k] = (t.blk_off_dst[gb0 + bb + 1] - boff[k]) >> 4;
+      }
+    }
+    MetaRegs pre;
+    if (wave < nblk) pre = meta_issue<true>(ent + (boff[0] >> 1), bwid[0], q, j);
+
+    // ------------------------------------------------ phase A: transform + project into the tile
+    const int nxt = tid + gridDim.x;
+#pragma unroll
+    for (int u = 0; u < BPW; ++u) {
+      const int b = wave + PF_NW * u;
+      if (b >= nblk) break;
+      const int row = 16 * b + j;
+      const bool live = row < n;                 // dead rows: px = 0 and pd = 0 -> x = 0
+      f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        uint32_t keep = 0xFu;
+#ifndef PF_DIAG_SKIP_DROP
+        if (use_drop) {
+          keep = drop_bits(drop, (uint32_t)(base + row), (uint32_t)(4 * c + q));
+          if (mask_out && live) mask_out[(int64_t)(base + row) * 16 + 4 * c + q] = (uint8_t)keep;
+        }
+#endif
+        float4 f;
+        const float4 x = scale4(act4(px[u][c], ld4(bnab + 16 * c + 4 * q), ld4(bnab + HID + 16 * c + 4 * q),
+                                     keep, drop.scale, f), pd[u]);
+        const float xa[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          // reduction index k = 16c + 4q + s4 on lane group q
+#ifdef PF_DIAG_SKIP_MFMA
+          acc[s4][c] += xa[s4];
+#else
+          const float4 w4 = ld4(Wt + (16 * c + 4 * q + s4) * HID + 4 * j);
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s4], w4.x, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s4], w4.y, acc[1], 0, 0, 0);
+          acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s4], w4.z, acc[2], 0, 0, 0);
+          acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s4], w4.w, acc[3], 0, 0, 0);
+#endif
+        }
+        __builtin_amdgcn_sched_barrier(0);      // keep the W^T / BatchNorm LDS reads of later chunks
+                                                // from being hoisted (96 live registers otherwise)
+      }
+      // accumulator tile tj holds columns 4j + tj of rows 4q + r: one float4 per row
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        st4(tile + (16 * b + 4 * q + r) * HID + 4 * j, make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]));
+      if (q == 0) disl[row] = pd[u];
+      if (nxt < t.num_tiles) request_block(nxt, u);
+    }
+    if (nxt < t.num_tiles) {
+      // blocks this wave did not have in THIS tile (ragged tiles) but may have in the next one
+#pragma unroll
+      for (int u = 0; u < BPW; ++u)
+        if (wave + PF_NW * u >= nblk) request_block(nxt, u);
+    }
+    __syncthreads();
+
+    // ------------------------------------------------ phase B: aggregate, bias, store, statistics
+#pragma unroll
+    for (int u = 0; u < BPW; ++u) {
+      const int b = wave + PF_NW * u;
+      if (b >= nblk) break;
+      float4 ag[4];
+#ifdef PF_DIAG_SKIP_AGG
+#pragma unroll
+      for (int it = 0; it < 4; ++it) ag[it] = ld4(tile + (16 * b + 4 * q + it) * HID + 4 * j);
+#else
+      agg_block<CGNN_PF_G, true>(tile, pre, ent + (boff[u] >> 1), bwid[u], q, j, ag);
+#endif
+      if (u + 1 < BPW && b + PF_NW < nblk) pre = meta_issue<true>(ent + (boff[u + 1 < BPW ? u + 1 : u] >> 1), bwid[u + 1 < BPW ? u + 1 : u], q, j);
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = 16 * b + 4 * q + it;
+        if (row < n) {
+          const float4 a = scale4(ag[it], disl[row]);
+          const float4 y = make_float4(a.x + bias4.x, a.y + bias4.y, a.z + bias4.z, a.w + bias4.w);
+#ifndef PF_DIAG_SKIP_STORE
+          st4(Y + (int64_t)(base + row) * HID + 4 * j, y);
+#endif
+          s1[0] += y.x; s1[1] += y.y; s1[2] += y.z; s1[3] += y.w;
+          s2[0] += (double)y.x * y.x; s2[1] += (double)y.y * y.y;
+          s2[2] += (double)y.z * y.z; s2[3] += (double)y.w * y.w;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (stat_slab)
+    reduce_stats<double, PF_NW>(s1, s2, reinterpret_cast<double*>(tile), stat_slab + (int64_t)blockIdx.x * 128);
 }
 
 // ==========================================================================================
@@ -1042,8 +1217,8 @@ int cgnn_gcn_fused_fwd(const cgnn_tiles* t, const float* Yprev, const float* bn_
   int use_drop;
   DropCfg d = make_drop(p_drop, seed, &use_drop);
   d.dev_key = seed_dev;
-  k_gcn_fwd<CGNN_FUSED_MAX_ROWS, false><<<fused_grid(), NTHR, 0, cgnn_stream(stream)>>>(
-      *t, Yprev, 0, bn_prev, d, use_drop, mask_out, W, bias, Y, stat_slab);
+  k_gcn_fwd_pf<CGNN_FUSED_MAX_ROWS><<<fused_grid(), PF_NTHR, 0, cgnn_stream(stream)>>>(
+      *t, Yprev, bn_prev, d, use_drop, mask_out, W, bias, Y, stat_slab);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }
