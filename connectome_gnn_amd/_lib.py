@@ -35,6 +35,14 @@ class CgnnTiles(ctypes.Structure):
 
 TP = ctypes.POINTER(CgnnTiles)
 
+
+class CgnnL0Src(ctypes.Structure):
+    """Mirror of `struct cgnn_l0src` (include/cgnn.h): layer 0's output in factored form."""
+    _fields_ = [("P0", c_void_p), ("W0", c_void_p), ("b0", c_void_p), ("F0", c_int32)]
+
+
+LP = ctypes.POINTER(CgnnL0Src)
+
 # name -> (restype, argtypes).  Order and meaning follow include/cgnn.h exactly.
 PROTOTYPES = {
     "cgnn_abi_version": (c_int, []),
@@ -83,20 +91,21 @@ PROTOTYPES = {
     "cgnn_fused_grid": (c_int, []),
     "cgnn_gcn_fused_fwd_first": (c_int, [TP, P, I32, P, P, P, P, P]),
     "cgnn_rng_advance": (c_int, [P, I32, P]),
-    "cgnn_gcn_fused_fwd": (c_int, [TP, P, P, F32, U64, P, P, P, P, P, P, P]),
+    "cgnn_gcn_fused_fwd": (c_int, [TP, P, LP, P, F32, U64, P, P, P, P, P, P, P]),
     "cgnn_bn_reduce": (c_int, [P, I32, I32, P, P]),
     "cgnn_bn_finalize": (c_int, [P, F64, P, P, P, P, P, F32, F32, I32, P, P]),
-    "cgnn_gcn_fused_pool_fwd": (c_int, [P, P, F32, U64, P, P, P, I32, P, P]),
+    "cgnn_gcn_fused_pool_fwd": (c_int, [P, P, F32, U64, P, P, P, I32, P, P, P, P]),
+    "cgnn_gcn_fused_pool_bwd_sums": (c_int, [P, P, P, P, I32, P, P]),
     "cgnn_gcn_fused_pool_bwd": (c_int, [P, P, P, F32, P, P, I32, P, P, P]),
     "cgnn_bn_bwd_finalize": (c_int, [P, F64, P, I32, P, P, P, P]),
-    "cgnn_gcn_fused_bwd": (c_int, [TP, P, P, P, P, P, P, F32, P, P, P, P, P, P, P, P, P, P, P]),
+    "cgnn_gcn_fused_bwd": (c_int, [TP, P, P, P, P, P, LP, P, F32, P, P, P, P, P, P, P, P, P, P, P]),
     "cgnn_gcn_fused_bwd_first": (c_int, [TP, P, P, P, P, P, I32, P, P, F32, P, P, P, P, P]),
     "cgnn_bn_stats_finalize": (c_int, [P, I32, F64, P, P, P, P, F32, F32, P, P, P]),
     "cgnn_bn_bwd_stats_finalize": (c_int, [P, I32, F64, I32, P, P, P, P]),
     "cgnn_dw_db_reduce": (c_int, [P, P, I32, I32, I32, P, I32, P, P]),
     "cgnn_l0_grid": (c_int, []),
     "cgnn_gcn_l0_fwd": (c_int, [TP, P, I32, P, P, P, P, P, P]),
-    "cgnn_gcn_l0_bwd": (c_int, [P, P, P, P, P, I64, P, P, P]),
+    "cgnn_gcn_l0_bwd": (c_int, [P, P, LP, P, P, P, I64, P, P, P]),
     "cgnn_slab_reduce_f32": (c_int, [P, I32, I32, I32, I32, P, I32, P]),
     "cgnn_slab_reduce_f64": (c_int, [P, I32, I32, P, P]),
 }

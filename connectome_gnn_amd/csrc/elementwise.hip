@@ -25,9 +25,9 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
 }
 
 __device__ __forceinline__ uint32_t drop_bits(const DropCfg& d, uint32_t chunk_index) {
-  const uint32_t e = chunk_index * 2u;
-  const uint32_t h0 = mix32(mix32(e ^ d.key0) + d.key1);
-  const uint32_t h1 = mix32(mix32((e + 1u) ^ d.key0) + d.key1);
+  // one keyed counter hash + one chained round = 64 random bits (as in fused_gcn.hip)
+  const uint32_t h0 = mix32((chunk_index ^ d.key0) + d.key1);
+  const uint32_t h1 = mix32(h0 + 0x9E3779B9u);
   uint32_t b = 0;
   b |= ((h0 & 0xFFFFu) >= d.thr16) ? 1u : 0u;
   b |= ((h0 >> 16) >= d.thr16) ? 2u : 0u;

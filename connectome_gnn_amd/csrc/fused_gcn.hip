@@ -32,6 +32,7 @@
 // No atomics anywhere: per-workgroup partial sums go to slabs reduced in a fixed order.
 #include "common.h"
 #include "agg_block.h"
+#include "l0src.h"
 
 // Diagnostic build only (-DCGNN_STAMPS, tools/stamp_probe.py): per-phase s_memtime shares.
 #ifdef CGNN_STAMPS
@@ -79,11 +80,13 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   return x;
 }
 
-// 4 keep-bits for the float4 at (global row, chunk); bit i <-> column 4*chunk + i.
+// 4 keep-bits for the float4 at (global row, chunk); bit i <-> column 4*chunk + i.  One keyed
+// counter hash gives the first 32 random bits, a second round of the same mixer the other 32
+// (chained, not a second counter: half the multiplies of two independent hashes).
 __device__ __forceinline__ uint32_t drop_bits(const DropCfg& d, uint32_t row, uint32_t chunk) {
-  const uint32_t e = (row * 16u + chunk) * 2u;
-  const uint32_t h0 = mix32(mix32(e ^ d.key0) + d.key1);
-  const uint32_t h1 = mix32(mix32((e + 1u) ^ d.key0) + d.key1);
+  const uint32_t e = row * 16u + chunk;
+  const uint32_t h0 = mix32((e ^ d.key0) + d.key1);
+  const uint32_t h1 = mix32(h0 + 0x9E3779B9u);
   uint32_t b = 0;
   b |= ((h0 & 0xFFFFu) >= d.thr16) ? 1u : 0u;
   b |= ((h0 >> 16) >= d.thr16) ? 2u : 0u;
@@ -396,9 +399,11 @@ constexpr int PF_NTHR = PF_NW * 64;          // 768
 #define CGNN_PF_G 2
 #endif
 
-template <int MAXR>
+// FROM_P0: the previous layer is layer 0 in factored form (cgnn_l0src): a row of Y0 is rebuilt
+// from its 32-byte narrow aggregate instead of being read (256 bytes) from HBM.
+template <int MAXR, bool FROM_P0>
 __global__ void __launch_bounds__(PF_NTHR) k_gcn_fwd_pf(
-    cgnn_tiles t, const float* __restrict__ Xin, const float* __restrict__ bn_prev, DropCfg drop_in,
+    cgnn_tiles t, const float* __restrict__ Xin, cgnn_l0src l0, const float* __restrict__ bn_prev, DropCfg drop_in,
     int use_drop, uint8_t* __restrict__ mask_out, const float* __restrict__ W,
     const float* __restrict__ bias, float* __restrict__ Y, double* __restrict__ stat_slab) {
   const DropCfg drop = drop_resolve(drop_in);
@@ -410,13 +415,17 @@ __global__ void __launch_bounds__(PF_NTHR) k_gcn_fwd_pf(
   const uint4* ent = static_cast<const uint4*>(t.ent_dst);
   constexpr int BPW = (MAXR / 16 + PF_NW - 1) / PF_NW;        // blocks per wave and tile (2)
 
+  __shared__ __attribute__((aligned(16))) float wl0[FROM_P0 ? L0_LDS_FLOATS : 4];
   for (int i = threadIdx.x; i < HID * HID; i += PF_NTHR) Wt[(i & 63) * HID + (i >> 6)] = W[i];
   for (int i = threadIdx.x; i < 2 * HID; i += PF_NTHR) bnab[i] = bn_prev[i];
+  if (FROM_P0) l0_stage(wl0, l0, PF_NTHR);
   const float4 bias4 = ld4(bias + 4 * j);
   double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
 
   // operand rows of the NEXT tile: block u of this wave, row j, columns 16c + 4q .. +3
-  float4 px[BPW][4];
+  // (FROM_P0: the row's narrow aggregate, px[u][0..1])
+  constexpr int NPX = FROM_P0 ? 2 : 4;
+  float4 px[BPW][NPX];
   float pd[BPW];
   // block u of tile `tid`: issued right after the previous tile's block u has been consumed, so
   // the loads are in flight through the rest of phase A AND all of phase B (HBM never idles)
@@ -425,11 +434,17 @@ __global__ void __launch_bounds__(PF_NTHR) k_gcn_fwd_pf(
     const int row = 16 * (wave + PF_NW * u) + j;
     pd[u] = 0.f;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) px[u][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = 0; c < NPX; ++c) px[u][c] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row < nn2) {
-      const float* src = Xin + (int64_t)(nb2 + row) * HID + 4 * q;
+      if (FROM_P0) {
+        const float* src = l0.P0 + (int64_t)(nb2 + row) * L0_FP;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) px[u][c] = ld4(src + 16 * c);
+        for (int c = 0; c < NPX; ++c) px[u][c] = ld4(src + 4 * c);
+      } else {
+        const float* src = Xin + (int64_t)(nb2 + row) * HID + 4 * q;
+#pragma unroll
+        for (int c = 0; c < NPX; ++c) px[u][c] = ld4(src + 16 * c);
+      }
       pd[u] = t.dis[nb2 + row];
     }
   };
@@ -477,7 +492,9 @@ __global__ void __launch_bounds__(PF_NTHR) k_gcn_fwd_pf(
         }
 #endif
         float4 f;
-        const float4 x = scale4(act4(px[u][c], ld4(bnab + 16 * c + 4 * q), ld4(bnab + HID + 16 * c + 4 * q),
+        const float4 yraw = FROM_P0 ? l0_rebuild4(px[u][0], px[u][NPX > 1 ? 1 : 0], wl0, 16 * c + 4 * q, l0.F0)
+                                    : px[u][c < NPX ? c : 0];
+        const float4 x = scale4(act4(yraw, ld4(bnab + 16 * c + 4 * q), ld4(bnab + HID + 16 * c + 4 * q),
                                      keep, drop.scale, f), pd[u]);
         const float xa[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
@@ -559,9 +576,11 @@ struct PoolIn {
 };
 
 
-template <int MAXR, bool FIRST, bool POOLIN>
+// XP0: the previous layer's output is layer 0's in factored form: its rows are rebuilt from the
+// narrow aggregate l0.P0 (32 bytes per row) instead of being read from Xprev (256 bytes per row).
+template <int MAXR, bool FIRST, bool POOLIN, bool XP0 = false>
 __global__ void __launch_bounds__(NTHR) k_gcn_bwd(
-    cgnn_tiles t, PoolIn pin, const float* __restrict__ dZ, const float* __restrict__ Y,
+    cgnn_tiles t, PoolIn pin, cgnn_l0src l0, const float* __restrict__ dZ, const float* __restrict__ Y,
     const float* __restrict__ bn, const float* __restrict__ bwc,
     const float* __restrict__ Xprev /* Yprev [Nn,64] or X0 [Nn,F0] */, int F0,
     const float* __restrict__ bn_prev, DropCfg drop, int use_drop,
@@ -584,6 +603,8 @@ __global__ void __launch_bounds__(NTHR) k_gcn_bwd(
   if (!FIRST) {
     for (int i = threadIdx.x; i < 4 * HID; i += NTHR) bnl[i] = bn_prev[i];
   }
+  __shared__ __attribute__((aligned(16))) float wl0[XP0 ? L0_LDS_FLOATS : 4];
+  if (XP0) l0_stage(wl0, l0, NTHR);
   // dW accumulators: FIRST: dw[ti][0] only (16 input columns); else dw[ti][tj].
   f32x4 dw[4][FIRST ? 1 : 4];
 #pragma unroll
@@ -690,6 +711,7 @@ __global__ void __launch_bounds__(NTHR) k_gcn_bwd(
     // --------------------- phase B: dT = A_hat^T dY per block; dW += dT^T X; dZprev = ...
     for (int b = wave; b < nblk; b += NWAVE) {
       float4 yp[4];
+      float4 pr[XP0 ? 4 : 1][2];                // XP0: narrow aggregates of rows 4q+r
       uint32_t keeps = 0u;                      // byte r: keep bits of row 4q+r (0 = no such row)
       {
         ++bk;
@@ -704,8 +726,14 @@ __global__ void __launch_bounds__(NTHR) k_gcn_bwd(
           for (int r = 0; r < 4; ++r) {
             const int row = 16 * b + 4 * q + r;
             yp[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (XP0) pr[XP0 ? r : 0][0] = pr[XP0 ? r : 0][1] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row < n) {
-                yp[r] = ld4(Xprev + (int64_t)(base + row) * HID + 4 * j);
+                if (XP0) {
+                  pr[XP0 ? r : 0][0] = ld4(l0.P0 + (int64_t)(base + row) * L0_FP);
+                  pr[XP0 ? r : 0][1] = ld4(l0.P0 + (int64_t)(base + row) * L0_FP + 4);
+                } else {
+                  yp[r] = ld4(Xprev + (int64_t)(base + row) * HID + 4 * j);
+                }
                 uint32_t kb = 0xFu;
                 if (use_drop) kb = mask_prev[(int64_t)(base + row) * 16 + j];
                 keeps |= kb << (8 * r);
@@ -713,8 +741,18 @@ __global__ void __launch_bounds__(NTHR) k_gcn_bwd(
           }
         }
         float4 ag[4];
+#ifdef BW_DIAG_SKIP_AGG
+#pragma unroll
+        for (int it = 0; it < 4; ++it) ag[it] = ld4(tile + (16 * b + 4 * q + it) * HID + 4 * j);
+#else
         agg_block<FIRST ? 4 : BWD_G, FIRST>(tile, pre, ent + (off0 >> 1), width, q, j, ag);
+#endif
         CGNN_STAMP(3)
+        if (XP0) {
+          // rows outside the tile rebuild to b0, harmless: their keep byte is 0 -> x = f = 0
+#pragma unroll
+          for (int r = 0; r < 4; ++r) yp[r] = l0_rebuild4(pr[XP0 ? r : 0][0], pr[XP0 ? r : 0][1], wl0, 4 * j, l0.F0);
+        }
 #pragma unroll
         for (int it = 0; it < 4; ++it)
           st4(stg + (4 * q + it) * SLD + 4 * j, scale4(ag[it], disl[16 * b + 4 * q + it]));
@@ -756,7 +794,11 @@ __global__ void __launch_bounds__(NTHR) k_gcn_bwd(
           const float av = stg[(4 * q + s) * SLD + 16 * ti + j];
 #pragma unroll
           for (int tj = 0; tj < 4; ++tj)
+#ifdef BW_DIAG_SKIP_DW
+            dw[ti][tj][s] += av * bx[tj];
+#else
             dw[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bx[tj], dw[ti][tj], 0, 0, 0);
+#endif
         }
       }
       // dX[row][col] = sum_o dT[row][o] W[o][col]; k <-> o = 16q + s
@@ -769,11 +811,15 @@ __global__ void __launch_bounds__(NTHR) k_gcn_bwd(
       }
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
+#ifdef BW_DIAG_SKIP_DX
+        dx[s & 3][s >> 2] += af[s];
+#else
         const float4 w4 = ld4(Wl + (16 * q + s) * HID + 4 * j);
         dx[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], w4.x, dx[0], 0, 0, 0);
         dx[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], w4.y, dx[1], 0, 0, 0);
         dx[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], w4.z, dx[2], 0, 0, 0);
         dx[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], w4.w, dx[3], 0, 0, 0);
+#endif
       }
       __builtin_amdgcn_wave_barrier();
       const float4 pa2 = ld4(bnl + 4 * j), pb2 = ld4(bnl + HID + 4 * j);
@@ -871,14 +917,20 @@ __global__ void __launch_bounds__(PTHR) k_pool_fwd(const float* __restrict__ Y,
                                                    const float* __restrict__ bn, DropCfg drop_in,
                                                    int use_drop, uint8_t* __restrict__ mask_out,
                                                    const int32_t* __restrict__ gptr, int B,
-                                                   float* __restrict__ P) {
+                                                   float* __restrict__ P, float* __restrict__ F1,
+                                                   float* __restrict__ F2) {
+  // F1/F2 (training): per graph and column, sum over the graph's rows of the factor f =
+  // relu'(z) * keep / (1-p) and of f * xhat.  The readout's gradient is constant per graph
+  // (dP[g] / (n_g + 1e-8)), so the BatchNorm-backward sums of the last layer are
+  // sum_g dP[g]/n_g * F1[g] and sum_g dP[g]/n_g * F2[g]: the backward never re-reads Y.
   const DropCfg drop = drop_resolve(drop_in);
-  __shared__ float red[16 * HID];
+  __shared__ float red[3 * 16 * HID];
   const int j = threadIdx.x & 15, rr = threadIdx.x >> 4;
   const float4 a = ld4(bn + 4 * j), b = ld4(bn + HID + 4 * j);
+  const float4 mean = ld4(bn + 2 * HID + 4 * j), is = ld4(bn + 3 * HID + 4 * j);
   for (int g = blockIdx.x; g < B; g += gridDim.x) {
     const int rbeg = gptr[g], rend = gptr[g + 1];
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), f1 = s, f2 = s;
     constexpr int U = 4;                       // rows in flight per thread (latency-bound otherwise)
     for (int row0 = rbeg + rr; row0 < rend; row0 += 16 * U) {
       float4 yb[U];
@@ -897,21 +949,54 @@ __global__ void __launch_bounds__(PTHR) k_pool_fwd(const float* __restrict__ Y,
             if (mask_out) mask_out[(int64_t)row * 16 + j] = (uint8_t)keep;
           }
           float4 f;
-          const float4 x = act4(yb[u], a, b, keep, drop.scale, f);
+          const float4 y = yb[u];
+          const float4 x = act4(y, a, b, keep, drop.scale, f);
           s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
+          if (F1) {
+            f1.x += f.x; f1.y += f.y; f1.z += f.z; f1.w += f.w;
+            f2.x = fmaf(f.x, (y.x - mean.x) * is.x, f2.x); f2.y = fmaf(f.y, (y.y - mean.y) * is.y, f2.y);
+            f2.z = fmaf(f.z, (y.z - mean.z) * is.z, f2.z); f2.w = fmaf(f.w, (y.w - mean.w) * is.w, f2.w);
+          }
         }
       }
     }
     st4(red + rr * HID + 4 * j, s);
+    if (F1) {
+      st4(red + (16 + rr) * HID + 4 * j, f1);
+      st4(red + (32 + rr) * HID + 4 * j, f2);
+    }
     __syncthreads();
     if (threadIdx.x < HID) {
       float tot = 0.f;
 #pragma unroll
       for (int k = 0; k < 16; ++k) tot += red[k * HID + threadIdx.x];
       P[(int64_t)g * HID + threadIdx.x] = tot / ((float)(rend - rbeg) + 1e-8f);
+    } else if (F1 && threadIdx.x < 3 * HID) {
+      const int which = threadIdx.x / HID, col = threadIdx.x % HID;          // 1: F1, 2: F2
+      double tot = 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) tot += (double)red[(16 * which + k) * HID + col];
+      (which == 1 ? F1 : F2)[(int64_t)g * HID + col] = (float)tot;
     }
     __syncthreads();
   }
+}
+
+// BatchNorm-backward sums of the last layer from the per-graph factor sums of k_pool_fwd:
+// slab[wg][0..63] = sum_g dP[g]/(n_g+1e-8) * F1[g], slab[wg][64..127] = ... * F2[g]  (fp64).
+__global__ void __launch_bounds__(128) k_pool_bwd_sums(const float* __restrict__ dP,
+                                                       const float* __restrict__ F1,
+                                                       const float* __restrict__ F2,
+                                                       const int32_t* __restrict__ gptr, int B,
+                                                       double* __restrict__ s_slab) {
+  const int col = threadIdx.x & 63;
+  const float* F = threadIdx.x < 64 ? F1 : F2;
+  double acc = 0.0;
+  for (int g = blockIdx.x; g < B; g += gridDim.x) {
+    const float inv = 1.0f / ((float)(gptr[g + 1] - gptr[g]) + 1e-8f);
+    acc += (double)(dP[(int64_t)g * HID + col] * inv) * (double)F[(int64_t)g * HID + col];
+  }
+  s_slab[(int64_t)blockIdx.x * 128 + threadIdx.x] = acc;
 }
 
 constexpr int PBTHR = 1024;  // readout backward: 64 row-lanes x 16 chunks (16 waves per CU)
@@ -1168,6 +1253,10 @@ __global__ void k_rng_advance(uint32_t* state, int n) {
   if (i < n) state[i] = mix32(state[i] + 0x9E3779B9u * (uint32_t)(i + 1));
 }
 
+bool l0src_ok(const cgnn_l0src* l0) {
+  return l0 && l0->P0 && l0->W0 && l0->b0 && l0->F0 >= 1 && l0->F0 <= L0_FP;
+}
+
 bool tiles_ok(const cgnn_tiles* t) {
   return t && t->num_tiles >= 0 && t->num_nodes >= 0 && t->max_tile_rows <= CGNN_FUSED_MAX_ROWS &&
          (t->num_tiles == 0 || (t->tile_ptr && t->tile_blk && t->blk_off_dst && t->ent_dst &&
@@ -1209,16 +1298,21 @@ int cgnn_rng_advance(uint32_t* state, int32_t n, void* stream) {
   return CGNN_OK;
 }
 
-int cgnn_gcn_fused_fwd(const cgnn_tiles* t, const float* Yprev, const float* bn_prev, float p_drop,
-                       uint64_t seed, const uint32_t* seed_dev, uint8_t* mask_out, const float* W,
-                       const float* bias, float* Y, double* stat_slab, void* stream) {
+int cgnn_gcn_fused_fwd(const cgnn_tiles* t, const float* Yprev, const cgnn_l0src* l0,
+                       const float* bn_prev, float p_drop, uint64_t seed, const uint32_t* seed_dev,
+                       uint8_t* mask_out, const float* W, const float* bias, float* Y,
+                       double* stat_slab, void* stream) {
   if (!tiles_ok(t)) return t && t->max_tile_rows > CGNN_FUSED_MAX_ROWS ? CGNN_EUNSUPPORTED : CGNN_EINVAL;
-  if (!Yprev || !bn_prev || !W || !bias || !Y || p_drop < 0.f || p_drop >= 1.f) return CGNN_EINVAL;
+  if ((!Yprev && !l0src_ok(l0)) || !bn_prev || !W || !bias || !Y || p_drop < 0.f || p_drop >= 1.f) return CGNN_EINVAL;
   int use_drop;
   DropCfg d = make_drop(p_drop, seed, &use_drop);
   d.dev_key = seed_dev;
-  k_gcn_fwd_pf<CGNN_FUSED_MAX_ROWS><<<fused_grid(), PF_NTHR, 0, cgnn_stream(stream)>>>(
-      *t, Yprev, bn_prev, d, use_drop, mask_out, W, bias, Y, stat_slab);
+  if (Yprev)
+    k_gcn_fwd_pf<CGNN_FUSED_MAX_ROWS, false><<<fused_grid(), PF_NTHR, 0, cgnn_stream(stream)>>>(
+        *t, Yprev, cgnn_l0src{}, bn_prev, d, use_drop, mask_out, W, bias, Y, stat_slab);
+  else
+    k_gcn_fwd_pf<CGNN_FUSED_MAX_ROWS, true><<<fused_grid(), PF_NTHR, 0, cgnn_stream(stream)>>>(
+        *t, nullptr, *l0, bn_prev, d, use_drop, mask_out, W, bias, Y, stat_slab);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }
@@ -1244,15 +1338,26 @@ int cgnn_bn_finalize(const double* sums, double count, const double* count_dev, 
 
 int cgnn_gcn_fused_pool_fwd(const float* Y, const float* bn, float p_drop, uint64_t seed,
                             const uint32_t* seed_dev, uint8_t* mask_out, const int32_t* gptr,
-                            int32_t num_graphs, float* P, void* stream) {
+                            int32_t num_graphs, float* P, float* F1, float* F2, void* stream) {
   if (num_graphs < 0 || p_drop < 0.f || p_drop >= 1.f) return CGNN_EINVAL;
   if (num_graphs == 0) return CGNN_OK;
-  if (!Y || !bn || !gptr || !P) return CGNN_EINVAL;
+  if (!Y || !bn || !gptr || !P || (!F1) != (!F2)) return CGNN_EINVAL;
   int use_drop;
   DropCfg d = make_drop(p_drop, seed, &use_drop);
   d.dev_key = seed_dev;
   const int grid = num_graphs < 8 * fused_grid() ? num_graphs : 8 * fused_grid();
-  k_pool_fwd<<<grid, PTHR, 0, cgnn_stream(stream)>>>(Y, bn, d, use_drop, mask_out, gptr, num_graphs, P);
+  k_pool_fwd<<<grid, PTHR, 0, cgnn_stream(stream)>>>(Y, bn, d, use_drop, mask_out, gptr, num_graphs, P,
+                                                     F1, F2);
+  CGNN_CHECK_LAUNCH();
+  return CGNN_OK;
+}
+
+int cgnn_gcn_fused_pool_bwd_sums(const float* dP, const float* F1, const float* F2,
+                                 const int32_t* gptr, int32_t num_graphs, double* s_slab,
+                                 void* stream) {
+  if (num_graphs < 0 || !dP || !F1 || !F2 || !gptr || !s_slab) return CGNN_EINVAL;
+  // exactly cgnn_fused_grid() workgroups so that the slab has the documented row count
+  k_pool_bwd_sums<<<fused_grid(), 128, 0, cgnn_stream(stream)>>>(dP, F1, F2, gptr, num_graphs, s_slab);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }
@@ -1281,28 +1386,28 @@ int cgnn_bn_bwd_finalize(const double* sums, double count, const double* count_d
 }
 
 int cgnn_gcn_fused_bwd(const cgnn_tiles* t, const float* dZ, const float* Y, const float* bn,
-                       const float* bwc, const float* Yprev, const float* bn_prev, float p_drop,
-                       const uint8_t* mask_prev, const float* W, float* dZprev,
-                       double* s_slab_prev, float* dW_slab, double* db_slab, const float* dP,
-                       const int32_t* node_graph, const int32_t* gptr, const uint8_t* mask_cur,
-                       void* stream) {
+                       const float* bwc, const float* Yprev, const cgnn_l0src* l0,
+                       const float* bn_prev, float p_drop, const uint8_t* mask_prev, const float* W,
+                       float* dZprev, double* s_slab_prev, float* dW_slab, double* db_slab,
+                       const float* dP, const int32_t* node_graph, const int32_t* gptr,
+                       const uint8_t* mask_cur, void* stream) {
   if (!tiles_ok(t)) return t && t->max_tile_rows > CGNN_FUSED_MAX_ROWS ? CGNN_EUNSUPPORTED : CGNN_EINVAL;
-  if (!Y || !bn || !bwc || !Yprev || !bn_prev || !W || !dZprev || !s_slab_prev || !dW_slab ||
-      !db_slab || p_drop < 0.f || p_drop >= 1.f)
+  if (!Y || !bn || !bwc || (!Yprev && !l0src_ok(l0)) || !bn_prev || !W || !dZprev || !s_slab_prev ||
+      !dW_slab || !db_slab || p_drop < 0.f || p_drop >= 1.f)
     return CGNN_EINVAL;
   if (p_drop > 0.f && !mask_prev) return CGNN_EINVAL;
   if (dP ? (!node_graph || !gptr || (p_drop > 0.f && !mask_cur)) : !dZ) return CGNN_EINVAL;
   int use_drop;
   DropCfg d = make_drop(p_drop, 0, &use_drop);
   PoolIn pin{dP, node_graph, gptr, mask_cur};
-  if (dP)
-    k_gcn_bwd<CGNN_FUSED_MAX_ROWS, false, true><<<fused_grid(), NTHR, 0, cgnn_stream(stream)>>>(
-        *t, pin, dZ, Y, bn, bwc, Yprev, 0, bn_prev, d, use_drop, mask_prev, W, dZprev, s_slab_prev,
-        dW_slab, db_slab);
-  else
-    k_gcn_bwd<CGNN_FUSED_MAX_ROWS, false, false><<<fused_grid(), NTHR, 0, cgnn_stream(stream)>>>(
-        *t, pin, dZ, Y, bn, bwc, Yprev, 0, bn_prev, d, use_drop, mask_prev, W, dZprev, s_slab_prev,
-        dW_slab, db_slab);
+  const cgnn_l0src src = Yprev ? cgnn_l0src{} : *l0;
+#define CGNN_BWD_LAUNCH(POOL, XP)                                                                      \
+  k_gcn_bwd<CGNN_FUSED_MAX_ROWS, false, POOL, XP><<<fused_grid(), NTHR, 0, cgnn_stream(stream)>>>(     \
+      *t, pin, src, dZ, Y, bn, bwc, Yprev, 0, bn_prev, d, use_drop, mask_prev, W, dZprev, s_slab_prev, \
+      dW_slab, db_slab)
+  if (dP) { if (Yprev) CGNN_BWD_LAUNCH(true, false); else CGNN_BWD_LAUNCH(true, true); }
+  else    { if (Yprev) CGNN_BWD_LAUNCH(false, false); else CGNN_BWD_LAUNCH(false, true); }
+#undef CGNN_BWD_LAUNCH
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }
@@ -1320,11 +1425,11 @@ int cgnn_gcn_fused_bwd_first(const cgnn_tiles* t, const float* dZ, const float* 
   PoolIn pin{dP, node_graph, gptr, mask_cur};
   if (dP)
     k_gcn_bwd<CGNN_FUSED_MAX_ROWS, true, true><<<fused_grid(), NTHR, 0, cgnn_stream(stream)>>>(
-        *t, pin, dZ, Y, bn, bwc, X0, F0, nullptr, d, use_drop, nullptr, nullptr, nullptr, nullptr,
+        *t, pin, cgnn_l0src{}, dZ, Y, bn, bwc, X0, F0, nullptr, d, use_drop, nullptr, nullptr, nullptr, nullptr,
         dW_slab, db_slab);
   else
     k_gcn_bwd<CGNN_FUSED_MAX_ROWS, true, false><<<fused_grid(), NTHR, 0, cgnn_stream(stream)>>>(
-        *t, pin, dZ, Y, bn, bwc, X0, F0, nullptr, d, use_drop, nullptr, nullptr, nullptr, nullptr,
+        *t, pin, cgnn_l0src{}, dZ, Y, bn, bwc, X0, F0, nullptr, d, use_drop, nullptr, nullptr, nullptr, nullptr,
         dW_slab, db_slab);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;

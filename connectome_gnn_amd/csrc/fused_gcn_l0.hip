@@ -9,10 +9,14 @@
 //
 //   k_l0_fwd : per tile, X0*dis -> LDS [rows][8]; one thread per destination row walks its
 //              blocked-ELL entries; P0 -> LDS + HBM; Y0 = P0 W0^T + b on the vector ALUs
-//              (5 FMAs per output) with float4 stores; BatchNorm sums in the epilogue.
+//              (5 FMAs per output) for the BatchNorm sums in the epilogue.  Y0 itself is
+//              written only on request (Y != NULL): the fused path rebuilds its rows from P0
+//              wherever they are needed (l0src.h), 32 instead of 256 bytes per node.
 //              25 KB of LDS per workgroup -> 6 workgroups per CU hide the gather latency.
-//   k_l0_bwd : dY0 = BatchNorm'(dZ0); dW0 += dY0^T P0; db0 += dY0  (no LDS tile, no metadata).
+//   k_l0_bwd : dY0 = BatchNorm'(dZ0); dW0 += dY0^T P0; db0 += dY0  (no LDS tile, no metadata;
+//              Y0 read from HBM or rebuilt from the P0 row it loads anyway).
 #include "common.h"
+#include "l0src.h"
 
 namespace {
 
@@ -38,12 +42,8 @@ __global__ void __launch_bounds__(L0THR, 5) k_l0_fwd(cgnn_tiles t, const float* 
   const uint2* ent = static_cast<const uint2*>(t.ent_dst);
   // W0^T in LDS: wl[k][col] = W0[col][k] (zero for k >= F0); occupancy matters more here than
   // 32 registers of weights (the row gather is hidden by many resident waves, not by ILP)
-  __shared__ __attribute__((aligned(16))) float wl[FP * HID];
-  for (int i = threadIdx.x; i < FP * HID; i += L0THR) {
-    const int k = i >> 6, c = i & 63;
-    wl[i] = k < F0 ? W0[c * F0 + k] : 0.f;
-  }
-  const float4 b4 = ld4(bias + 4 * j);
+  __shared__ __attribute__((aligned(16))) float wl[L0_LDS_FLOATS];
+  l0_stage(wl, cgnn_l0src{nullptr, W0, bias, F0}, L0THR);
   // per-thread partial sums stay fp32 (a thread sees <= ~16 rows per tile, a few tiles); the
   // cross-thread / cross-workgroup combination is fp64
   float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
@@ -107,25 +107,14 @@ __global__ void __launch_bounds__(L0THR, 5) k_l0_fwd(cgnn_tiles t, const float* 
       const float4 p0 = ld4(ps + r * FP), p1 = ld4(ps + r * FP + 4);
       const float4 q0 = two ? ld4(ps + r2 * FP) : make_float4(0.f, 0.f, 0.f, 0.f);
       const float4 q1 = two ? ld4(ps + r2 * FP + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-      const float pv[FP] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
-      const float qv[FP] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-      float4 y = b4, z = b4;
-#pragma unroll
-      for (int k = 0; k < FP; ++k) {
-        if (k < F0) {                                 // wave-uniform: columns >= F0 are zero
-          const float4 wk = ld4(wl + k * HID + 4 * j);
-          y.x = fmaf(pv[k], wk.x, y.x); y.y = fmaf(pv[k], wk.y, y.y);
-          y.z = fmaf(pv[k], wk.z, y.z); y.w = fmaf(pv[k], wk.w, y.w);
-          z.x = fmaf(qv[k], wk.x, z.x); z.y = fmaf(qv[k], wk.y, z.y);
-          z.z = fmaf(qv[k], wk.z, z.z); z.w = fmaf(qv[k], wk.w, z.w);
-        }
-      }
-      st4(Y + (int64_t)(base + r) * HID + 4 * j, y);
+      const float4 y = l0_rebuild4(p0, p1, wl, 4 * j, F0);
+      const float4 z = l0_rebuild4(q0, q1, wl, 4 * j, F0);
+      if (Y) st4(Y + (int64_t)(base + r) * HID + 4 * j, y);
       s1[0] += y.x; s1[1] += y.y; s1[2] += y.z; s1[3] += y.w;
       s2[0] = fmaf(y.x, y.x, s2[0]); s2[1] = fmaf(y.y, y.y, s2[1]);
       s2[2] = fmaf(y.z, y.z, s2[2]); s2[3] = fmaf(y.w, y.w, s2[3]);
       if (two) {
-        st4(Y + (int64_t)(base + r2) * HID + 4 * j, z);
+        if (Y) st4(Y + (int64_t)(base + r2) * HID + 4 * j, z);
         s1[0] += z.x; s1[1] += z.y; s1[2] += z.z; s1[3] += z.w;
         s2[0] = fmaf(z.x, z.x, s2[0]); s2[1] = fmaf(z.y, z.y, s2[1]);
         s2[2] = fmaf(z.z, z.z, s2[2]); s2[3] = fmaf(z.w, z.w, s2[3]);
@@ -151,8 +140,9 @@ __global__ void __launch_bounds__(L0THR, 5) k_l0_fwd(cgnn_tiles t, const float* 
 }
 
 // dW0[o][k] = sum_rows dY0[row][o] * P0[row][k];  db0[o] = sum_rows dY0[row][o]
+template <bool REBUILD>
 __global__ void __launch_bounds__(L0BTHR) k_l0_bwd(const float* __restrict__ dZ,
-                                                  const float* __restrict__ Y,
+                                                  const float* __restrict__ Y, cgnn_l0src l0,
                                                   const float* __restrict__ bn,
                                                   const float* __restrict__ bwc,
                                                   const float* __restrict__ P0, int64_t nn,
@@ -160,6 +150,11 @@ __global__ void __launch_bounds__(L0BTHR) k_l0_bwd(const float* __restrict__ dZ,
                                                   double* __restrict__ db_slab) {
   __shared__ float redw[16 * HID * FP];          // 32 KB
   __shared__ double redb[16 * HID];
+  __shared__ __attribute__((aligned(16))) float wl[REBUILD ? L0_LDS_FLOATS : 4];
+  if (REBUILD) {
+    l0_stage(wl, l0, L0BTHR);
+    __syncthreads();
+  }
   const int j = threadIdx.x & 15, rr = threadIdx.x >> 4;
   const float4 ca = ld4(bn + 4 * j), cmean = ld4(bn + 2 * HID + 4 * j), cis = ld4(bn + 3 * HID + 4 * j);
   const float4 c1 = ld4(bwc + 4 * j), c2 = ld4(bwc + HID + 4 * j);
@@ -179,7 +174,7 @@ __global__ void __launch_bounds__(L0BTHR) k_l0_bwd(const float* __restrict__ dZ,
       zb[u] = yb[u] = pa[u] = pb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row < nn) {
         zb[u] = ld4(dZ + row * HID + 4 * j);
-        yb[u] = ld4(Y + row * HID + 4 * j);
+        if (!REBUILD) yb[u] = ld4(Y + row * HID + 4 * j);
         pa[u] = ld4(P0 + row * FP);
         pb[u] = ld4(P0 + row * FP + 4);
       }
@@ -188,7 +183,8 @@ __global__ void __launch_bounds__(L0BTHR) k_l0_bwd(const float* __restrict__ dZ,
     for (int u = 0; u < U; ++u) {
       const int64_t row = row0 + stride * u;
       if (row < nn) {
-        const float4 dz = zb[u], y = yb[u];
+        const float4 dz = zb[u];
+        const float4 y = REBUILD ? l0_rebuild4(pa[u], pb[u], wl, 4 * j, l0.F0) : yb[u];
         const float dy[4] = {ca.x * (dz.x - c1.x - (y.x - cmean.x) * cis.x * c2.x),
                              ca.y * (dz.y - c1.y - (y.y - cmean.y) * cis.y * c2.y),
                              ca.z * (dz.z - c1.z - (y.z - cmean.z) * cis.z * c2.z),
@@ -240,7 +236,7 @@ int cgnn_gcn_l0_fwd(const cgnn_tiles* t, const float* X0, int32_t F0, const floa
                     const float* bias, float* P0, float* Y, double* stat_slab, void* stream) {
   if (!t || F0 <= 0 || F0 > FP || t->max_tile_rows > CGNN_FUSED_MAX_ROWS) return t && F0 > FP ? CGNN_EUNSUPPORTED : CGNN_EINVAL;
   if (t->num_tiles == 0) return CGNN_OK;
-  if (!X0 || !W0 || !bias || !P0 || !Y || !t->tile_ptr || !t->tile_blk || !t->blk_off_dst ||
+  if (!X0 || !W0 || !bias || !P0 || !t->tile_ptr || !t->tile_blk || !t->blk_off_dst ||
       !t->ent_dst || !t->dis)
     return CGNN_EINVAL;
   k_l0_fwd<<<l0_grid(), L0THR, 0, cgnn_stream(stream)>>>(*t, X0, F0, W0, bias, P0, Y, stat_slab);
@@ -248,11 +244,17 @@ int cgnn_gcn_l0_fwd(const cgnn_tiles* t, const float* X0, int32_t F0, const floa
   return CGNN_OK;
 }
 
-int cgnn_gcn_l0_bwd(const float* dZ, const float* Y, const float* bn, const float* bwc,
-                    const float* P0, int64_t num_nodes, float* dW_slab, double* db_slab,
-                    void* stream) {
-  if (num_nodes < 0 || !dZ || !Y || !bn || !bwc || !P0 || !dW_slab || !db_slab) return CGNN_EINVAL;
-  k_l0_bwd<<<l0_grid(), L0BTHR, 0, cgnn_stream(stream)>>>(dZ, Y, bn, bwc, P0, num_nodes, dW_slab, db_slab);
+int cgnn_gcn_l0_bwd(const float* dZ, const float* Y, const cgnn_l0src* l0, const float* bn,
+                    const float* bwc, const float* P0, int64_t num_nodes, float* dW_slab,
+                    double* db_slab, void* stream) {
+  if (num_nodes < 0 || !dZ || !bn || !bwc || !P0 || !dW_slab || !db_slab) return CGNN_EINVAL;
+  if (!Y && !(l0 && l0->W0 && l0->b0 && l0->F0 >= 1 && l0->F0 <= FP)) return CGNN_EINVAL;
+  if (Y)
+    k_l0_bwd<false><<<l0_grid(), L0BTHR, 0, cgnn_stream(stream)>>>(dZ, Y, cgnn_l0src{}, bn, bwc, P0,
+                                                                   num_nodes, dW_slab, db_slab);
+  else
+    k_l0_bwd<true><<<l0_grid(), L0BTHR, 0, cgnn_stream(stream)>>>(dZ, nullptr, *l0, bn, bwc, P0,
+                                                                  num_nodes, dW_slab, db_slab);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }

@@ -50,7 +50,7 @@ def _tiles_struct(s: BatchStructure, meta, dis: torch.Tensor):
 
 class _Ctx:
     """Everything of one forward pass that backward needs and autograd must not track."""
-    __slots__ = ("s", "meta", "dis", "tiles", "grid", "ys", "bns", "masks", "p", "x0", "f0", "p0", "count_dev",
+    __slots__ = ("s", "meta", "dis", "tiles", "grid", "ys", "bns", "masks", "p", "x0", "f0", "p0", "count_dev", "fsum", "l0src", "l0keep",
                  "count", "sync_group", "num_layers", "training")
 
 
@@ -91,7 +91,7 @@ class FusedGCNEncode(torch.autograd.Function):
         local_count = count = float(nn_)
         count_dev = None                           # device copy of the global row count (sync-BN)
         narrow0 = L >= 2 and x0.shape[1] <= 8      # layer-0 narrow form (fused_gcn_l0.hip)
-        p0 = None
+        p0 = l0src = l0keep = None
         _sp = _lib.stream_ptr(dev)          # one lookup per pass (torch.cuda.current_stream is ~10 us)
         st = lambda: _sp
         rng = meta.get("rng_state")       # device uint32 words: set when the step is graph-captured
@@ -104,17 +104,22 @@ class FusedGCNEncode(torch.autograd.Function):
                 _lib.check(lib.cgnn_rng_advance(_lib.ptr(rng), L + 1, st()), "cgnn_rng_advance")
             for l in range(L):
                 w, b, gamma, beta = (t.contiguous() for t in params[4 * l:4 * l + 4])
-                y = torch.empty(nn_, HID, **f32)
+                y = torch.empty(nn_, HID, **f32) if not (l == 0 and narrow0) else None
                 slab, slab_rows = stat_slab, grid
                 if l == 0 and narrow0:
-                    # layer 0, narrow form: Y0 = (A_hat X0) W0^T + b, P0 = A_hat X0 kept
+                    # layer 0, narrow form: Y0 = (A_hat X0) W0^T + b is NEVER written: only the
+                    # narrow aggregate P0 = A_hat X0 (32 B per node) is kept and every consumer
+                    # rebuilds the rows of Y0 it needs from it (cgnn_l0src)
+                    y = None
                     p0 = torch.empty(nn_, 8, **f32)
+                    l0src = _lib.CgnnL0Src(_lib.ptr(p0), _lib.ptr(w), _lib.ptr(b), int(x0.shape[1]))
+                    l0keep = (w, b)                     # the struct holds raw pointers
                     slab_rows = lib.cgnn_l0_grid()
                     slab = torch.empty(slab_rows, 128, dtype=torch.float64, device=dev) if training else None
                     with _lib.timed("cgnn_gcn_l0_fwd"):
                         _lib.check(lib.cgnn_gcn_l0_fwd(
                             tp, _lib.ptr(x0), x0.shape[1], _lib.ptr(w), _lib.ptr(b), _lib.ptr(p0),
-                            _lib.ptr(y), _lib.ptr(slab), st()), "cgnn_gcn_l0_fwd")
+                            None, _lib.ptr(slab), st()), "cgnn_gcn_l0_fwd")
                 elif l == 0:
                     with _lib.timed("cgnn_gcn_fused_fwd_first"):
                         _lib.check(lib.cgnn_gcn_fused_fwd_first(
@@ -125,7 +130,8 @@ class FusedGCNEncode(torch.autograd.Function):
                     seed = _lib.next_seed(dev) if p > 0 else 0
                     with _lib.timed("cgnn_gcn_fused_fwd"):
                         _lib.check(lib.cgnn_gcn_fused_fwd(
-                            tp, _lib.ptr(ys[-1]), _lib.ptr(bns[-1]), p, seed, rng_ptr(l), _lib.ptr(mask),
+                            tp, _lib.ptr(ys[-1]), ctypes.byref(l0src) if ys[-1] is None else None,
+                            _lib.ptr(bns[-1]), p, seed, rng_ptr(l), _lib.ptr(mask),
                             _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), _lib.ptr(stat_slab), st()),
                             "cgnn_gcn_fused_fwd")
                     masks.append(mask)
@@ -161,15 +167,21 @@ class FusedGCNEncode(torch.autograd.Function):
             mask = torch.empty(nn_ * 16, dtype=torch.uint8, device=dev) if p > 0 else None
             seed = _lib.next_seed(dev) if p > 0 else 0
             pooled = torch.empty(B, HID, **f32)
+            # per-graph factor sums: the readout backward needs no second pass over Y
+            want_grad = any(ctx.needs_input_grad[2:])
+            fsum = torch.empty(2, B, HID, **f32) if want_grad else None
             _lib.check(lib.cgnn_gcn_fused_pool_fwd(
                 _lib.ptr(ys[-1]), _lib.ptr(bns[-1]), p, seed, rng_ptr(L), _lib.ptr(mask), _lib.ptr(s.gptr), B,
-                _lib.ptr(pooled), st()), "cgnn_gcn_fused_pool_fwd")
+                _lib.ptr(pooled), _lib.ptr(fsum), None if fsum is None else fsum.data_ptr() + 4 * B * HID,
+                st()), "cgnn_gcn_fused_pool_fwd")
             masks.append(mask)
         c = _Ctx()
         c.s, c.meta, c.dis, c.tiles, c.grid = s, fmeta, dis, tiles, grid
         c.ys, c.bns, c.masks, c.p, c.x0, c.f0, c.p0 = ys, bns, masks, p, x0, x0.shape[1], p0
         c.count, c.sync_group, c.num_layers, c.training = count, sync_group, L, training
         c.count_dev = count_dev
+        c.fsum = fsum
+        c.l0src, c.l0keep = l0src, l0keep
         if meta.get("record") is not None:
             meta["record"]["layers"] = list(masks)
         ctx.c = c
@@ -225,10 +237,15 @@ class FusedGCNEncode(torch.autograd.Function):
         pool_args = (_lib.ptr(d_pooled), _lib.ptr(s.node_graph), _lib.ptr(s.gptr), _lib.ptr(c.masks[-1]))
         none_args = (None, None, None, None)
         with _lib.device_guard(dev):
-            _lib.check(lib.cgnn_gcn_fused_pool_bwd(
-                _lib.ptr(d_pooled), _lib.ptr(c.ys[-1]), _lib.ptr(c.bns[-1]), c.p,
-                _lib.ptr(c.masks[-1]), _lib.ptr(s.gptr), B, None, _lib.ptr(s_slab), st()),
-                "cgnn_gcn_fused_pool_bwd")
+            if c.fsum is not None:
+                _lib.check(lib.cgnn_gcn_fused_pool_bwd_sums(
+                    _lib.ptr(d_pooled), _lib.ptr(c.fsum), c.fsum.data_ptr() + 4 * B * HID, _lib.ptr(s.gptr), B,
+                    _lib.ptr(s_slab), st()), "cgnn_gcn_fused_pool_bwd_sums")
+            else:
+                _lib.check(lib.cgnn_gcn_fused_pool_bwd(
+                    _lib.ptr(d_pooled), _lib.ptr(c.ys[-1]), _lib.ptr(c.bns[-1]), c.p,
+                    _lib.ptr(c.masks[-1]), _lib.ptr(s.gptr), B, None, _lib.ptr(s_slab), st()),
+                    "cgnn_gcn_fused_pool_bwd")
             bwc = bn_backward(L - 1)
             for l in range(L - 1, 0, -1):
                 w = params[4 * l].contiguous()
@@ -236,7 +253,8 @@ class FusedGCNEncode(torch.autograd.Function):
                 with _lib.timed("cgnn_gcn_fused_bwd"):
                     _lib.check(lib.cgnn_gcn_fused_bwd(
                         tp, _lib.ptr(dz), _lib.ptr(c.ys[l]), _lib.ptr(c.bns[l]), _lib.ptr(bwc),
-                        _lib.ptr(c.ys[l - 1]), _lib.ptr(c.bns[l - 1]), c.p, _lib.ptr(c.masks[l - 1]),
+                        _lib.ptr(c.ys[l - 1]), ctypes.byref(c.l0src) if c.ys[l - 1] is None else None,
+                        _lib.ptr(c.bns[l - 1]), c.p, _lib.ptr(c.masks[l - 1]),
                         _lib.ptr(w), _lib.ptr(dz_prev), _lib.ptr(s_slab), _lib.ptr(dw_slab),
                         _lib.ptr(db_slab), *extra, st()), "cgnn_gcn_fused_bwd")
                 dw, db = torch.empty(HID, HID, **f32), torch.empty(HID, **f32)
@@ -254,7 +272,7 @@ class FusedGCNEncode(torch.autograd.Function):
                 db_slab0 = torch.empty(g0, HID, **f64)
                 with _lib.timed("cgnn_gcn_l0_bwd"):
                     _lib.check(lib.cgnn_gcn_l0_bwd(
-                        _lib.ptr(dz), _lib.ptr(c.ys[0]), _lib.ptr(c.bns[0]), _lib.ptr(bwc),
+                        _lib.ptr(dz), None, ctypes.byref(c.l0src), _lib.ptr(c.bns[0]), _lib.ptr(bwc),
                         _lib.ptr(c.p0), nn_, _lib.ptr(dw_slab0), _lib.ptr(db_slab0), st()),
                         "cgnn_gcn_l0_bwd")
                 _lib.check(lib.cgnn_dw_db_reduce(_lib.ptr(dw_slab0), _lib.ptr(db_slab0), g0, 8, c.f0,

@@ -245,6 +245,18 @@ typedef struct cgnn_tiles {
   const float* dis;             /* [num_nodes] */
 } cgnn_tiles;
 
+/* Layer 0's output in factored form.  For F0 <= 8 input features the fused path never writes
+ * Y0 [Nn,64] to HBM: consumers rebuild a row from the narrow aggregate P0 = A_hat X0 (32 bytes per
+ * node) as  y[c] = b0[c] + sum_{k<F0} P0[row][k] * W0[c][k]  (k ascending, fused multiply-adds --
+ * the same expression in every kernel, so all of them see the same bits).  Saves one 256-byte
+ * write and three 256-byte reads per node and step for 5 FMAs per rebuilt element. */
+typedef struct cgnn_l0src {
+  const float* P0;              /* [num_nodes, 8], columns >= F0 zero */
+  const float* W0;              /* [64, F0] */
+  const float* b0;              /* [64] */
+  int32_t F0;                   /* 1..8 */
+} cgnn_l0src;
+
 /* Number of persistent workgroups every fused kernel launches (= rows of every slab). */
 int cgnn_fused_grid(void);
 
@@ -295,15 +307,16 @@ int cgnn_dense_aggregate_f16(const void* M, int32_t P, const int32_t* gptr, int3
 int cgnn_gcn_fused_fwd_first(const cgnn_tiles* t, const float* X0, int32_t F0, const float* W0,
                              const float* bias, float* Y, double* stat_slab, void* stream);
 
-/* Layer l>0 forward.  Yprev [Nn,64] + bn_prev -> X on the fly; W [64,64]; mask_out nullable. */
+/* Layer l>0 forward.  Yprev [Nn,64] + bn_prev -> X on the fly; W [64,64]; mask_out nullable.
+ * Yprev == NULL: the previous layer is layer 0 in factored form, rows rebuilt from *l0. */
 /* seed_dev (nullable): device word XOR-ed into the dropout key at kernel start.  Under HIP-graph
  * replay the by-value `seed` is frozen in the graph; a captured cgnn_rng_advance on the same
  * stream then makes every replay draw fresh masks. */
 int cgnn_rng_advance(uint32_t* state, int32_t n, void* stream);
-int cgnn_gcn_fused_fwd(const cgnn_tiles* t, const float* Yprev, const float* bn_prev,
-                       float p_drop, uint64_t seed, const uint32_t* seed_dev, uint8_t* mask_out,
-                       const float* W, const float* bias, float* Y, double* stat_slab,
-                       void* stream);
+int cgnn_gcn_fused_fwd(const cgnn_tiles* t, const float* Yprev, const cgnn_l0src* l0,
+                       const float* bn_prev, float p_drop, uint64_t seed, const uint32_t* seed_dev,
+                       uint8_t* mask_out, const float* W, const float* bias, float* Y,
+                       double* stat_slab, void* stream);
 
 /* slab [rows][width] fp64 -> sums [width] fp64 (fixed-order tree). */
 int cgnn_bn_reduce(const double* slab, int32_t rows, int32_t width, double* sums, void* stream);
@@ -318,10 +331,19 @@ int cgnn_bn_finalize(const double* sums, double count, const double* count_dev, 
                      const float* beta, float* running_mean, float* running_var, float momentum,
                      float eps, int32_t training, float* bn_out, void* stream);
 
-/* Readout: P[g,:] = mean over nodes of drop(relu(a*Y+b)) (models.py:209-211,57-59). */
+/* Readout: P[g,:] = mean over nodes of drop(relu(a*Y+b)) (models.py:209-211,57-59).
+ * F1, F2 (both or neither; [num_graphs,64]): per graph and column the sums over the graph's rows
+ * of f = relu'(z)*keep/(1-p) and of f*xhat -- what cgnn_gcn_fused_pool_bwd_sums needs. */
 int cgnn_gcn_fused_pool_fwd(const float* Y, const float* bn, float p_drop, uint64_t seed,
                             const uint32_t* seed_dev, uint8_t* mask_out, const int32_t* gptr,
-                            int32_t num_graphs, float* P, void* stream);
+                            int32_t num_graphs, float* P, float* F1, float* F2, void* stream);
+
+/* BatchNorm-backward sums of the LAST layer without re-reading Y: the readout's gradient is
+ * dP[g]/(n_g+1e-8) for every row of graph g, so  sum dZ = sum_g dP[g]/n_g * F1[g]  and
+ * sum dZ*xhat = sum_g dP[g]/n_g * F2[g].  s_slab [cgnn_fused_grid()][128] fp64 partials. */
+int cgnn_gcn_fused_pool_bwd_sums(const float* dP, const float* F1, const float* F2,
+                                 const int32_t* gptr, int32_t num_graphs, double* s_slab,
+                                 void* stream);
 
 /* Backward of the readout through dropout/ReLU: dZ = dP[g]/(n_g+1e-8) * drop' * relu';
  * also the BatchNorm-backward sums of the last layer: s_slab [grid][128] = sum dZ | sum dZ*xhat.
@@ -339,13 +361,14 @@ int cgnn_bn_bwd_finalize(const double* sums, double count, const double* count_d
  * Outputs: dZprev [Nn,64]; s_slab_prev [grid][128]; dW_slab [grid][64*64]; db_slab [grid][64]. */
 /* Last layer only: pass dP != NULL (then dZ is ignored and may be NULL) together with
  * node_graph int32 [Nn], gptr int32 [B+1] and mask_cur (this layer's keep bits): the incoming
- * gradient is rebuilt per row as dP[g]/(n_g+1e-8) * relu' * dropout'.  Otherwise dP = NULL. */
+ * gradient is rebuilt per row as dP[g]/(n_g+1e-8) * relu' * dropout'.  Otherwise dP = NULL.
+ * Yprev == NULL: the previous layer is layer 0 in factored form, rows rebuilt from *l0. */
 int cgnn_gcn_fused_bwd(const cgnn_tiles* t, const float* dZ, const float* Y, const float* bn,
-                       const float* bwc, const float* Yprev, const float* bn_prev, float p_drop,
-                       const uint8_t* mask_prev, const float* W, float* dZprev,
-                       double* s_slab_prev, float* dW_slab, double* db_slab, const float* dP,
-                       const int32_t* node_graph, const int32_t* gptr, const uint8_t* mask_cur,
-                       void* stream);
+                       const float* bwc, const float* Yprev, const cgnn_l0src* l0,
+                       const float* bn_prev, float p_drop, const uint8_t* mask_prev, const float* W,
+                       float* dZprev, double* s_slab_prev, float* dW_slab, double* db_slab,
+                       const float* dP, const int32_t* node_graph, const int32_t* gptr,
+                       const uint8_t* mask_cur, void* stream);
 
 /* Layer 0 backward: dW0 = dT^T X0 only.  dW_slab [grid][64*16] (columns >= F0 are zero). */
 int cgnn_gcn_fused_bwd_first(const cgnn_tiles* t, const float* dZ, const float* Y,
@@ -360,11 +383,13 @@ int cgnn_gcn_fused_bwd_first(const cgnn_tiles* t, const float* dZ, const float* 
  * db_slab [..][64] fp64.  (cgnn_gcn_fused_fwd_first/bwd_first remain for 8 < F0 <= 16 and for
  * one-layer models.) */
 int cgnn_l0_grid(void);
+/* Y (forward) may be NULL: only P0 and the statistics are produced and every consumer rebuilds
+ * Y0's rows from a cgnn_l0src.  Backward: Y == NULL -> rebuilt from P0 with l0->W0/b0/F0. */
 int cgnn_gcn_l0_fwd(const cgnn_tiles* t, const float* X0, int32_t F0, const float* W0,
                     const float* bias, float* P0, float* Y, double* stat_slab, void* stream);
-int cgnn_gcn_l0_bwd(const float* dZ, const float* Y, const float* bn, const float* bwc,
-                    const float* P0, int64_t num_nodes, float* dW_slab, double* db_slab,
-                    void* stream);
+int cgnn_gcn_l0_bwd(const float* dZ, const float* Y, const cgnn_l0src* l0, const float* bn,
+                    const float* bwc, const float* P0, int64_t num_nodes, float* dW_slab,
+                    double* db_slab, void* stream);
 
 /* Single-launch forms of (cgnn_bn_reduce + cgnn_bn_finalize [+ num_batches_tracked += 1]),
  * (cgnn_bn_reduce + cgnn_bn_bwd_finalize) and (cgnn_slab_reduce_f32 + cgnn_slab_reduce_f64):
