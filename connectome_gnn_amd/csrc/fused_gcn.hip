@@ -373,6 +373,86 @@ __global__ void __launch_bounds__(NTHR) k_gcn_fwd(
     reduce_stats(s1, s2, reinterpret_cast<double*>(tile), stat_slab + (int64_t)blockIdx.x * 128);
 }
 
+// ------------------------------------------------------------------------------------------
+// fp32 products on the bf16 matrix pipe, exactly split ("bf16x3").
+// An fp32 value is cut into three bf16 pieces by TRUNCATION: h = top 8 significant bits,
+// m = the next 8, l = the last 8, so x == h + m + l exactly and every piece is exactly a bf16.
+// A product x*w is then the six partial products of total order <= 2
+//     h*h' + (h*m' + m*h') + (h*l' + m*m' + l*h')
+// each exact in fp32 (8 x 8 significant bits) and accumulated in fp32 by
+// v_mfma_f32_16x16x32_bf16; the three dropped terms are <= 2^-24 of the product, i.e. at the
+// rounding level of an fp32 multiply-add.  Six bf16 MFMAs of K = 32 replace sixteen fp32 MFMAs
+// of K = 4 for the same 16x16x64 product: 6 x 2 x 16 = 192 instead of 16 x 32 = 512 matrix-pipe
+// cycles per output tile (the fp32 pipe is 1/16 of the bf16 rate on gfx950).
+// ------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ uint32_t pack_hi16(float lo, float hi) {   // (bf16(lo), bf16(hi)), truncating
+  return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
+}
+__device__ __forceinline__ float trunc_bf16(float x) { return __uint_as_float(__float_as_uint(x) & 0xFFFF0000u); }
+
+struct Split8 { uint4 h, m, l; };     // 8 values (two float4) as three bf16x8 fragments
+
+__device__ __forceinline__ Split8 split8(const float4& a, const float4& b) {
+  const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  uint32_t ph[4], pm[4], pl[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float x0 = x[2 * p], x1 = x[2 * p + 1];
+    const float r0 = x0 - trunc_bf16(x0), r1 = x1 - trunc_bf16(x1);
+    const float l0 = r0 - trunc_bf16(r0), l1 = r1 - trunc_bf16(r1);
+    ph[p] = pack_hi16(x0, x1);
+    pm[p] = pack_hi16(r0, r1);
+    pl[p] = pack_hi16(l0, l1);
+  }
+  Split8 s;
+  s.h = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+  s.m = make_uint4(pm[0], pm[1], pm[2], pm[3]);
+  s.l = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+  return s;
+}
+
+__device__ __forceinline__ f32x4 mfma_bf16(const uint4& a, const uint4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
+                                                 c, 0, 0, 0);
+}
+// acc += A * B for split operands, smallest terms first
+__device__ __forceinline__ f32x4 mfma_split(const Split8& a, const uint4& bh, const uint4& bm,
+                                            const uint4& bl, f32x4 acc) {
+  acc = mfma_bf16(a.l, bh, acc);
+  acc = mfma_bf16(a.h, bl, acc);
+  acc = mfma_bf16(a.m, bm, acc);
+  acc = mfma_bf16(a.m, bh, acc);
+  acc = mfma_bf16(a.h, bm, acc);
+  acc = mfma_bf16(a.h, bh, acc);
+  return acc;
+}
+
+// Split weight panel in LDS for  out[row][4j+tj] = sum_k x[row][k] * B[k][4j+tj]  (16x16x32 tiles):
+// fragment (term, mstep, tj) of lane (q, j) holds k = 16*(2*mstep + (e>>2)) + 4q + (e&3), e = 0..7
+// -- the k order in which the A side keeps a row (two float4 chunks per MFMA).  Layout
+// wsp[((term*2 + mstep)*4 + tj)*64 + lane], 16 bytes each: every B read is one conflict-free
+// ds_read_b128.  24 KB.
+constexpr int WSP_FRAGS = 3 * 2 * 4 * 64;
+template <bool TRANSPOSED>     // false: B[k][n] = W[n][k] (X W^T);  true: B[k][n] = W[k][n] (dT W)
+__device__ __forceinline__ void stage_split_weight(uint4* wsp, const float* __restrict__ W, int nthreads) {
+  for (int idx = threadIdx.x; idx < 2 * 4 * 64; idx += nthreads) {
+    const int ln = idx & 63, tj = (idx >> 6) & 3, ms = idx >> 8;
+    const int qq = ln >> 4, jj = ln & 15;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = 16 * (2 * ms + (e >> 2)) + 4 * qq + (e & 3), n = 4 * jj + tj;
+      v[e] = TRANSPOSED ? W[k * HID + n] : W[n * HID + k];
+    }
+    const Split8 s = split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
+    wsp[((0 * 2 + ms) * 4 + tj) * 64 + ln] = s.h;
+    wsp[((1 * 2 + ms) * 4 + tj) * 64 + ln] = s.m;
+    wsp[((2 * 2 + ms) * 4 + tj) * 64 + ln] = s.l;
+  }
+}
+
 // ==========================================================================================
 // forward, projection first (layers l > 0)
 // ==========================================================================================
@@ -408,7 +488,7 @@ __global__ void __launch_bounds__(PF_NTHR) k_gcn_fwd_pf(
     const float* __restrict__ bias, float* __restrict__ Y, double* __restrict__ stat_slab) {
   const DropCfg drop = drop_resolve(drop_in);
   __shared__ __attribute__((aligned(16))) float tile[MAXR * HID];
-  __shared__ __attribute__((aligned(16))) float Wt[HID * HID];
+  __shared__ uint4 wsp[WSP_FRAGS];                               // split W^T panel, 24 KB
   __shared__ __attribute__((aligned(16))) float bnab[2 * HID];
   __shared__ float disl[MAXR];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, j = lane & 15;
@@ -416,7 +496,7 @@ __global__ void __launch_bounds__(PF_NTHR) k_gcn_fwd_pf(
   constexpr int BPW = (MAXR / 16 + PF_NW - 1) / PF_NW;        // blocks per wave and tile (2)
 
   __shared__ __attribute__((aligned(16))) float wl0[FROM_P0 ? L0_LDS_FLOATS : 4];
-  for (int i = threadIdx.x; i < HID * HID; i += PF_NTHR) Wt[(i & 63) * HID + (i >> 6)] = W[i];
+  stage_split_weight<false>(wsp, W, PF_NTHR);
   for (int i = threadIdx.x; i < 2 * HID; i += PF_NTHR) bnab[i] = bn_prev[i];
   if (FROM_P0) l0_stage(wl0, l0, PF_NTHR);
   const float4 bias4 = ld4(bias + 4 * j);
@@ -483,35 +563,40 @@ __global__ void __launch_bounds__(PF_NTHR) k_gcn_fwd_pf(
       const bool live = row < n;                 // dead rows: px = 0 and pd = 0 -> x = 0
       f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        uint32_t keep = 0xFu;
-#ifndef PF_DIAG_SKIP_DROP
-        if (use_drop) {
-          keep = drop_bits(drop, (uint32_t)(base + row), (uint32_t)(4 * c + q));
-          if (mask_out && live) mask_out[(int64_t)(base + row) * 16 + 4 * c + q] = (uint8_t)keep;
-        }
-#endif
-        float4 f;
-        const float4 yraw = FROM_P0 ? l0_rebuild4(px[u][0], px[u][NPX > 1 ? 1 : 0], wl0, 16 * c + 4 * q, l0.F0)
-                                    : px[u][c < NPX ? c : 0];
-        const float4 x = scale4(act4(yraw, ld4(bnab + 16 * c + 4 * q), ld4(bnab + HID + 16 * c + 4 * q),
-                                     keep, drop.scale, f), pd[u]);
-        const float xa[4] = {x.x, x.y, x.z, x.w};
+      for (int ms = 0; ms < 2; ++ms) {
+        float4 xc[2];
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-          // reduction index k = 16c + 4q + s4 on lane group q
-#ifdef PF_DIAG_SKIP_MFMA
-          acc[s4][c] += xa[s4];
-#else
-          const float4 w4 = ld4(Wt + (16 * c + 4 * q + s4) * HID + 4 * j);
-          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s4], w4.x, acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s4], w4.y, acc[1], 0, 0, 0);
-          acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s4], w4.z, acc[2], 0, 0, 0);
-          acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s4], w4.w, acc[3], 0, 0, 0);
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const int c = 2 * ms + h2;
+          uint32_t keep = 0xFu;
+#ifndef PF_DIAG_SKIP_DROP
+          if (use_drop) {
+            keep = drop_bits(drop, (uint32_t)(base + row), (uint32_t)(4 * c + q));
+            if (mask_out && live) mask_out[(int64_t)(base + row) * 16 + 4 * c + q] = (uint8_t)keep;
+          }
 #endif
+          float4 f;
+          const float4 yraw = FROM_P0 ? l0_rebuild4(px[u][0], px[u][NPX > 1 ? 1 : 0], wl0, 16 * c + 4 * q, l0.F0)
+                                      : px[u][c < NPX ? c : 0];
+          xc[h2] = scale4(act4(yraw, ld4(bnab + 16 * c + 4 * q), ld4(bnab + HID + 16 * c + 4 * q),
+                               keep, drop.scale, f), pd[u]);
         }
-        __builtin_amdgcn_sched_barrier(0);      // keep the W^T / BatchNorm LDS reads of later chunks
-                                                // from being hoisted (96 live registers otherwise)
+        // k-step ms of the 16x16x32 product: this lane's 8 reduction indices are the columns
+        // 16*(2ms) + 4q .. +3 and 16*(2ms+1) + 4q .. +3 (the order of stage_split_weight)
+        const Split8 a = split8(xc[0], xc[1]);
+#ifdef PF_DIAG_SKIP_MFMA
+        acc[0][ms] += xc[0].x + xc[1].y; acc[1][ms] += __uint_as_float(a.m.x);
+#else
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) {
+          const uint4 bh = wsp[((0 * 2 + ms) * 4 + tj) * 64 + lane];
+          const uint4 bm = wsp[((1 * 2 + ms) * 4 + tj) * 64 + lane];
+          const uint4 bl = wsp[((2 * 2 + ms) * 4 + tj) * 64 + lane];
+          acc[tj] = mfma_split(a, bh, bm, bl, acc[tj]);
+        }
+#endif
+        __builtin_amdgcn_sched_barrier(0);      // keep the LDS reads of the next k-step from being
+                                                // hoisted above this one's (register pressure)
       }
       // accumulator tile tj holds columns 4j + tj of rows 4q + r: one float4 per row
 #pragma unroll
@@ -589,15 +674,13 @@ __global__ void __launch_bounds__(NTHR) k_gcn_bwd(
     double* __restrict__ db_slab) {
   __shared__ __attribute__((aligned(16))) float tile[MAXR * HID];
   __shared__ __attribute__((aligned(16))) float stg_all[NWAVE * STG_FLOATS];
-  __shared__ __attribute__((aligned(16))) float Wl[FIRST ? 4 : HID * HID];
+  __shared__ uint4 wsp[FIRST ? 1 : WSP_FRAGS];          // split W panel for dX = dT W (24 KB)
   __shared__ float disl[MAXR];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, j = lane & 15;
   float* stg = stg_all + wave * STG_FLOATS;
   const uint4* ent = static_cast<const uint4*>(t.ent_src);
 
-  if (!FIRST) {
-    for (int i = threadIdx.x; i < HID * HID / 4; i += NTHR) st4(Wl + 4 * i, ld4(W + 4 * i));
-  }
+  if (!FIRST) stage_split_weight<true>(wsp, W, NTHR);
   // previous layer's BatchNorm block (a | b | mean | invstd) lives in LDS, not in 16 registers
   __shared__ __attribute__((aligned(16))) float bnl[FIRST ? 4 : 4 * HID];
   if (!FIRST) {
@@ -801,24 +884,23 @@ __global__ void __launch_bounds__(NTHR) k_gcn_bwd(
 #endif
         }
       }
-      // dX[row][col] = sum_o dT[row][o] W[o][col]; k <-> o = 16q + s
+      // dX[row][col] = sum_o dT[row][o] W[o][col] as split-bf16 products (see mfma_split): lane
+      // (q, j) takes row j of the block, k-step ms covers o = 16*(2ms) + 4q.. and 16*(2ms+1) + 4q..
       f32x4 dx[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-      float af[16];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float4 v = ld4(stg + j * SLD + 16 * q + 4 * u);
-        af[4 * u + 0] = v.x; af[4 * u + 1] = v.y; af[4 * u + 2] = v.z; af[4 * u + 3] = v.w;
-      }
-#pragma unroll
-      for (int s = 0; s < 16; ++s) {
+      for (int ms = 0; ms < 2; ++ms) {
+        const Split8 a = split8(ld4(stg + j * SLD + 16 * (2 * ms) + 4 * q),
+                                ld4(stg + j * SLD + 16 * (2 * ms + 1) + 4 * q));
 #ifdef BW_DIAG_SKIP_DX
-        dx[s & 3][s >> 2] += af[s];
+        dx[0][ms] += __uint_as_float(a.h.x) + __uint_as_float(a.l.w);
 #else
-        const float4 w4 = ld4(Wl + (16 * q + s) * HID + 4 * j);
-        dx[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], w4.x, dx[0], 0, 0, 0);
-        dx[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], w4.y, dx[1], 0, 0, 0);
-        dx[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], w4.z, dx[2], 0, 0, 0);
-        dx[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], w4.w, dx[3], 0, 0, 0);
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) {
+          const uint4 bh = wsp[((0 * 2 + ms) * 4 + tj) * 64 + lane];
+          const uint4 bm = wsp[((1 * 2 + ms) * 4 + tj) * 64 + lane];
+          const uint4 bl = wsp[((2 * 2 + ms) * 4 + tj) * 64 + lane];
+          dx[tj] = mfma_split(a, bh, bm, bl, dx[tj]);
+        }
 #endif
       }
       __builtin_amdgcn_wave_barrier();
