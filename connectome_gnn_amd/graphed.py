@@ -67,9 +67,12 @@ class GraphedTrainStep:
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):                       # warm-up off the capture stream
             for _ in range(warmup):
-                self._fwd_bwd()
+                first = self._fwd_bwd()
                 self._exchange()
                 self.optimizer.step()
+            # the warm-up passes are REAL optimisation steps on this batch; a caller that counts
+            # them (Trainer(graph=True) uses warmup=1 as the batch's first step) reads the loss here
+            self.first_loss = first.clone()
         torch.cuda.current_stream(dev).wait_stream(side)
         self._zero()
         self.graph = torch.cuda.CUDAGraph()

@@ -39,9 +39,17 @@ class ResidentDataLoader:
     over a PackedDataset that already lives on the device.  rank/world_size select this
     rank's contiguous shard of every global batch (graph-sharded data parallelism)."""
 
-    def __init__(self, dataset: PackedDataset, batch_size: int = 16, shuffle: bool = True,
-                 rank: int = 0, world_size: int = 1, prefetch: bool = False, prepare=None):
-        """prefetch: assemble the NEXT batch and build its structure (CSR, and whatever
+    def __init__(self, dataset: PackedDataset, batch_size: int = 16, shuffle=True,
+                 rank: int = 0, world_size: int = 1, prefetch: bool = False, prepare=None,
+                 cache_batches: bool = False):
+        """shuffle: True (new random composition of every batch each epoch, the reference's
+        semantics), False, or "batches": the batches are composed once (one random permutation)
+        and only their ORDER is re-drawn every epoch.  cache_batches (needs shuffle False or
+        "batches"): the assembled device batches -- with their CSR / blocked-ELL structure -- are
+        kept and handed out again each epoch, so per-batch work is paid once and
+        ``Trainer(graph=True)`` can replay one captured HIP graph per batch.
+
+        prefetch: assemble the NEXT batch and build its structure (CSR, and whatever
         ``prepare(batch)`` builds, e.g. ``model.prepare_batch``) on a side stream while the caller
         trains on the current one -- the builds read sizes back to the host, and on the training
         stream those read-backs would wait for the whole previous step."""
@@ -49,13 +57,23 @@ class ResidentDataLoader:
         self.rank, self.world_size = rank, world_size
         self.prefetch, self.prepare = prefetch, prepare
         self._side = None
+        if cache_batches and shuffle is True:
+            raise ValueError("cache_batches needs shuffle=False or shuffle='batches' (fixed batch composition)")
+        self.cache_batches = cache_batches
+        self._fixed_order = None           # composition of the batches for shuffle='batches'
+        self._cache = None
 
     def __len__(self) -> int:
         return -(-self.dataset.num_subjects // self.batch_size)
 
     def _chunks(self):
         n = self.dataset.num_subjects
-        order = torch.randperm(n) if self.shuffle else torch.arange(n)
+        if self.shuffle == "batches":
+            if self._fixed_order is None:
+                self._fixed_order = torch.randperm(n)
+            order = self._fixed_order
+        else:
+            order = torch.randperm(n) if self.shuffle else torch.arange(n)
         for lo in range(0, n, self.batch_size):
             chunk = order[lo:lo + self.batch_size]
             if self.world_size > 1:
@@ -66,6 +84,19 @@ class ResidentDataLoader:
             yield chunk
 
     def __iter__(self):
+        if self.cache_batches:
+            if self._cache is None:
+                self._cache = []
+                for chunk in self._chunks():
+                    b = assemble_batch(self.dataset, chunk)
+                    if self.prepare is not None:
+                        self.prepare(b)
+                    self._cache.append(b)
+            order = torch.randperm(len(self._cache)).tolist() if self.shuffle == "batches" \
+                else range(len(self._cache))
+            for i in order:
+                yield self._cache[i]
+            return
         if not self.prefetch or self.dataset.x.device.type != "cuda":
             for chunk in self._chunks():
                 b = assemble_batch(self.dataset, chunk)

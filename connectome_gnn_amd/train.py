@@ -68,12 +68,28 @@ class _BestWeights:
 
 class Trainer:
     def __init__(self, model: nn.Module, optimizer: torch.optim.Optimizer, device: str = "cuda",
-                 grad_sync: Optional[Callable[[], None]] = None, loss_fn: Optional[nn.Module] = None):
+                 grad_sync: Optional[Callable[[], None]] = None, loss_fn: Optional[nn.Module] = None,
+                 graph: bool = False, graph_collectives: str = "split"):
+        """``graph=True``: every distinct RESIDENT batch (same device tensors seen again, e.g. a
+        ``ResidentDataLoader(cache_batches=True)`` or any loader that yields the same device
+        batches each epoch) gets its training step captured once as a HIP graph
+        (graphed.GraphedTrainStep) and replayed afterwards -- one launch instead of ~45 for the
+        small batches where issuing kernels from Python costs more than running them.  Batches
+        that never repeat just pay one eager-speed step each (the capture).  The optimizer must be
+        capturable (``torch.optim.Adam(..., capturable=True)``)."""
         self.device = device
         self.model = model.to(device)
         self.optimizer = optimizer
         self.loss_fn = loss_fn if loss_fn is not None else ops.CrossEntropyLoss()
         self.grad_sync = grad_sync
+        self.graph = bool(graph)
+        self.graph_collectives = graph_collectives
+        self._graphs: Dict[tuple, object] = {}
+        if self.graph:
+            for grp in optimizer.param_groups:
+                if not grp.get("capturable", False):
+                    raise ValueError("Trainer(graph=True) needs a capturable optimizer, e.g. "
+                                     "torch.optim.Adam(params, ..., capturable=True)")
 
     def _data_parallel(self) -> bool:
         return self.grad_sync is not None and torch.distributed.is_initialized() \
@@ -95,9 +111,25 @@ class Trainer:
         return host[:-1], int(round(host[-1]))
 
     # ------------------------------------------------------------------------------ training
+    def _graphed_step(self, batch) -> torch.Tensor:
+        key = (batch.node_features.data_ptr(), batch.edge_index.data_ptr(), batch.edge_weight.data_ptr(),
+               batch.labels.data_ptr(), batch.num_nodes, batch.num_graphs, batch.edge_index._version,
+               batch.edge_weight._version)
+        step = self._graphs.get(key)
+        if step is None:
+            from .graphed import GraphedTrainStep
+            local = batch.num_graphs if isinstance(self.grad_sync, cdist.GradSync) else None
+            step = GraphedTrainStep(self.model, self.optimizer, batch, self.loss_fn, grad_sync=self.grad_sync,
+                                    warmup=1, collectives=self.graph_collectives, local_graphs=local)
+            self._graphs[key] = step
+            return step.first_loss            # the warm-up pass WAS this batch's step (eager)
+        return step().clone()
+
     def train_step(self, batch) -> torch.Tensor:
         """One optimisation step (reference train.py:46-51); returns the detached device loss."""
         batch = batch.to(self.device)
+        if self.graph and self.model.training:
+            return self._graphed_step(batch)
         if hasattr(self.grad_sync, "zero_grad"):
             self.grad_sync.zero_grad()       # keeps .grad as views of the all-reduce buffer
         else:
