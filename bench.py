@@ -46,9 +46,11 @@ WORKLOADS = {
     "cfg4-headline-gcn-4096x360-h64": dict(model="gcn", n=360, k=14, hidden=64, batch=4096),
     "cfg2-gcn-512x84-h64": dict(model="gcn", n=84, k=8, hidden=64, batch=512),
     "cfg3-sage-512x360-h128": dict(model="sage", n=360, k=14, hidden=128, batch=512),
-    # BASELINE config 5's shape run in fp32 (fp16 storage exists for its scatter kernel only:
-    # tools/scatter_bench.py); dense 1000-ROI graphs, 100k edges each
+    # BASELINE config 5's shape run in fp32 (the reference's arithmetic); dense 1000-ROI graphs,
+    # 100k edges each
     "cfg5-gcn-64x1000-h256-fp32": dict(model="gcn", n=1000, k=100, hidden=256, batch=64),
+    # BASELINE config 5 as specified: fp16 storage / fp32 accumulate (GCNConnectome(storage="fp16"))
+    "cfg5-gcn-64x1000-h256-fp16": dict(model="gcn", n=1000, k=100, hidden=256, batch=64, storage="fp16"),
 }
 
 
@@ -220,6 +222,10 @@ def main() -> None:
     torch.manual_seed(42)
     cls = C.GCNConnectome if model_kind == "gcn" else C.GraphSAGEConnectome
     kw = {} if args.impl == "auto" else {"impl": args.impl}
+    storage = wl.get("storage", "fp32")
+    if storage != "fp32":
+        kw["storage"] = storage
+    elem = 2 if storage == "fp16" else 4
     model = cls(5, hidden, 2, 3, 0.3, **kw).to(dev).train()
     if world > 1:
         cdist.broadcast_parameters(model)
@@ -275,8 +281,13 @@ def main() -> None:
         "cgnn_gcn_fused_bwd": lambda nn_, ee: nn_ * 4.0 * (5 * hidden + hidden + 2 * hidden) + 8.0 * ee,
         f"cgnn_aggregate_tiled_f32[F={hidden}]": agg_bytes,     # LDS-tiled aggregate (wide layers)
         f"cgnn_aggregate_f32[F={hidden}]": agg_bytes,           # gather form (graphs > 384 nodes)
+        # fp16 storage: the dense per-graph aggregate, priced at the SPARSE operator's bytes (s = 2)
+        f"cgnn_dense_aggregate_f16[F={hidden}]": lambda nn_, ee: 2.0 * nn_ * hidden * 2 + 8.0 * ee + 4.0 * (nn_ + 1),
     }
-    if impl_used == "fused" and model_kind == "gcn":
+    fused_kind = getattr(model, "_fused_kind", None) if impl_used == "fused" else None
+    if fused_kind == "half":
+        dom = f"cgnn_dense_aggregate_f16[F={hidden}]"
+    elif fused_kind == "tile":
         dom = "cgnn_gcn_fused_bwd"
     elif batches[0].structure().tiled_ok(hidden):
         dom = f"cgnn_aggregate_tiled_f32[F={hidden}]"
@@ -305,7 +316,7 @@ def main() -> None:
 
     if rank == 0:
         graphs_per_s = global_batch * args.steps / dt
-        bpg = algorithmic_bytes_per_graph(model_kind, n, e, hidden)
+        bpg = algorithmic_bytes_per_graph(model_kind, n, e, hidden, elem)
         kms = timer.ms(dom)
         nn_, ee = bsz * n, bsz * e
         dom_bytes = dom_bytes_fn(nn_, ee)
@@ -331,7 +342,8 @@ def main() -> None:
             if args.workload.startswith("cfg4") else f"training graphs/sec, {args.workload}",
             "value": graphs_per_s, "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "f16" if storage == "fp16" else "f32",
             "data": "synthetic",
             "config": {"workload": args.workload, "model": model_kind, "rois": n, "ws_k": k,
                        "edges_per_graph": e, "hidden": hidden, "layers": 3,

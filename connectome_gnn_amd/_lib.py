@@ -82,6 +82,11 @@ PROTOTYPES = {
     "cgnn_bn_act_bwd_finalize": (c_int, [P, I32, I32, F64, P, I32, P, P, P, P]),
     "cgnn_bn_act_apply_blocks": (I64, [I64, I32]),
     "cgnn_bn_act_bwd_apply": (c_int, [P, P, P, P, P, I32, F32, I32, P, P, I64, I32, P, P, P, P]),
+    "cgnn_bn_act_fwd_stats_f16": (c_int, [P, I64, I32, P, P]),
+    "cgnn_bn_act_fwd_apply_f16": (c_int, [P, P, I32, F32, U64, P, P, P, I64, I32, P]),
+    "cgnn_bn_act_pool_fwd_f16": (c_int, [P, P, I32, F32, U64, P, P, P, I32, P, I32, P]),
+    "cgnn_bn_act_bwd_stats_f16": (c_int, [P, P, P, P, I32, F32, I64, I32, P, P, P, P, P]),
+    "cgnn_bn_act_bwd_apply_f16": (c_int, [P, P, P, P, P, I32, F32, I32, P, P, I64, I32, P, P, P, P]),
     # fused per-tile GCN path
     "cgnn_bell_plan": (c_int, [P, P, I32, I32, P, P, P, P]),
     "cgnn_bell_fill": (c_int, [P, P, I32, P, P, P, P, F32, P, P, P]),

@@ -53,6 +53,18 @@ DropCfg make_drop(float p, uint64_t seed, int* use_drop) {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+// the activation arrays are float or IEEE half (fp16 storage, fp32 arithmetic: BASELINE config 5);
+// four consecutive elements at a time, 16 or 8 bytes
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4(const _Float16* p) {
+  const h4 v = *reinterpret_cast<const h4*>(p);
+  return make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
+}
+__device__ __forceinline__ void st4(_Float16* p, const float4& v) {
+  h4 h;
+  h.x = (_Float16)v.x; h.y = (_Float16)v.y; h.z = (_Float16)v.z; h.w = (_Float16)v.w;
+  *reinterpret_cast<h4*>(p) = h;
+}
 
 // Readout gradient in place of a stored dX' (models.py:57-59 backward): the row's gradient is
 // dP[graph] / (n_graph + 1e-8), rebuilt on the fly instead of written out and read back.
@@ -69,19 +81,19 @@ __device__ __forceinline__ float4 pool_grad(const PoolGrad& pg, int64_t r, int N
   return make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
 }
 
-constexpr int ROWS = 256;     // rows per block of the reduction kernels
+constexpr int ROWS = 256;     // most rows per block of the reduction kernels (fewer for short arrays)
 constexpr int THR = 256;
 
 // per-thread fp32 partials over <= ROWS*nch/THR rows, fp64 across threads -> slab[block][2N]
-template <bool BWD>
+template <bool BWD, typename T>
 __global__ void __launch_bounds__(THR) k_colstats(
-    const float* __restrict__ A /* Y (fwd) or dX' (bwd) */, const float* __restrict__ Y,
+    const T* __restrict__ A /* Y (fwd) or dX' (bwd) */, const T* __restrict__ Y,
     const uint8_t* __restrict__ mask, const float* __restrict__ coef, int relu, DropCfg drop,
-    int use_drop, int64_t M, int N, double* __restrict__ slab, PoolGrad pg) {
+    int use_drop, int64_t M, int N, double* __restrict__ slab, PoolGrad pg, int rows_per_block) {
   extern __shared__ double red[];                    // [rpp][2N]
   const int nch = N >> 2;
   const int c = threadIdx.x % nch, rr = threadIdx.x / nch, rpp = THR / nch;
-  const int64_t rbeg = (int64_t)blockIdx.x * ROWS, rend = min(M, rbeg + ROWS);
+  const int64_t rbeg = (int64_t)blockIdx.x * rows_per_block, rend = min(M, rbeg + rows_per_block);
   float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
   float4 ca = s1, cb = s1, cm = s1, ci = s1;
   if (BWD) {
@@ -133,40 +145,72 @@ __device__ __forceinline__ double block_sum256(double v, double* sh) {
   return t;
 }
 
-// one block per channel
-__global__ void __launch_bounds__(256) k_bn_fwd_finalize_n(
+// Column sums of a slab [rows][2N] fp64 for FIN_C consecutive channels per block: thread (rg, cc)
+// adds rows rg, rg + FIN_G, ... of columns c and N + c (each load instruction reads FIN_C
+// consecutive doubles of a row: coalesced; one block per channel read 4 KB-strided columns), then
+// the FIN_G partials are combined in fixed order.  Results in s1[cc], s2[cc] for threads rg == 0.
+constexpr int FIN_C = 8, FIN_G = 128;      // 1024 threads: 64-byte row pieces, 128 row groups
+__device__ __forceinline__ void slab_colsum2(const double* __restrict__ slab, int rows, int N, int c0,
+                                             double (*sh)[FIN_C][2], double& S1, double& S2) {
+  const int cc = threadIdx.x % FIN_C, rg = threadIdx.x / FIN_C, c = c0 + cc;
+  double a1 = 0.0, a2 = 0.0;
+  if (c < N) {
+    int r = rg;
+    for (; r + 3 * FIN_G < rows; r += 4 * FIN_G) {        // 8 independent loads in flight
+      double v1[4], v2[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        v1[u] = slab[(int64_t)(r + u * FIN_G) * 2 * N + c];
+        v2[u] = slab[(int64_t)(r + u * FIN_G) * 2 * N + N + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a1 += v1[u]; a2 += v2[u]; }
+    }
+    for (; r < rows; r += FIN_G) {
+      a1 += slab[(int64_t)r * 2 * N + c];
+      a2 += slab[(int64_t)r * 2 * N + N + c];
+    }
+  }
+  sh[rg][cc][0] = a1;
+  sh[rg][cc][1] = a2;
+  __syncthreads();
+  S1 = S2 = 0.0;
+  if (rg == 0) {
+#pragma unroll
+    for (int k = 0; k < FIN_G; ++k) { S1 += sh[k][cc][0]; S2 += sh[k][cc][1]; }
+  }
+}
+
+__global__ void __launch_bounds__(FIN_C * FIN_G) k_bn_fwd_finalize_n(
     const double* __restrict__ slab, int rows, int N, double count_host,
     const double* __restrict__ count_dev, int training,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean,
     float* __restrict__ rvar, float momentum, float eps, long long* __restrict__ tracked,
     float* __restrict__ coef) {
-  __shared__ double sh[4];
+  __shared__ double sh[FIN_G][FIN_C][2];
   const double count = count_dev ? count_dev[0] : count_host;
-  const int c = blockIdx.x;
-  float mean, var;
+  const int c = blockIdx.x * FIN_C + threadIdx.x % FIN_C;
+  const bool owner = threadIdx.x < FIN_C && c < N;
+  float mean = 0.f, var = 1.f;
   if (training) {
-    double a1 = 0.0, a2 = 0.0;
-    for (int r = threadIdx.x; r < rows; r += 256) {
-      a1 += slab[(int64_t)r * 2 * N + c];
-      a2 += slab[(int64_t)r * 2 * N + N + c];
-    }
-    const double S1 = block_sum256(a1, sh), S2 = block_sum256(a2, sh);
-    const double m = S1 / count;
-    double v = S2 / count - m * m;
-    if (v < 0.0) v = 0.0;
-    mean = (float)m;
-    var = (float)v;
-    if (threadIdx.x == 0) {
+    double S1, S2;
+    slab_colsum2(slab, rows, N, blockIdx.x * FIN_C, sh, S1, S2);
+    if (owner) {
+      const double m = S1 / count;
+      double v = S2 / count - m * m;
+      if (v < 0.0) v = 0.0;
+      mean = (float)m;
+      var = (float)v;
       const double unbiased = count > 1.0 ? v * count / (count - 1.0) : v;
       rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean;
       rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (float)unbiased;
       if (c == 0 && tracked) *tracked += 1;
     }
-  } else {
+  } else if (owner) {
     mean = rmean[c];
     var = rvar[c];
   }
-  if (threadIdx.x == 0) {
+  if (owner) {
     const float invstd = 1.0f / sqrtf(var + eps);
     const float a = gamma[c] * invstd;
     coef[c] = a;
@@ -176,22 +220,18 @@ __global__ void __launch_bounds__(256) k_bn_fwd_finalize_n(
   }
 }
 
-__global__ void __launch_bounds__(256) k_bn_bwd_finalize_n(const double* __restrict__ slab, int rows,
+__global__ void __launch_bounds__(FIN_C * FIN_G) k_bn_bwd_finalize_n(const double* __restrict__ slab, int rows,
                                                            int N, double count_host,
                                                            const double* __restrict__ count_dev,
                                                            int zero_coef, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta,
                                                            float* __restrict__ bwc) {
-  __shared__ double sh[4];
+  __shared__ double sh[FIN_G][FIN_C][2];
   const double count = count_dev ? count_dev[0] : count_host;
-  const int c = blockIdx.x;
-  double a1 = 0.0, a2 = 0.0;
-  for (int r = threadIdx.x; r < rows; r += 256) {
-    a1 += slab[(int64_t)r * 2 * N + c];
-    a2 += slab[(int64_t)r * 2 * N + N + c];
-  }
-  const double S1 = block_sum256(a1, sh), S2 = block_sum256(a2, sh);
-  if (threadIdx.x == 0) {
+  const int c = blockIdx.x * FIN_C + threadIdx.x % FIN_C;
+  double S1, S2;
+  slab_colsum2(slab, rows, N, blockIdx.x * FIN_C, sh, S1, S2);
+  if (threadIdx.x < FIN_C && c < N) {
     dbeta[c] = (float)S1;
     dgamma[c] = (float)S2;
     bwc[c] = zero_coef ? 0.f : (float)(S1 / count);
@@ -201,11 +241,11 @@ __global__ void __launch_bounds__(256) k_bn_bwd_finalize_n(const double* __restr
 
 // forward apply (BWD=false): X' = drop(act(a*Y+b)), keep bytes out
 // backward apply (BWD=true): dY = a*(dZ - c1 - xhat*c2), dZ = dX'*drop'*act'
-template <bool BWD>
+template <bool BWD, typename T>
 __global__ void __launch_bounds__(256) k_bn_act_apply(
-    const float* __restrict__ Y, const float* __restrict__ dXp, const float* __restrict__ coef,
+    const T* __restrict__ Y, const T* __restrict__ dXp, const float* __restrict__ coef,
     const float* __restrict__ bwc, int relu, DropCfg drop, int use_drop,
-    uint8_t* __restrict__ mask_out, const uint8_t* __restrict__ mask_in, float* __restrict__ out,
+    uint8_t* __restrict__ mask_out, const uint8_t* __restrict__ mask_in, T* __restrict__ out,
     int64_t M, int N, int relu_in, double* __restrict__ colsum_slab, PoolGrad pg) {
   if (drop.dev_key) drop.key1 ^= drop.dev_key[0];
   const int nch = N >> 2;
@@ -267,8 +307,9 @@ __global__ void __launch_bounds__(256) k_bn_act_apply(
 // One 1024-thread block per graph at a time; X' itself is never written.
 constexpr int PTHR = 1024;
 
+template <typename T>
 __global__ void __launch_bounds__(PTHR) k_bn_act_pool_fwd(
-    const float* __restrict__ Y, const float* __restrict__ coef, int relu, DropCfg drop, int use_drop,
+    const T* __restrict__ Y, const float* __restrict__ coef, int relu, DropCfg drop, int use_drop,
     uint8_t* __restrict__ mask_out, const int32_t* __restrict__ gptr, int B, float* __restrict__ P,
     int N) {
   if (drop.dev_key) drop.key1 ^= drop.dev_key[0];
@@ -318,7 +359,15 @@ __global__ void __launch_bounds__(PTHR) k_bn_act_pool_fwd(
 }
 
 bool width_ok(int N) { return N >= 4 && N <= 1024 && (N & (N - 1)) == 0; }
-int stat_blocks(int64_t M) { return (int)((M + ROWS - 1) / ROWS); }
+// rows per block: ROWS for long arrays, fewer (down to 32) when that would leave the chip with less
+// than ~2048 blocks -- a 64000-row array at 256 rows per block is 250 blocks = one per CU, and the
+// pass is then bound by the latency of each block's own loads
+int stat_rows(int64_t M) {
+  int r = ROWS;
+  while (r > 32 && (M + r - 1) / r < 2048) r >>= 1;
+  return r;
+}
+int stat_blocks(int64_t M) { const int r = stat_rows(M); return (int)((M + r - 1) / r); }
 unsigned apply_blocks(int64_t M, int N, bool colsum = false) {
   const int64_t total = M * (N >> 2);
   int64_t grid = (total + 255) / 256;
@@ -330,56 +379,43 @@ unsigned apply_blocks(int64_t M, int N, bool colsum = false) {
 
 }  // namespace
 
-extern "C" {
+namespace {
 
-int cgnn_bn_act_width_ok(int32_t N) { return width_ok(N) ? 1 : 0; }
-int64_t cgnn_bn_act_slab_rows(int64_t M) { return M < 0 ? CGNN_EINVAL : (M == 0 ? 1 : stat_blocks(M)); }
-
-int cgnn_bn_act_fwd_stats(const float* Y, int64_t M, int32_t N, double* slab, void* stream) {
+template <typename T>
+int bn_act_fwd_stats_t(const T* Y, int64_t M, int32_t N, double* slab, void* stream) {
   if (M < 0 || !width_ok(N) || !slab) return width_ok(N) ? CGNN_EINVAL : CGNN_EUNSUPPORTED;
   if (M == 0) return CGNN_OK;
   if (!Y) return CGNN_EINVAL;
   DropCfg d{};
   const int rpp = THR / (N >> 2);
-  k_colstats<false><<<stat_blocks(M), THR, (size_t)rpp * 2 * N * sizeof(double), cgnn_stream(stream)>>>(
-      Y, nullptr, nullptr, nullptr, 0, d, 0, M, N, slab, PoolGrad{nullptr, nullptr, nullptr});
+  k_colstats<false, T><<<stat_blocks(M), THR, (size_t)rpp * 2 * N * sizeof(double), cgnn_stream(stream)>>>(
+      Y, (const T*)nullptr, nullptr, nullptr, 0, d, 0, M, N, slab, PoolGrad{nullptr, nullptr, nullptr}, stat_rows(M));
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }
 
-int cgnn_bn_act_finalize(const double* slab, int32_t rows, int32_t N, double count,
-                         const double* count_dev, int32_t training,
-                         const float* gamma, const float* beta, float* running_mean,
-                         float* running_var, float momentum, float eps,
-                         int64_t* num_batches_tracked, float* coef, void* stream) {
-  if (!width_ok(N) || !gamma || !beta || !running_mean || !running_var || !coef) return CGNN_EINVAL;
-  if (training && (!slab || rows <= 0 || (!count_dev && count <= 0.0))) return CGNN_EINVAL;
-  k_bn_fwd_finalize_n<<<N, 256, 0, cgnn_stream(stream)>>>(
-      slab, rows, N, count, count_dev, training, gamma, beta, running_mean, running_var, momentum, eps,
-      reinterpret_cast<long long*>(num_batches_tracked), coef);
-  CGNN_CHECK_LAUNCH();
-  return CGNN_OK;
-}
 
-int cgnn_bn_act_fwd_apply(const float* Y, const float* coef, int32_t relu, float p_drop, uint64_t seed,
-                          const uint32_t* seed_dev, uint8_t* mask_out, float* X, int64_t M, int32_t N,
-                          void* stream) {
+template <typename T>
+int bn_act_fwd_apply_t(const T* Y, const float* coef, int32_t relu, float p_drop, uint64_t seed,
+                       const uint32_t* seed_dev, uint8_t* mask_out, T* X, int64_t M, int32_t N,
+                       void* stream) {
   if (M < 0 || !width_ok(N) || p_drop < 0.f || p_drop >= 1.f) return CGNN_EINVAL;
   if (M == 0) return CGNN_OK;
   if (!Y || !coef || !X) return CGNN_EINVAL;
   int use_drop;
   DropCfg d = make_drop(p_drop, seed, &use_drop);
   d.dev_key = seed_dev;
-  k_bn_act_apply<false><<<apply_blocks(M, N), 256, 0, cgnn_stream(stream)>>>(
-      Y, nullptr, coef, nullptr, relu, d, use_drop, mask_out, nullptr, X, M, N, 0, nullptr,
+  k_bn_act_apply<false, T><<<apply_blocks(M, N), 256, 0, cgnn_stream(stream)>>>(
+      Y, (const T*)nullptr, coef, nullptr, relu, d, use_drop, mask_out, nullptr, X, M, N, 0, nullptr,
       PoolGrad{nullptr, nullptr, nullptr});
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }
 
-int cgnn_bn_act_pool_fwd(const float* Y, const float* coef, int32_t relu, float p_drop, uint64_t seed,
-                         const uint32_t* seed_dev, uint8_t* mask_out, const int32_t* gptr,
-                         int32_t num_graphs, float* P, int32_t N, void* stream) {
+template <typename T>
+int bn_act_pool_fwd_t(const T* Y, const float* coef, int32_t relu, float p_drop, uint64_t seed,
+                      const uint32_t* seed_dev, uint8_t* mask_out, const int32_t* gptr,
+                      int32_t num_graphs, float* P, int32_t N, void* stream) {
   if (num_graphs < 0 || !width_ok(N) || p_drop < 0.f || p_drop >= 1.f) return CGNN_EINVAL;
   if (num_graphs == 0) return CGNN_OK;
   if (!Y || !coef || !gptr || !P) return CGNN_EINVAL;
@@ -388,16 +424,17 @@ int cgnn_bn_act_pool_fwd(const float* Y, const float* coef, int32_t relu, float 
   d.dev_key = seed_dev;
   const int rpp = PTHR / (N >> 2);
   const unsigned grid = (unsigned)(num_graphs < 2048 ? num_graphs : 2048);
-  k_bn_act_pool_fwd<<<grid, PTHR, (size_t)rpp * N * sizeof(float), cgnn_stream(stream)>>>(
+  k_bn_act_pool_fwd<T><<<grid, PTHR, (size_t)rpp * N * sizeof(float), cgnn_stream(stream)>>>(
       Y, coef, relu, d, use_drop, mask_out, gptr, num_graphs, P, N);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }
 
-int cgnn_bn_act_bwd_stats(const float* dX, const float* Y, const uint8_t* mask, const float* coef,
-                          int32_t relu, float p_drop, int64_t M, int32_t N, double* slab,
-                          const float* dP, const int32_t* node_graph, const int32_t* gptr,
-                          void* stream) {
+template <typename T>
+int bn_act_bwd_stats_t(const T* dX, const T* Y, const uint8_t* mask, const float* coef,
+                       int32_t relu, float p_drop, int64_t M, int32_t N, double* slab,
+                       const float* dP, const int32_t* node_graph, const int32_t* gptr,
+                       void* stream) {
   if (M < 0 || !width_ok(N) || !slab || p_drop < 0.f || p_drop >= 1.f) return CGNN_EINVAL;
   if (M == 0) return CGNN_OK;
   if ((!dX && !dP) || !Y || !coef || (p_drop > 0.f && !mask)) return CGNN_EINVAL;
@@ -405,8 +442,50 @@ int cgnn_bn_act_bwd_stats(const float* dX, const float* Y, const uint8_t* mask, 
   int use_drop;
   DropCfg d = make_drop(p_drop, 0, &use_drop);
   const int rpp = THR / (N >> 2);
-  k_colstats<true><<<stat_blocks(M), THR, (size_t)rpp * 2 * N * sizeof(double), cgnn_stream(stream)>>>(
-      dX, Y, mask, coef, relu, d, use_drop, M, N, slab, PoolGrad{dP, node_graph, gptr});
+  k_colstats<true, T><<<stat_blocks(M), THR, (size_t)rpp * 2 * N * sizeof(double), cgnn_stream(stream)>>>(
+      dX, Y, mask, coef, relu, d, use_drop, M, N, slab, PoolGrad{dP, node_graph, gptr}, stat_rows(M));
+  CGNN_CHECK_LAUNCH();
+  return CGNN_OK;
+}
+
+
+
+template <typename T>
+int bn_act_bwd_apply_t(const T* dX, const T* Y, const uint8_t* mask, const float* coef,
+                       const float* bwc, int32_t relu, float p_drop, int32_t relu_in,
+                       double* colsum_slab, T* dY, int64_t M, int32_t N, const float* dP,
+                       const int32_t* node_graph, const int32_t* gptr, void* stream) {
+  if (M < 0 || !width_ok(N) || p_drop < 0.f || p_drop >= 1.f) return CGNN_EINVAL;
+  if (M == 0) return CGNN_OK;
+  if ((!dX && !dP) || !Y || !coef || !bwc || !dY || (p_drop > 0.f && !mask)) return CGNN_EINVAL;
+  if (dP && (!node_graph || !gptr)) return CGNN_EINVAL;
+  int use_drop;
+  DropCfg d = make_drop(p_drop, 0, &use_drop);
+  k_bn_act_apply<true, T><<<apply_blocks(M, N, colsum_slab != nullptr), 256, 0, cgnn_stream(stream)>>>(
+      Y, dX, coef, bwc, relu, d, use_drop, nullptr, mask, dY, M, N, relu_in, colsum_slab,
+      PoolGrad{dP, node_graph, gptr});
+  CGNN_CHECK_LAUNCH();
+  return CGNN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cgnn_bn_act_width_ok(int32_t N) { return width_ok(N) ? 1 : 0; }
+
+int64_t cgnn_bn_act_slab_rows(int64_t M) { return M < 0 ? CGNN_EINVAL : (M == 0 ? 1 : stat_blocks(M)); }
+
+int cgnn_bn_act_finalize(const double* slab, int32_t rows, int32_t N, double count,
+                         const double* count_dev, int32_t training,
+                         const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, float momentum, float eps,
+                         int64_t* num_batches_tracked, float* coef, void* stream) {
+  if (!width_ok(N) || !gamma || !beta || !running_mean || !running_var || !coef) return CGNN_EINVAL;
+  if (training && (!slab || rows <= 0 || (!count_dev && count <= 0.0))) return CGNN_EINVAL;
+  k_bn_fwd_finalize_n<<<(N + FIN_C - 1) / FIN_C, FIN_C * FIN_G, 0, cgnn_stream(stream)>>>(
+      slab, rows, N, count, count_dev, training, gamma, beta, running_mean, running_var, momentum, eps,
+      reinterpret_cast<long long*>(num_batches_tracked), coef);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }
@@ -416,7 +495,7 @@ int cgnn_bn_act_bwd_finalize(const double* slab, int32_t rows, int32_t N, double
                              float* bwc, void* stream) {
   if (!width_ok(N) || !slab || rows <= 0 || (!count_dev && count <= 0.0) || !dgamma || !dbeta || !bwc)
     return CGNN_EINVAL;
-  k_bn_bwd_finalize_n<<<N, 256, 0, cgnn_stream(stream)>>>(slab, rows, N, count, count_dev, zero_coef, dgamma,
+  k_bn_bwd_finalize_n<<<(N + FIN_C - 1) / FIN_C, FIN_C * FIN_G, 0, cgnn_stream(stream)>>>(slab, rows, N, count, count_dev, zero_coef, dgamma,
                                                           dbeta, bwc);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
@@ -426,21 +505,66 @@ int64_t cgnn_bn_act_apply_blocks(int64_t M, int32_t N) {
   return (M < 0 || !width_ok(N)) ? CGNN_EINVAL : (int64_t)apply_blocks(M, N, true);
 }
 
+
+// ---- fp32 storage
+int cgnn_bn_act_fwd_stats(const float* Y, int64_t M, int32_t N, double* slab, void* stream) {
+  return bn_act_fwd_stats_t<float>(Y, M, N, slab, stream);
+}
+int cgnn_bn_act_fwd_apply(const float* Y, const float* coef, int32_t relu, float p_drop, uint64_t seed,
+                          const uint32_t* seed_dev, uint8_t* mask_out, float* X, int64_t M, int32_t N,
+                          void* stream) {
+  return bn_act_fwd_apply_t<float>(Y, coef, relu, p_drop, seed, seed_dev, mask_out, X, M, N, stream);
+}
+int cgnn_bn_act_pool_fwd(const float* Y, const float* coef, int32_t relu, float p_drop, uint64_t seed,
+                         const uint32_t* seed_dev, uint8_t* mask_out, const int32_t* gptr,
+                         int32_t num_graphs, float* P, int32_t N, void* stream) {
+  return bn_act_pool_fwd_t<float>(Y, coef, relu, p_drop, seed, seed_dev, mask_out, gptr, num_graphs, P, N, stream);
+}
+int cgnn_bn_act_bwd_stats(const float* dX, const float* Y, const uint8_t* mask, const float* coef,
+                          int32_t relu, float p_drop, int64_t M, int32_t N, double* slab,
+                          const float* dP, const int32_t* node_graph, const int32_t* gptr,
+                          void* stream) {
+  return bn_act_bwd_stats_t<float>(dX, Y, mask, coef, relu, p_drop, M, N, slab, dP, node_graph, gptr, stream);
+}
 int cgnn_bn_act_bwd_apply(const float* dX, const float* Y, const uint8_t* mask, const float* coef,
                           const float* bwc, int32_t relu, float p_drop, int32_t relu_in,
                           double* colsum_slab, float* dY, int64_t M, int32_t N, const float* dP,
                           const int32_t* node_graph, const int32_t* gptr, void* stream) {
-  if (M < 0 || !width_ok(N) || p_drop < 0.f || p_drop >= 1.f) return CGNN_EINVAL;
-  if (M == 0) return CGNN_OK;
-  if ((!dX && !dP) || !Y || !coef || !bwc || !dY || (p_drop > 0.f && !mask)) return CGNN_EINVAL;
-  if (dP && (!node_graph || !gptr)) return CGNN_EINVAL;
-  int use_drop;
-  DropCfg d = make_drop(p_drop, 0, &use_drop);
-  k_bn_act_apply<true><<<apply_blocks(M, N, colsum_slab != nullptr), 256, 0, cgnn_stream(stream)>>>(
-      Y, dX, coef, bwc, relu, d, use_drop, nullptr, mask, dY, M, N, relu_in, colsum_slab,
-      PoolGrad{dP, node_graph, gptr});
-  CGNN_CHECK_LAUNCH();
-  return CGNN_OK;
+  return bn_act_bwd_apply_t<float>(dX, Y, mask, coef, bwc, relu, p_drop, relu_in, colsum_slab, dY, M, N, dP,
+                                   node_graph, gptr, stream);
+}
+
+// ---- fp16 storage (IEEE half arrays, fp32 arithmetic, fp64 statistics): same semantics
+typedef _Float16 cgnn_h;
+int cgnn_bn_act_fwd_stats_f16(const void* Y, int64_t M, int32_t N, double* slab, void* stream) {
+  return bn_act_fwd_stats_t<cgnn_h>(static_cast<const cgnn_h*>(Y), M, N, slab, stream);
+}
+int cgnn_bn_act_fwd_apply_f16(const void* Y, const float* coef, int32_t relu, float p_drop, uint64_t seed,
+                              const uint32_t* seed_dev, uint8_t* mask_out, void* X, int64_t M,
+                              int32_t N, void* stream) {
+  return bn_act_fwd_apply_t<cgnn_h>(static_cast<const cgnn_h*>(Y), coef, relu, p_drop, seed, seed_dev,
+                                    mask_out, static_cast<cgnn_h*>(X), M, N, stream);
+}
+int cgnn_bn_act_pool_fwd_f16(const void* Y, const float* coef, int32_t relu, float p_drop, uint64_t seed,
+                             const uint32_t* seed_dev, uint8_t* mask_out, const int32_t* gptr,
+                             int32_t num_graphs, float* P, int32_t N, void* stream) {
+  return bn_act_pool_fwd_t<cgnn_h>(static_cast<const cgnn_h*>(Y), coef, relu, p_drop, seed, seed_dev, mask_out,
+                                   gptr, num_graphs, P, N, stream);
+}
+int cgnn_bn_act_bwd_stats_f16(const void* dX, const void* Y, const uint8_t* mask, const float* coef,
+                              int32_t relu, float p_drop, int64_t M, int32_t N, double* slab,
+                              const float* dP, const int32_t* node_graph, const int32_t* gptr,
+                              void* stream) {
+  return bn_act_bwd_stats_t<cgnn_h>(static_cast<const cgnn_h*>(dX), static_cast<const cgnn_h*>(Y), mask, coef,
+                                    relu, p_drop, M, N, slab, dP, node_graph, gptr, stream);
+}
+int cgnn_bn_act_bwd_apply_f16(const void* dX, const void* Y, const uint8_t* mask, const float* coef,
+                              const float* bwc, int32_t relu, float p_drop, int32_t relu_in,
+                              double* colsum_slab, void* dY, int64_t M, int32_t N, const float* dP,
+                              const int32_t* node_graph, const int32_t* gptr, void* stream) {
+  return bn_act_bwd_apply_t<cgnn_h>(static_cast<const cgnn_h*>(dX), static_cast<const cgnn_h*>(Y), mask, coef,
+                                    bwc, relu, p_drop, relu_in, colsum_slab, static_cast<cgnn_h*>(dY), M, N,
+                                    dP, node_graph, gptr, stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,214 @@
+"""GCN encoder with fp16-STORAGE activations for large dense parcellations (BASELINE config 5:
+1000-ROI graphs at 10 % density, hidden 256) -- one autograd node, host orchestration only.
+
+The reference has no fp16 path (models.py:46,97,103,147 hard-code fp32; ``.half()`` raises), so
+this is new: every [Nn, H] array that crosses HBM is IEEE half, every accumulation is fp32 (fp64 for
+the BatchNorm statistics), parameters and their gradients stay fp32.  Selected with
+``GCNConnectome(..., storage="fp16")``; validated against the fp32 oracle at fp16 resolution.
+
+At ~100 neighbours per node the per-edge forms of the aggregation are bound by vector/LDS work
+per edge, so the operator is applied DENSE, per graph, on the fp16 matrix cores:
+
+  once per batch    Mf, Mb = dense D^-1/2 (A + I) D^-1/2 of every graph and its transpose, half,
+                    MFMA-fragment-major                         cgnn_dense_adj_f16 (static, cached)
+  layer 0           P0 = Mf X0 on a 64-column half panel (narrow: a quarter of a 256-wide pass),
+                    Y0 = P0 W0^T + b0
+  layer l > 0       T = X W^T                       half GEMM, fp32 accumulate (library GEMM)
+                    Y = Mf T + b                    cgnn_dense_aggregate_f16 (v_mfma_f32_32x32x16_f16)
+  every layer       X' = dropout(relu(BatchNorm(Y)))            cgnn_bn_act_*_f16 (two passes)
+  readout           fused into the last BatchNorm pass          cgnn_bn_act_pool_fwd_f16
+  backward          dY = BatchNorm'(...) (two passes, db = column sums), dT = Mb dY,
+                    dW = dT^T X, dX = dT W  (half GEMMs);  layer 0: dW0 = dY0^T P0, no aggregation
+
+The projections are plain [Nn,256] x [256,256] GEMMs and go to the GEMM library through torch
+(hipBLASLt, fp16 in / fp32 accumulate); the hand-written kernels are the aggregation and the
+fused elementwise passes, which carry the bytes.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from . import _lib, ops
+from .sage_path import bn_modules_ok
+from .structure import BatchStructure
+
+MAX_NODES = 1024          # dense pitch limit of cgnn_dense_adj_f16
+
+
+def eligible(model, batch, structure: BatchStructure) -> Optional[str]:
+    hid = model.convs[0].linear.weight.shape[0]
+    if hid % 64 or not bool(_lib.load().cgnn_bn_act_width_ok(hid)):
+        return "hidden_dim is not 64, 128, 256, ..."
+    if not structure.block_diagonal:
+        return "edges cross graph boundaries"
+    if structure.max_nodes_per_graph > MAX_NODES:
+        return f"a graph has more than {MAX_NODES} nodes"
+    if batch.node_features.requires_grad:
+        return "node_features require grad"
+    if model.convs[0].linear.weight.shape[1] > P0_COLS:
+        return f"more than {P0_COLS} input features"
+    if not bn_modules_ok(model) or any(isinstance(bn, torch.nn.SyncBatchNorm) for bn in model.batch_norms):
+        return "BatchNorm is not a plain affine BatchNorm1d with running stats"
+    return None
+
+
+def dense_operators(s: BatchStructure):
+    """(Mf, Mb): dense normalised operator and its transpose, built once per batch structure."""
+    cached = s.__dict__.get("_dense_f16")
+    if cached is None:
+        norm = s.gcn_norm()
+        cached = (ops.dense_adj_f16(s, norm.coef_dst, norm.selfc, False),
+                  ops.dense_adj_f16(s, norm.coef_src, norm.selfc, True))
+        s.__dict__["_dense_f16"] = cached
+    return cached
+
+
+P0_COLS = 64             # layer 0's input features ride in one 64-column half panel
+
+
+def _weight_grad(dt: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """dW = dT^T X  ([Nn, N]^T [Nn, K] -> fp32 [N, K]) as a split-K batched half GEMM: chunks of ~2048
+    rows each produce a half [N, K] partial (fp32 accumulate inside), the partials are summed in
+    fp32.  The single tall GEMM runs at a tenth of this in the library (no split-K heuristics for
+    a 64000-deep reduction) and rounds the whole sum to half once."""
+    n = dt.shape[0]
+    chunks = max(1, n // 2048)
+    rows = (n // chunks) * chunks
+    per = rows // chunks
+    part = torch.bmm(dt[:rows].view(chunks, per, dt.shape[1]).transpose(1, 2),
+                     x[:rows].view(chunks, per, x.shape[1]))
+    dw = part.float().sum(0)
+    if rows < n:
+        dw += torch.matmul(dt[rows:].t(), x[rows:]).float()
+    return dw
+
+
+class _Saved:
+    __slots__ = ("s", "mb", "xs", "ys", "coefs", "masks", "ws", "p0", "p", "training")
+
+
+def _f32(dev, *shape):
+    return torch.empty(*shape, dtype=torch.float32, device=dev)
+
+
+class GcnHalfEncode(torch.autograd.Function):
+    """P[B,H] = mean-pool(GCN stack(x0)), activations stored as half."""
+
+    @staticmethod
+    def forward(ctx, x0, cfg, *params):
+        lib = _lib.load()
+        s: BatchStructure = cfg["structure"]
+        bns_mod = cfg["batch_norms"]
+        training: bool = cfg["training"]
+        p: float = cfg["dropout"] if training else 0.0
+        L = len(params) // 4
+        dev = x0.device
+        sp = _lib.stream_ptr(dev)
+        n_nodes, B = s.num_nodes, s.num_graphs
+        mf, mb = dense_operators(s)
+        sv = _Saved()
+        sv.s, sv.mb, sv.p, sv.training = s, mb, p, training
+        sv.xs, sv.ys, sv.coefs, sv.masks, sv.ws = [], [], [], [], []
+        x = None
+        with _lib.device_guard(dev):
+            rows = int(lib.cgnn_bn_act_slab_rows(n_nodes))
+            for li in range(L):
+                w, b, gamma, beta = (t.contiguous() for t in params[4 * li:4 * li + 4])
+                hid = w.shape[0]
+                if li == 0:
+                    # A_hat (X0 W0^T) == (A_hat X0) W0^T: aggregate the few input columns (one
+                    # 64-column half panel through the dense operator), then project
+                    f0 = x0.shape[1]
+                    x0h = torch.zeros(n_nodes, P0_COLS, dtype=torch.float16, device=dev)
+                    x0h[:, :f0] = x0
+                    sv.p0 = ops.dense_aggregate_f16_raw(s, mf, x0h)        # [Nn, 64] half, cols >= F0 zero
+                    y = torch.addmm(b.half(), sv.p0[:, :f0], w.half().t())
+                else:
+                    t = torch.matmul(x, w.half().t())                      # half GEMM, fp32 accumulate
+                    y = ops.dense_aggregate_f16_raw(s, mf, t, b)
+                slab = None
+                if training:
+                    slab = torch.empty(rows, 2 * hid, dtype=torch.float64, device=dev)
+                    _lib.check(lib.cgnn_bn_act_fwd_stats_f16(_lib.ptr(y), n_nodes, hid, _lib.ptr(slab), sp),
+                               "cgnn_bn_act_fwd_stats_f16")
+                bn = bns_mod[li]
+                coef = _f32(dev, 4 * hid)
+                _lib.check(lib.cgnn_bn_act_finalize(
+                    _lib.ptr(slab), rows, hid, float(max(n_nodes, 1)), None, int(training), _lib.ptr(gamma),
+                    _lib.ptr(beta), _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var), float(bn.momentum),
+                    float(bn.eps), _lib.ptr(bn.num_batches_tracked) if training else None, _lib.ptr(coef), sp),
+                    "cgnn_bn_act_finalize")
+                mask = torch.empty(n_nodes * (hid // 4), dtype=torch.uint8, device=dev) if p > 0 else None
+                seed = _lib.next_seed(dev) if p > 0 else 0
+                sv.xs.append(x); sv.ys.append(y); sv.coefs.append(coef); sv.masks.append(mask); sv.ws.append(w)
+                if li == L - 1:
+                    pooled = _f32(dev, B, hid)
+                    _lib.check(lib.cgnn_bn_act_pool_fwd_f16(_lib.ptr(y), _lib.ptr(coef), 1, p, seed, None,
+                                                            _lib.ptr(mask), _lib.ptr(s.gptr), B,
+                                                            _lib.ptr(pooled), hid, sp), "cgnn_bn_act_pool_fwd_f16")
+                    break
+                xn = torch.empty_like(y)
+                _lib.check(lib.cgnn_bn_act_fwd_apply_f16(_lib.ptr(y), _lib.ptr(coef), 1, p, seed, None,
+                                                         _lib.ptr(mask), _lib.ptr(xn), n_nodes, hid, sp),
+                           "cgnn_bn_act_fwd_apply_f16")
+                x = xn
+        if cfg.get("record") is not None:
+            cfg["record"]["layers"] = list(sv.masks)
+        ctx.sv, ctx.L = sv, L
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dP):
+        lib = _lib.load()
+        sv: _Saved = ctx.sv
+        s, L = sv.s, ctx.L
+        dev = dP.device
+        sp = _lib.stream_ptr(dev)
+        n_nodes = s.num_nodes
+        dP = dP.contiguous()
+        grads: List[Optional[torch.Tensor]] = [None] * (4 * L)
+        with _lib.device_guard(dev):
+            rows = int(lib.cgnn_bn_act_slab_rows(n_nodes))
+            dx = None                           # last layer: gradient rebuilt from dP inside the kernels
+            for li in range(L - 1, -1, -1):
+                x, y, coef, mask, w = sv.xs[li], sv.ys[li], sv.coefs[li], sv.masks[li], sv.ws[li]
+                hid = w.shape[0]
+                pool = (_lib.ptr(dP), _lib.ptr(s.node_graph), _lib.ptr(s.gptr)) if li == L - 1 else (None, None, None)
+                slab = torch.empty(rows, 2 * hid, dtype=torch.float64, device=dev)
+                _lib.check(lib.cgnn_bn_act_bwd_stats_f16(_lib.ptr(dx), _lib.ptr(y), _lib.ptr(mask), _lib.ptr(coef),
+                                                         1, sv.p, n_nodes, hid, _lib.ptr(slab), *pool, sp),
+                           "cgnn_bn_act_bwd_stats_f16")
+                dgamma, dbeta, bwc = _f32(dev, hid), _f32(dev, hid), _f32(dev, 2 * hid)
+                _lib.check(lib.cgnn_bn_act_bwd_finalize(_lib.ptr(slab), rows, hid, float(max(n_nodes, 1)), None,
+                                                        int(not sv.training), _lib.ptr(dgamma), _lib.ptr(dbeta),
+                                                        _lib.ptr(bwc), sp), "cgnn_bn_act_bwd_finalize")
+                cs_rows = int(lib.cgnn_bn_act_apply_blocks(n_nodes, hid))
+                cs_slab = torch.empty(cs_rows, hid, dtype=torch.float64, device=dev)
+                dy = torch.empty_like(y)
+                _lib.check(lib.cgnn_bn_act_bwd_apply_f16(_lib.ptr(dx), _lib.ptr(y), _lib.ptr(mask), _lib.ptr(coef),
+                                                         _lib.ptr(bwc), 1, sv.p, 0, _lib.ptr(cs_slab), _lib.ptr(dy),
+                                                         n_nodes, hid, *pool, sp), "cgnn_bn_act_bwd_apply_f16")
+                db = _f32(dev, hid)            # the bias is added after the aggregation: db = colsum(dY)
+                _lib.check(lib.cgnn_slab_reduce_f64(_lib.ptr(cs_slab), cs_rows, hid, _lib.ptr(db), sp),
+                           "cgnn_slab_reduce_f64")
+                if li == 0:
+                    # Y0 = (A_hat X0) W0^T + b0: dW0 = dY0^T P0, no aggregation in the backward
+                    dw = _weight_grad(dy, sv.p0)[:, :w.shape[1]].contiguous()
+                    grads[0:4] = [dw, db, dgamma, dbeta]
+                    break
+                dt = ops.dense_aggregate_f16_raw(s, sv.mb, dy)             # dT = A_hat^T dY
+                grads[4 * li:4 * li + 4] = [_weight_grad(dt, x), db, dgamma, dbeta]
+                dx = torch.matmul(dt, w.half())                            # dX = dT W
+        ctx.sv = None
+        return (None, None, *grads)
+
+
+def encode(model, batch, structure: BatchStructure) -> torch.Tensor:
+    params = []
+    for conv, bn in zip(model.convs, model.batch_norms):
+        params += [conv.linear.weight, conv.bias, bn.weight, bn.bias]
+    cfg = {"structure": structure, "batch_norms": list(model.batch_norms), "training": model.training,
+           "dropout": float(model.dropout), "record": model._dropout_record()}
+    return GcnHalfEncode.apply(batch.node_features, cfg, *params)

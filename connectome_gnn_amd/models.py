@@ -120,12 +120,19 @@ class _ConnectomeModel(nn.Module):
     _relu_after_bn = False
 
     def __init__(self, in_channels: int, hidden_dim: int = 64, num_classes: int = 2,
-                 num_layers: int = 3, dropout: float = 0.3, *, impl: str = "auto"):
+                 num_layers: int = 3, dropout: float = 0.3, *, impl: str = "auto", storage: str = "fp32"):
         super().__init__()
         if impl not in ("auto", "fused", "layered"):
             raise ValueError("impl must be 'auto', 'fused' or 'layered'")
+        if storage not in ("fp32", "fp16"):
+            raise ValueError("storage must be 'fp32' (the reference's arithmetic) or 'fp16'")
         self.dropout = dropout
         self.impl = impl              # execution path; not part of the reference API/state_dict
+        # "fp16": activations cross HBM as IEEE half, fp32 accumulate (GCN, large dense graphs:
+        # gcn_half_path.py); parameters, gradients and the state_dict stay fp32
+        self.storage = storage
+        if storage == "fp16" and not self._relu_after_bn:
+            raise ValueError("storage='fp16' is implemented for GCNConnectome only")
         self.impl_used = None
         self.rng_device_state = None  # uint32 device words for graph-captured dropout (graphed.py)
         # parity hook: when True, every training forward leaves the dropout keep decisions it drew
@@ -221,6 +228,10 @@ class _ConnectomeModel(nn.Module):
         blocked-ELL of the fused path) now -- these builds read sizes back to the host, so they
         must not happen inside a HIP-graph capture or a timed region."""
         s = batch.structure()
+        if self.storage == "fp16":
+            from . import gcn_half_path
+            gcn_half_path.dense_operators(s)
+            return
         if self._try_fused(batch, s) or s.tiled_ok(self.convs[-1].linear.weight.shape[0]):
             # GCN's ELL carries the self-loop (weight 1), GraphSAGE's does not (weight 0)
             s.fused_meta(_TILE_ROWS, _grid(), 1.0 if self._relu_after_bn else 0.0)
@@ -277,6 +288,13 @@ class GCNConnectome(_ConnectomeModel):
         """Fused per-tile kernels (fused.py) when the shape is covered: hidden 64, <= 16 input
         features, graphs of <= 384 nodes, block-diagonal edges; else the one-node wide encoder
         (gcn_wide_path.py) for hidden 64/128/256 on such graphs; else the op-by-op path."""
+        if self.storage == "fp16":
+            from . import gcn_half_path
+            why = gcn_half_path.eligible(self, batch, structure)
+            if why is not None:
+                raise RuntimeError(f"storage='fp16' requested but not applicable: {why}")
+            self._fused_kind = "half"
+            return True
         if self.impl == "layered":
             return False
         from . import fused, gcn_wide_path
@@ -287,8 +305,9 @@ class GCNConnectome(_ConnectomeModel):
         return self._decide(why)
 
     def _fused_encode(self, batch, structure):
-        from . import fused, gcn_wide_path
-        return (fused if self._fused_kind == "tile" else gcn_wide_path).encode(self, batch, structure)
+        from . import fused, gcn_half_path, gcn_wide_path
+        path = {"tile": fused, "wide": gcn_wide_path, "half": gcn_half_path}[self._fused_kind]
+        return path.encode(self, batch, structure)
 
 
 class GraphSAGEConnectome(_ConnectomeModel):

@@ -391,6 +391,27 @@ int cgnn_gcn_l0_bwd(const float* dZ, const float* Y, const cgnn_l0src* l0, const
                     const float* bwc, const float* P0, int64_t num_nodes, float* dW_slab,
                     double* db_slab, void* stream);
 
+/* fp16-storage forms of the BatchNorm(+ReLU)+dropout kernels (cgnn_bn_act_*): the [M,N] activation
+ * arrays (Y, X, dX, dY) are IEEE half, the arithmetic is fp32, the statistics fp64, coefficient
+ * blocks / masks / slabs / pooled rows exactly as in the fp32 forms.  Used by the fp16-storage
+ * GCN encoder for large dense parcellations (BASELINE config 5); the reference has no fp16 path
+ * (models.py is fp32-only), results are the fp32 oracle's to fp16 resolution. */
+int cgnn_bn_act_fwd_stats_f16(const void* Y, int64_t M, int32_t N, double* slab, void* stream);
+int cgnn_bn_act_fwd_apply_f16(const void* Y, const float* coef, int32_t relu, float p_drop, uint64_t seed,
+                              const uint32_t* seed_dev, uint8_t* mask_out, void* X, int64_t M,
+                              int32_t N, void* stream);
+int cgnn_bn_act_pool_fwd_f16(const void* Y, const float* coef, int32_t relu, float p_drop, uint64_t seed,
+                             const uint32_t* seed_dev, uint8_t* mask_out, const int32_t* gptr,
+                             int32_t num_graphs, float* P, int32_t N, void* stream);
+int cgnn_bn_act_bwd_stats_f16(const void* dX, const void* Y, const uint8_t* mask, const float* coef,
+                              int32_t relu, float p_drop, int64_t M, int32_t N, double* slab,
+                              const float* dP, const int32_t* node_graph, const int32_t* gptr,
+                              void* stream);
+int cgnn_bn_act_bwd_apply_f16(const void* dX, const void* Y, const uint8_t* mask, const float* coef,
+                              const float* bwc, int32_t relu, float p_drop, int32_t relu_in,
+                              double* colsum_slab, void* dY, int64_t M, int32_t N, const float* dP,
+                              const int32_t* node_graph, const int32_t* gptr, void* stream);
+
 /* Single-launch forms of (cgnn_bn_reduce + cgnn_bn_finalize [+ num_batches_tracked += 1]),
  * (cgnn_bn_reduce + cgnn_bn_bwd_finalize) and (cgnn_slab_reduce_f32 + cgnn_slab_reduce_f64):
  * used when no cross-rank exchange sits between the reduction and the finalisation.

@@ -686,3 +686,49 @@ def test_fused_paths_reject_wrong_dtype_and_width(kind, hidden):
     with pytest.raises(TypeError):
         _model(kind, 5, hidden).to(DEV).half()(b)
     m(b)                                                    # and the good batch still runs
+
+
+# ------------------------------------------------- config 5 in fp16 storage against the fp32 oracle
+@pytest.mark.parametrize("dropout", [0.0, 0.3])
+def test_cfg5_fp16_storage_gcn_vs_fp32_oracle(dropout):
+    """BASELINE config 5 as specified: 1000-ROI graphs at 10 % density, hidden 256, fp16 STORAGE with
+    fp32 accumulation (GCNConnectome(storage="fp16"), gcn_half_path.py).  The reference has no fp16
+    path (.half() raises), so the yardstick is the fp32 oracle at fp16 resolution: logits
+    and loss within 1e-2 of their scale, every gradient within 3e-2 of its tensor's scale (three
+    layers of half-rounded activations, 1000-node sums); with dropout the GPU's keep masks are
+    replayed through the oracle."""
+    import connectome_gnn_amd as C
+    from connectome_gnn_amd.resident import assemble_batch
+    from connectome_gnn_amd.synthetic import generate_packed
+    ds = generate_packed(4, 1000, 100, seed=9)
+    b = assemble_batch(ds, torch.arange(4))
+    torch.manual_seed(3)
+    m = C.GCNConnectome(5, 256, dropout=dropout, storage="fp16")
+    sd0 = {k_: v.clone() for k_, v in m.state_dict().items()}
+    m = m.to(DEV).train()
+    m.record_dropout = True
+    bd = b.to(DEV)
+    lg = m(bd)
+    assert lg.dtype == torch.float32 and m.impl_used == "fused" and m._fused_kind == "half"
+    loss_g = torch.nn.functional.cross_entropy(lg, bd.labels)
+    loss_g.backward()
+    masks = P.recorded_masks(m, b.num_nodes, b.num_graphs) if dropout > 0 else None
+    lo, loss_o, g32, st32 = P.oracle_run("gcn", sd0, b, dropout, True, masks)
+    scale = float(lo.abs().max()) + 1e-3
+    assert float((lg.detach().cpu() - lo).abs().max()) <= 1e-2 * scale
+    assert abs(float(loss_g) - float(loss_o)) <= 1e-2 * abs(float(loss_o))
+    for k_, p in m.named_parameters():
+        assert p.grad.dtype == torch.float32
+        w = g32[k_]
+        err = float((p.grad.cpu() - w).abs().max())
+        assert err <= 3e-2 * float(w.abs().max()) + 1e-5, f"{k_}: {err:.3e} vs scale {float(w.abs().max()):.3e}"
+    sd = m.state_dict()
+    for k_ in sd:
+        if "running" in k_:
+            torch.testing.assert_close(sd[k_].cpu(), st32[k_], rtol=5e-3, atol=5e-4)
+    m.eval()
+    with torch.no_grad():
+        e1, e2 = m.encode(bd), m.encode(bd)
+    assert torch.equal(e1, e2) and torch.isfinite(e1).all()
+    with pytest.raises(ValueError):
+        C.GraphSAGEConnectome(5, 64, storage="fp16")
