@@ -102,9 +102,12 @@ def cpu_baseline(model: str, n: int, k: int, hidden: int, budget_s: float = 20.0
 
 
 PMC_FILES = {   # workload -> (file under profiles/, batch it was taken at, kernel names averaged)
-    "cfg4-headline-gcn-4096x360-h64": ("r01_fused_pmc_traffic.json", 4096,
-                                       ("k_gcn_bwd<384, false, false>", "k_gcn_bwd<384, false, true>")),
-    "cfg3-sage-512x360-h128": ("r01_cfg3_pmc_traffic.json", 512, ("k_agg_tiled",)),
+    "cfg4-headline-gcn-4096x360-h64": ("r02_headline_pmc_traffic.json", 4096,
+                                       ("k_gcn_bwd<384, false, true, false>", "k_gcn_bwd<384, false, false, true>")),
+    "cfg3-sage-512x360-h128": ("r02_cfg3_pmc_traffic.json", 512, ("k_agg_tiled",)),
+    "cfg2-gcn-512x84-h64": ("r02_cfg2_pmc_traffic.json", 512,
+                            ("k_gcn_bwd<384, false, true, false>", "k_gcn_bwd<384, false, false, true>")),
+    "cfg5-gcn-64x1000-h256-fp16": ("r02_cfg5_fp16_pmc_traffic.json", 64, ("k_dense_agg",)),
 }
 
 

@@ -35,7 +35,7 @@ doc = {"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passe
 total = 0.0
 for k in f:
     s = short(k)
-    if not s.startswith("k_") or s in SETUP:
+    if s in SETUP or s.startswith("at::") or s.startswith("__amd") or "Cijk" in s:
         continue
     fa = sum(f[k]) / len(f[k])
     wl = w.get(k, [0.0])
