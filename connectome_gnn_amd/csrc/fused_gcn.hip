@@ -727,7 +727,15 @@ __global__ void __launch_bounds__(NTHR) k_gcn_bwd(
       const float4 ca = ld4(bn + 4 * j), cmean = ld4(bn + 2 * HID + 4 * j), cis = ld4(bn + 3 * HID + 4 * j);
       const float4 c1 = ld4(bwc + 4 * j), c2 = ld4(bwc + HID + 4 * j);
       const float4 cb = POOLIN ? ld4(bn + HID + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
-      constexpr int UNR = 6;
+#ifndef CGNN_BWD_UNR
+#define CGNN_BWD_UNR 6
+#endif
+#ifndef CGNN_BWD_UNR_POOL
+#define CGNN_BWD_UNR_POOL 6
+#endif
+      // rows requested per thread before the first is consumed: every batch is one exposed HBM
+      // round trip of this phase (the dW accumulators leave no room to prefetch across tiles)
+      constexpr int UNR = POOLIN ? CGNN_BWD_UNR_POOL : CGNN_BWD_UNR;
       for (int r0 = threadIdx.x >> 4; r0 < nblk * 16; r0 += 32 * UNR) {
         float4 zb[UNR], yb[UNR];
         float dv[UNR];
