@@ -196,12 +196,15 @@ class BatchStructure:
                 if cuts[-1] != ptr[-1]:
                     cuts = np.append(cuts, ptr[-1])
             else:
-                cuts, start = [0], 0
-                for g in range(sizes.size):            # greedy: close a tile before it overflows
-                    if ptr[g + 1] - start > cap:
-                        cuts.append(int(ptr[g]))
-                        start = int(ptr[g])
-                cuts.append(int(ptr[-1]))
+                # greedy: a tile takes as many whole graphs as fit under the cap -- one binary
+                # search per TILE over the node offsets (not a Python step per graph)
+                cuts, start, end, g = [0], 0, int(ptr[-1]), 0
+                while start < end:
+                    g = int(np.searchsorted(ptr, start + cap, side="right")) - 1   # ptr[g] <= start + cap
+                    if int(ptr[g]) <= start:
+                        raise ValueError("a graph exceeds the tile capacity")
+                    start = int(ptr[g])
+                    cuts.append(start)
                 cuts = np.asarray(cuts, dtype=np.int64)
             rows = int(np.diff(cuts).max()) if cuts.size > 1 else 0
             t = torch.from_numpy(cuts.astype(np.int32)).to(self.rowptr_dst.device)
