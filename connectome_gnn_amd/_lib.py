@@ -55,7 +55,7 @@ PROTOTYPES = {
     "cgnn_aggregate_f32": (c_int, [P, P, P, P, P, P, P, I64, P, I64, I64, I32, P]),
     "cgnn_aggregate_tiled_f16": (c_int, [TP, I32, P, I64, I32, P, P, P, P, I64, P]),
     "cgnn_head_supported": (c_int, [I32, I32, I32]),
-    "cgnn_head_grid": (c_int, [I32, I32]),
+    "cgnn_head_grid": (c_int, [I32, I32, I32, I32]),
     "cgnn_head_fwd_f32": (c_int, [P, I32, I32, I32, I32, P, P, P, P, F32, U64, P, P, P, P, P]),
     "cgnn_head_bwd_f32": (c_int, [P, P, P, P, I32, I32, I32, I32, P, P, P, P, P]),
     "cgnn_cross_entropy_f32": (c_int, [P, P, I32, I32, P, P, P]),

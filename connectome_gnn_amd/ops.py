@@ -407,7 +407,7 @@ class _Head(torch.autograd.Function):
         dev = p.device
         wd = h2 * h + h2 + c * h2 + c
         with _lib.device_guard(dev):
-            rows = int(lib.cgnn_head_grid(bsz, h2))
+            rows = int(lib.cgnn_head_grid(bsz, h, h2, c))
             slab = torch.empty(rows, wd, dtype=torch.float32, device=dev)
             dp = torch.empty_like(p)
             flat = torch.empty(wd, dtype=torch.float32, device=dev)

@@ -493,7 +493,7 @@ int cgnn_bn_act_bwd_apply(const float* dX, const float* Y, const uint8_t* mask, 
  * cgnn_head_supported: H <= 128, H2 <= 64 and a divisor of 256, C <= 16.
  * ------------------------------------------------------------------------------------- */
 int cgnn_head_supported(int32_t H, int32_t H2, int32_t C);
-int cgnn_head_grid(int32_t B, int32_t H2);
+int cgnn_head_grid(int32_t B, int32_t H, int32_t H2, int32_t C);   /* rows of cgnn_head_bwd_f32's slab */
 int cgnn_head_fwd_f32(const float* P, int32_t B, int32_t H, int32_t H2, int32_t C, const float* W1,
                       const float* b1, const float* W2, const float* b2, float p_drop,
                       uint64_t seed, const uint32_t* seed_dev, float* H1, float* fac, float* logits,
