@@ -663,8 +663,8 @@ struct PoolIn {
 
 // XP0: the previous layer's output is layer 0's in factored form: its rows are rebuilt from the
 // narrow aggregate l0.P0 (32 bytes per row) instead of being read from Xprev (256 bytes per row).
-template <int MAXR, bool FIRST, bool POOLIN, bool XP0 = false>
-__global__ void __launch_bounds__(NTHR) k_gcn_bwd(
+template <int MAXR, bool FIRST, bool POOLIN, bool XP0 = false, int NW = NWAVE>
+__global__ void __launch_bounds__(NW * 64) k_gcn_bwd(
     cgnn_tiles t, PoolIn pin, cgnn_l0src l0, const float* __restrict__ dZ, const float* __restrict__ Y,
     const float* __restrict__ bn, const float* __restrict__ bwc,
     const float* __restrict__ Xprev /* Yprev [Nn,64] or X0 [Nn,F0] */, int F0,
@@ -673,21 +673,21 @@ __global__ void __launch_bounds__(NTHR) k_gcn_bwd(
     float* __restrict__ dZprev, double* __restrict__ s_slab, float* __restrict__ dW_slab,
     double* __restrict__ db_slab) {
   __shared__ __attribute__((aligned(16))) float tile[MAXR * HID];
-  __shared__ __attribute__((aligned(16))) float stg_all[NWAVE * STG_FLOATS];
+  __shared__ __attribute__((aligned(16))) float stg_all[NW * STG_FLOATS];
   __shared__ uint4 wsp[FIRST ? 1 : WSP_FRAGS];          // split W panel for dX = dT W (24 KB)
   __shared__ float disl[MAXR];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, j = lane & 15;
   float* stg = stg_all + wave * STG_FLOATS;
   const uint4* ent = static_cast<const uint4*>(t.ent_src);
 
-  if (!FIRST) stage_split_weight<true>(wsp, W, NTHR);
+  if (!FIRST) stage_split_weight<true>(wsp, W, (NW * 64));
   // previous layer's BatchNorm block (a | b | mean | invstd) lives in LDS, not in 16 registers
   __shared__ __attribute__((aligned(16))) float bnl[FIRST ? 4 : 4 * HID];
   if (!FIRST) {
-    for (int i = threadIdx.x; i < 4 * HID; i += NTHR) bnl[i] = bn_prev[i];
+    for (int i = threadIdx.x; i < 4 * HID; i += (NW * 64)) bnl[i] = bn_prev[i];
   }
   __shared__ __attribute__((aligned(16))) float wl0[XP0 ? L0_LDS_FLOATS : 4];
-  if (XP0) l0_stage(wl0, l0, NTHR);
+  if (XP0) l0_stage(wl0, l0, (NW * 64));
   // dW accumulators: FIRST: dw[ti][0] only (16 input columns); else dw[ti][tj].
   f32x4 dw[4][FIRST ? 1 : 4];
 #pragma unroll
@@ -707,16 +707,13 @@ __global__ void __launch_bounds__(NTHR) k_gcn_bwd(
     const int n = t.tile_ptr[tid + 1] - base;
     const int nblk = (n + 15) >> 4;
     const int gb0 = t.tile_blk[tid];
-    int boff[3] = {0, 0, 0}, bwid[3] = {0, 0, 0};
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int bb = cgnn_uniform(wave) + NWAVE * k;
-      if (bb < nblk) {
-        boff[k] = t.blk_off_src[gb0 + bb];
-        bwid[k] = (t.blk_off_src[gb0 + bb + 1] - boff[k]) >> 4;
-      }
+    // entry offset / width of a block: scalar loads (wave-uniform index)
+    const int uw = cgnn_uniform(wave);
+    int off0 = 0, width = 0;
+    if (uw < nblk) {
+      off0 = t.blk_off_src[gb0 + uw];
+      width = (t.blk_off_src[gb0 + uw + 1] - off0) >> 4;
     }
-    int off0 = boff[0], width = bwid[0], bk = 0;
     MetaRegs pre;
     if (wave < nblk) pre = meta_issue<FIRST>(ent + (off0 >> 1), width, q, j);
 
@@ -736,14 +733,14 @@ __global__ void __launch_bounds__(NTHR) k_gcn_bwd(
       // rows requested per thread before the first is consumed: every batch is one exposed HBM
       // round trip of this phase (the dW accumulators leave no room to prefetch across tiles)
       constexpr int UNR = POOLIN ? CGNN_BWD_UNR_POOL : CGNN_BWD_UNR;
-      for (int r0 = threadIdx.x >> 4; r0 < nblk * 16; r0 += 32 * UNR) {
+      for (int r0 = threadIdx.x >> 4; r0 < nblk * 16; r0 += (NW * 4) * UNR) {
         float4 zb[UNR], yb[UNR];
         float dv[UNR];
         int gid[UNR];
         uint32_t kb[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-          const int row = r0 + 32 * u;
+          const int row = r0 + (NW * 4) * u;
           zb[u] = yb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
           dv[u] = 0.f;
           gid[u] = 0;
@@ -762,7 +759,7 @@ __global__ void __launch_bounds__(NTHR) k_gcn_bwd(
         if (POOLIN) {
 #pragma unroll
           for (int u = 0; u < UNR; ++u) {
-            const int row = r0 + 32 * u;
+            const int row = r0 + (NW * 4) * u;
             if (row < n) {
               const float inv = 1.0f / ((float)(pin.gptr[gid[u] + 1] - pin.gptr[gid[u]]) + 1e-8f);
               zb[u] = scale4(ld4(pin.dP + (int64_t)gid[u] * HID + 4 * j), inv);
@@ -771,7 +768,7 @@ __global__ void __launch_bounds__(NTHR) k_gcn_bwd(
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-          const int row = r0 + 32 * u;
+          const int row = r0 + (NW * 4) * u;
           if (row < nblk * 16) {
             float4 dy = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row < n) {
@@ -800,13 +797,19 @@ __global__ void __launch_bounds__(NTHR) k_gcn_bwd(
     CGNN_STAMP(1)
 
     // --------------------- phase B: dT = A_hat^T dY per block; dW += dT^T X; dZprev = ...
-    for (int b = wave; b < nblk; b += NWAVE) {
+    for (int b = wave; b < nblk; b += NW) {
       float4 yp[4];
       float4 pr[XP0 ? 4 : 1][2];                // XP0: narrow aggregates of rows 4q+r
       uint32_t keeps = 0u;                      // byte r: keep bits of row 4q+r (0 = no such row)
       {
-        ++bk;
-        const int off1 = bk == 1 ? boff[1] : boff[2], width1 = bk == 1 ? bwid[1] : bwid[2];
+        int off1 = 0, width1 = 0;
+        {
+          const int bn2 = cgnn_uniform(b) + NW;
+          if (bn2 < nblk) {
+            off1 = t.blk_off_src[gb0 + bn2];
+            width1 = (t.blk_off_src[gb0 + bn2 + 1] - off1) >> 4;
+          }
+        }
         CGNN_STAMP(2)
         // previous layer's block (rows 4q+r, columns 4j..4j+3): requested AFTER the metadata
         // commit (so the commit does not wait on it) and BEFORE the aggregation (which hides
@@ -847,7 +850,7 @@ __global__ void __launch_bounds__(NTHR) k_gcn_bwd(
 #pragma unroll
         for (int it = 0; it < 4; ++it)
           st4(stg + (4 * q + it) * SLD + 4 * j, scale4(ag[it], disl[16 * b + 4 * q + it]));
-        if (b + NWAVE < nblk) pre = meta_issue<FIRST>(ent + (off1 >> 1), width1, q, j);
+        if (b + NW < nblk) pre = meta_issue<FIRST>(ent + (off1 >> 1), width1, q, j);
         off0 = off1; width = width1;
       }
       __builtin_amdgcn_wave_barrier();
@@ -947,19 +950,19 @@ __global__ void __launch_bounds__(NTHR) k_gcn_bwd(
     __syncthreads();
     if (threadIdx.x < 64) {
       double s = 0.0;
-      for (int g2 = 0; g2 < NTHR / 16; ++g2) s += red[g2 * 64 + threadIdx.x];
+      for (int g2 = 0; g2 < (NW * 64) / 16; ++g2) s += red[g2 * 64 + threadIdx.x];
       db_slab[(int64_t)blockIdx.x * 64 + threadIdx.x] = s;
     }
     __syncthreads();
   }
-  if (!FIRST) reduce_stats(s1, s2, reinterpret_cast<double*>(tile), s_slab + (int64_t)blockIdx.x * 128);
+  if (!FIRST) reduce_stats<float, NW>(s1, s2, reinterpret_cast<double*>(tile), s_slab + (int64_t)blockIdx.x * 128);
   // dW: tree over the 8 waves through LDS (fixed order), wave 0 writes the partial.
   {
     constexpr int NTJ = FIRST ? 1 : 4;
     constexpr int PER = 64 * 16 * NTJ;                    // floats per wave partial
     float* red = tile;                                    // up to 4 * 4096 floats = 64 KB
     __syncthreads();
-    for (int half = NWAVE / 2; half >= 1; half >>= 1) {
+    for (int half = NW / 2; half >= 1; half >>= 1) {
       if (wave >= half && wave < 2 * half) {
         float* dst = red + (wave - half) * PER;
 #pragma unroll
@@ -1491,8 +1494,11 @@ int cgnn_gcn_fused_bwd(const cgnn_tiles* t, const float* dZ, const float* Y, con
   DropCfg d = make_drop(p_drop, 0, &use_drop);
   PoolIn pin{dP, node_graph, gptr, mask_cur};
   const cgnn_l0src src = Yprev ? cgnn_l0src{} : *l0;
+#ifndef CGNN_BWD_NW
+#define CGNN_BWD_NW 8
+#endif
 #define CGNN_BWD_LAUNCH(POOL, XP)                                                                      \
-  k_gcn_bwd<CGNN_FUSED_MAX_ROWS, false, POOL, XP><<<fused_grid(), NTHR, 0, cgnn_stream(stream)>>>(     \
+  k_gcn_bwd<CGNN_FUSED_MAX_ROWS, false, POOL, XP, CGNN_BWD_NW><<<fused_grid(), CGNN_BWD_NW * 64, 0, cgnn_stream(stream)>>>( \
       *t, pin, src, dZ, Y, bn, bwc, Yprev, 0, bn_prev, d, use_drop, mask_prev, W, dZprev, s_slab_prev, \
       dW_slab, db_slab)
   if (dP) { if (Yprev) CGNN_BWD_LAUNCH(true, false); else CGNN_BWD_LAUNCH(true, true); }
