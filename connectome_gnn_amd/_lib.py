@@ -43,6 +43,16 @@ class CgnnL0Src(ctypes.Structure):
 
 LP = ctypes.POINTER(CgnnL0Src)
 
+DW_MAX_JOBS = 8
+
+
+class CgnnDwJobs(ctypes.Structure):
+    """Mirror of `struct cgnn_dw_jobs` (include/cgnn.h): several slab -> dW/db reductions, one launch."""
+    _fields_ = [("n", c_int32), ("dw_slab", c_void_p * DW_MAX_JOBS), ("db_slab", c_void_p * DW_MAX_JOBS),
+                ("rows", c_int32 * DW_MAX_JOBS), ("out_cols", c_int32 * DW_MAX_JOBS),
+                ("take_cols", c_int32 * DW_MAX_JOBS), ("dW", c_void_p * DW_MAX_JOBS),
+                ("db", c_void_p * DW_MAX_JOBS)]
+
 # name -> (restype, argtypes).  Order and meaning follow include/cgnn.h exactly.
 PROTOTYPES = {
     "cgnn_abi_version": (c_int, []),
@@ -108,6 +118,7 @@ PROTOTYPES = {
     "cgnn_bn_stats_finalize": (c_int, [P, I32, F64, P, P, P, P, F32, F32, P, P, P]),
     "cgnn_bn_bwd_stats_finalize": (c_int, [P, I32, F64, I32, P, P, P, P]),
     "cgnn_dw_db_reduce": (c_int, [P, P, I32, I32, I32, P, I32, P, P]),
+    "cgnn_dw_db_reduce_multi": (c_int, [ctypes.POINTER(CgnnDwJobs), P]),
     "cgnn_l0_grid": (c_int, []),
     "cgnn_gcn_l0_fwd": (c_int, [TP, P, I32, P, P, P, P, P, P]),
     "cgnn_gcn_l0_bwd": (c_int, [P, P, LP, P, P, P, I64, P, P, P]),

@@ -1287,13 +1287,13 @@ __global__ void __launch_bounds__(256) k_bn_bwd_stats(const double* __restrict__
 
 // dW (f32 slab [rows][64*out_cols]) and db (f64 slab [rows][64]) in one launch:
 // one wave per output element, 4 elements per block.
-__global__ void __launch_bounds__(256) k_dw_db_reduce(const float* __restrict__ dw_slab,
-                                                      const double* __restrict__ db_slab, int rows,
-                                                      int out_cols, int take_cols,
-                                                      float* __restrict__ dW, int ldw,
-                                                      float* __restrict__ db) {
+__device__ __forceinline__ void dw_db_reduce_block(const float* __restrict__ dw_slab,
+                                                   const double* __restrict__ db_slab, int rows,
+                                                   int out_cols, int take_cols,
+                                                   float* __restrict__ dW, int ldw,
+                                                   float* __restrict__ db, int block) {
   const int nw = HID * out_cols;
-  const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int e = block * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (e >= nw + HID) return;
   double s = 0.0;
@@ -1310,6 +1310,31 @@ __global__ void __launch_bounds__(256) k_dw_db_reduce(const float* __restrict__ 
     } else {
       db[e - nw] = (float)s;
     }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_dw_db_reduce(const float* __restrict__ dw_slab,
+                                                      const double* __restrict__ db_slab, int rows,
+                                                      int out_cols, int take_cols,
+                                                      float* __restrict__ dW, int ldw,
+                                                      float* __restrict__ db) {
+  dw_db_reduce_block(dw_slab, db_slab, rows, out_cols, take_cols, dW, ldw, db, blockIdx.x);
+}
+
+// several layers' slabs in ONE launch (the reductions do not feed the backward chain, so they can
+// all wait for its end: one launch instead of one per layer)
+__global__ void __launch_bounds__(256) k_dw_db_reduce_multi(cgnn_dw_jobs jobs) {
+  int block = blockIdx.x;
+#pragma unroll
+  for (int i = 0; i < CGNN_DW_MAX_JOBS; ++i) {
+    if (i >= jobs.n) return;
+    const int nb = (HID * jobs.out_cols[i] + HID + 3) / 4;
+    if (block < nb) {
+      dw_db_reduce_block(jobs.dw_slab[i], jobs.db_slab[i], jobs.rows[i], jobs.out_cols[i], jobs.take_cols[i],
+                         jobs.dW[i], jobs.take_cols[i], jobs.db[i], block);
+      return;
+    }
+    block -= nb;
   }
 }
 
@@ -1560,6 +1585,20 @@ int cgnn_dw_db_reduce(const float* dw_slab, const double* db_slab, int32_t rows,
   const int total = HID * out_cols + HID;
   k_dw_db_reduce<<<(total + 3) / 4, 256, 0, cgnn_stream(stream)>>>(dw_slab, db_slab, rows, out_cols,
                                                                  take_cols, dW, ld_dw, db);
+  CGNN_CHECK_LAUNCH();
+  return CGNN_OK;
+}
+
+int cgnn_dw_db_reduce_multi(const cgnn_dw_jobs* jobs, void* stream) {
+  if (!jobs || jobs->n < 1 || jobs->n > CGNN_DW_MAX_JOBS) return CGNN_EINVAL;
+  int total = 0;
+  for (int i = 0; i < jobs->n; ++i) {
+    if (!jobs->dw_slab[i] || !jobs->db_slab[i] || !jobs->dW[i] || !jobs->db[i] || jobs->rows[i] <= 0 ||
+        jobs->out_cols[i] <= 0 || jobs->take_cols[i] <= 0 || jobs->take_cols[i] > jobs->out_cols[i])
+      return CGNN_EINVAL;
+    total += (HID * jobs->out_cols[i] + HID + 3) / 4;
+  }
+  k_dw_db_reduce_multi<<<total, 256, 0, cgnn_stream(stream)>>>(*jobs);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }

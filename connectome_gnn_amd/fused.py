@@ -204,8 +204,9 @@ class FusedGCNEncode(torch.autograd.Function):
         d_pooled = d_pooled.contiguous()
         s_slab = torch.empty(grid, 128, **f64)
         sums = torch.empty(128, **f64)
-        dw_slab = torch.empty(grid, HID * HID, **f32)
-        db_slab = torch.empty(grid, HID, **f64)
+        # every layer gets its own slabs: all slab -> dW/db reductions run as ONE launch at the end
+        # of the backward (they do not feed the chain)
+        jobs = []
         dz = torch.empty(nn_, HID, **f32)
         dz_prev = torch.empty(nn_, HID, **f32) if L > 1 else None
         grads: List[Optional[torch.Tensor]] = [None] * (4 * L)
@@ -250,6 +251,8 @@ class FusedGCNEncode(torch.autograd.Function):
             for l in range(L - 1, 0, -1):
                 w = params[4 * l].contiguous()
                 extra = pool_args if l == L - 1 else none_args
+                dw_slab = torch.empty(grid, HID * HID, **f32)
+                db_slab = torch.empty(grid, HID, **f64)
                 with _lib.timed("cgnn_gcn_fused_bwd"):
                     _lib.check(lib.cgnn_gcn_fused_bwd(
                         tp, _lib.ptr(dz), _lib.ptr(c.ys[l]), _lib.ptr(c.bns[l]), _lib.ptr(bwc),
@@ -258,9 +261,7 @@ class FusedGCNEncode(torch.autograd.Function):
                         _lib.ptr(w), _lib.ptr(dz_prev), _lib.ptr(s_slab), _lib.ptr(dw_slab),
                         _lib.ptr(db_slab), *extra, st()), "cgnn_gcn_fused_bwd")
                 dw, db = torch.empty(HID, HID, **f32), torch.empty(HID, **f32)
-                _lib.check(lib.cgnn_dw_db_reduce(_lib.ptr(dw_slab), _lib.ptr(db_slab), grid, HID, HID,
-                                                 _lib.ptr(dw), HID, _lib.ptr(db), st()),
-                           "cgnn_dw_db_reduce")
+                jobs.append((dw_slab, db_slab, grid, HID, HID, dw, db))
                 grads[4 * l], grads[4 * l + 1] = dw, db
                 bwc = bn_backward(l - 1)
                 dz, dz_prev = dz_prev, dz
@@ -275,20 +276,27 @@ class FusedGCNEncode(torch.autograd.Function):
                         _lib.ptr(dz), None, ctypes.byref(c.l0src), _lib.ptr(c.bns[0]), _lib.ptr(bwc),
                         _lib.ptr(c.p0), nn_, _lib.ptr(dw_slab0), _lib.ptr(db_slab0), st()),
                         "cgnn_gcn_l0_bwd")
-                _lib.check(lib.cgnn_dw_db_reduce(_lib.ptr(dw_slab0), _lib.ptr(db_slab0), g0, 8, c.f0,
-                                                 _lib.ptr(dw0), c.f0, _lib.ptr(db0), st()),
-                           "cgnn_dw_db_reduce")
+                jobs.append((dw_slab0, db_slab0, g0, 8, c.f0, dw0, db0))
             else:
                 extra = pool_args if L == 1 else none_args
+                dw_slab = torch.empty(grid, HID * 16, **f32)
+                db_slab = torch.empty(grid, HID, **f64)
                 with _lib.timed("cgnn_gcn_fused_bwd_first"):
                     _lib.check(lib.cgnn_gcn_fused_bwd_first(
                         tp, _lib.ptr(dz), _lib.ptr(c.ys[0]), _lib.ptr(c.bns[0]), _lib.ptr(bwc),
                         _lib.ptr(c.x0), c.f0, _lib.ptr(dw_slab), _lib.ptr(db_slab), c.p, *extra, st()),
                         "cgnn_gcn_fused_bwd_first")
-                _lib.check(lib.cgnn_dw_db_reduce(_lib.ptr(dw_slab), _lib.ptr(db_slab), grid, 16, c.f0,
-                                                 _lib.ptr(dw0), c.f0, _lib.ptr(db0), st()),
-                           "cgnn_dw_db_reduce")
+                jobs.append((dw_slab, db_slab, grid, 16, c.f0, dw0, db0))
             grads[0], grads[1] = dw0, db0
+            for i0 in range(0, len(jobs), _lib.DW_MAX_JOBS):
+                chunk = jobs[i0:i0 + _lib.DW_MAX_JOBS]
+                jb = _lib.CgnnDwJobs()
+                jb.n = len(chunk)
+                for i, (sw, sb, rows, oc, tc, dw_o, db_o) in enumerate(chunk):
+                    jb.dw_slab[i], jb.db_slab[i] = sw.data_ptr(), sb.data_ptr()
+                    jb.rows[i], jb.out_cols[i], jb.take_cols[i] = rows, oc, tc
+                    jb.dW[i], jb.db[i] = dw_o.data_ptr(), db_o.data_ptr()
+                _lib.check(lib.cgnn_dw_db_reduce_multi(ctypes.byref(jb), st()), "cgnn_dw_db_reduce_multi")
         ctx.c = None
         return (None, None, *grads)
 

@@ -424,6 +424,18 @@ int cgnn_bn_bwd_stats_finalize(const double* slab, int32_t rows, double count, i
                                float* dgamma, float* dbeta, float* bwc, void* stream);
 int cgnn_dw_db_reduce(const float* dw_slab, const double* db_slab, int32_t rows, int32_t out_cols,
                       int32_t take_cols, float* dW, int32_t ld_dw, float* db, void* stream);
+/* The same for up to CGNN_DW_MAX_JOBS layers in one launch (dW[i] dense [64][take_cols[i]]): the
+ * reductions do not feed the backward chain, so all of a model's layers wait for its end. */
+#define CGNN_DW_MAX_JOBS 8
+typedef struct cgnn_dw_jobs {
+  int32_t n;
+  const float* dw_slab[CGNN_DW_MAX_JOBS];
+  const double* db_slab[CGNN_DW_MAX_JOBS];
+  int32_t rows[CGNN_DW_MAX_JOBS], out_cols[CGNN_DW_MAX_JOBS], take_cols[CGNN_DW_MAX_JOBS];
+  float* dW[CGNN_DW_MAX_JOBS];
+  float* db[CGNN_DW_MAX_JOBS];
+} cgnn_dw_jobs;
+int cgnn_dw_db_reduce_multi(const cgnn_dw_jobs* jobs, void* stream);
 
 /* Fixed-order combination of per-workgroup partials (fp64 accumulate):
  * f32 slab [rows][width] -> out[r*ld_out + c] for width = out_rows*out_cols (take the first
