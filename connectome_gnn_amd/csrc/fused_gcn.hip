@@ -1024,7 +1024,10 @@ __global__ void __launch_bounds__(PTHR) k_pool_fwd(const float* __restrict__ Y,
   for (int g = blockIdx.x; g < B; g += gridDim.x) {
     const int rbeg = gptr[g], rend = gptr[g + 1];
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f), f1 = s, f2 = s;
-    constexpr int U = 4;                       // rows in flight per thread (latency-bound otherwise)
+#ifndef CGNN_POOL_U
+#define CGNN_POOL_U 4
+#endif
+    constexpr int U = CGNN_POOL_U;             // rows in flight per thread (latency-bound otherwise)
     for (int row0 = rbeg + rr; row0 < rend; row0 += 16 * U) {
       float4 yb[U];
 #pragma unroll

@@ -164,7 +164,10 @@ __global__ void __launch_bounds__(L0BTHR) k_l0_bwd(const float* __restrict__ dZ,
 #pragma unroll
     for (int k = 0; k < FP; ++k) dw[c][k] = 0.f;
   float db[4] = {0.f, 0.f, 0.f, 0.f};
-  constexpr int U = 4;                           // rows in flight per thread
+#ifndef CGNN_L0B_U
+#define CGNN_L0B_U 4
+#endif
+  constexpr int U = CGNN_L0B_U;                  // rows in flight per thread
   const int64_t stride = (int64_t)gridDim.x * 16;
   for (int64_t row0 = (int64_t)blockIdx.x * 16 + rr; row0 < nn; row0 += stride * U) {
     float4 zb[U], yb[U], pa[U], pb[U];
