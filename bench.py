@@ -147,6 +147,21 @@ def end_to_end(C, ds, model, opt, bsz: int, epochs: int = 6) -> dict:
     out["cached_batches"] = {"graphs_per_s": steps * bsz / dt2, "ms_per_step": dt2 / steps * 1e3,
                              "what": "same Trainer loop, fixed batch composition (order shuffled), "
                                      "structure cached per batch"}
+    # fresh composition every epoch again, but the structure of a batch gathered from the
+    # per-SUBJECT cache (structure_cache.py; one graph per tile, per-tile GCN path)
+    n = int(big.x.shape[1])
+    if 192 < n <= 384 and getattr(model, "_fused_kind", None) == "tile":
+        ld3 = ResidentDataLoader(big, batch_size=bsz, shuffle=True, structure_cache=True)
+        tr.train_epoch(ld3)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(epochs):
+            tr.train_epoch(ld3)
+        torch.cuda.synchronize()
+        dt3 = time.perf_counter() - t0
+        out["subject_cache"] = {"graphs_per_s": steps * bsz / dt3, "ms_per_step": dt3 / steps * 1e3,
+                                "what": "fresh shuffled batch every step; blocked-ELL / dis of every "
+                                        "subject built once, a batch's structure = three gathers"}
     return out
 
 

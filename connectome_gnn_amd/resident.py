@@ -41,13 +41,18 @@ class ResidentDataLoader:
 
     def __init__(self, dataset: PackedDataset, batch_size: int = 16, shuffle=True,
                  rank: int = 0, world_size: int = 1, prefetch: bool = False, prepare=None,
-                 cache_batches: bool = False):
+                 cache_batches: bool = False, structure_cache: bool = False):
         """shuffle: True (new random composition of every batch each epoch, the reference's
         semantics), False, or "batches": the batches are composed once (one random permutation)
         and only their ORDER is re-drawn every epoch.  cache_batches (needs shuffle False or
         "batches"): the assembled device batches -- with their CSR / blocked-ELL structure -- are
         kept and handed out again each epoch, so per-batch work is paid once and
         ``Trainer(graph=True)`` can replay one captured HIP graph per batch.
+
+        structure_cache: build every SUBJECT's blocked-ELL / `dis` once (structure_cache.py) and
+        assemble a batch's structure by three small gathers -- for the per-tile fused GCN encoder on
+        datasets with one graph per tile (193..384 nodes); every epoch can then re-draw the batch
+        composition (shuffle=True) at no per-batch build cost.
 
         prefetch: assemble the NEXT batch and build its structure (CSR, and whatever
         ``prepare(batch)`` builds, e.g. ``model.prepare_batch``) on a side stream while the caller
@@ -62,6 +67,10 @@ class ResidentDataLoader:
         self.cache_batches = cache_batches
         self._fixed_order = None           # composition of the batches for shuffle='batches'
         self._cache = None
+        self.structure_cache = None
+        if structure_cache:
+            from .structure_cache import SubjectStructureCache
+            self.structure_cache = SubjectStructureCache(dataset)
 
     def __len__(self) -> int:
         return -(-self.dataset.num_subjects // self.batch_size)
@@ -84,6 +93,11 @@ class ResidentDataLoader:
             yield chunk
 
     def __iter__(self):
+        if self.structure_cache is not None and not self.cache_batches:
+            from .structure_cache import ResidentBatch
+            for chunk in self._chunks():
+                yield ResidentBatch(self.structure_cache, chunk)
+            return
         if self.cache_batches:
             if self._cache is None:
                 self._cache = []

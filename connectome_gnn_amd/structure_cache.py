@@ -1,0 +1,179 @@
+"""Per-subject structure cache for device-resident datasets.
+
+Re-shuffling a resident dataset every epoch (the reference's loader semantics, graph.py:192-197)
+makes every batch new, and building a batch's structure -- on-device collate of the int64 COO
+(454 MB at 4096 x 360 ROI), the two CSR orderings (342 MB), the two blocked-ELL arrays (424 MB)
+-- costs 1.5 ms against a 2.1 ms step.  None of it depends on the batch: a subject's graph is
+fixed, and when a tile holds exactly one graph (more than 192 nodes per graph, e.g. 360 ROI) the
+tile's blocked-ELL entries, its block offsets and its `dis` vector ARE the subject's.  So they
+are built once per subject (with the ordinary HIP builders, over the dataset in chunks) and a
+batch's structure becomes three small gathers:
+
+    blk_off_{dst,src}[tile] = cache.blk_off[subject]      (absolute offsets into the cache arrays)
+    dis[tile rows]          = cache.dis[subject]
+    entries                 = the cache arrays themselves  (never copied)
+
+The fused kernels index blocks as tile_blk[tile] + b and take a block's width from consecutive
+offsets, so tile_blk gets a stride of (blocks + 1) and every subject's offset row carries its end
+offset: no kernel change.  The public COO fields of the batch (`edge_index`, `edge_weight`,
+`batch`) are assembled lazily, only if something reads them.
+
+Scope: the per-tile fused GCN path (hidden 64) on regular datasets with one graph per tile; anything
+else keeps the ordinary per-batch build.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from .graph import ConnectomeBatch
+from .structure import FusedMeta
+from .synthetic import PackedDataset
+
+MAX_ROWS = 384
+
+
+class SubjectStructureCache:
+    """Blocked-ELL entries (both orderings), block offsets and `dis` of every subject of a dataset."""
+
+    def __init__(self, ds: PackedDataset, chunk: int = 2048):
+        from .resident import assemble_batch
+        lib = _lib.load()
+        n = int(ds.x.shape[1])
+        if not (MAX_ROWS // 2 < n <= MAX_ROWS):
+            raise ValueError(f"structure cache needs one graph per tile: {MAX_ROWS // 2} < nodes <= {MAX_ROWS}, got {n}")
+        dev = ds.x.device
+        self.dataset, self.n = ds, n
+        self.nb = (n + 15) // 16                                     # 16-row blocks per graph
+        S = ds.num_subjects
+        grid = int(lib.cgnn_fused_grid())
+        ents = {"dst": [], "src": []}
+        offs = {"dst": [], "src": []}
+        dis = []
+        base = {"dst": 0, "src": 0}
+        for lo in range(0, S, chunk):
+            ids = torch.arange(lo, min(S, lo + chunk), device=dev)
+            b = assemble_batch(ds, ids)
+            s = b.structure()
+            if not s.block_diagonal:
+                raise ValueError("structure cache: a subject has edges outside its graph")
+            m = s.fused_meta(MAX_ROWS, grid)
+            if int(m.tile_ptr.numel()) - 1 != ids.numel():
+                raise ValueError("structure cache: tiles are not one graph each")
+            dis.append(s.gcn_dis(m).view(ids.numel(), n))
+            for name, blk_off, ent in (("dst", m.blk_off_dst, m.ent_dst), ("src", m.blk_off_src, m.ent_src)):
+                used = int(blk_off[-1])                               # entries (8 bytes each)
+                ents[name].append(ent[:used * 8].clone())
+                # per subject: offsets of its nb blocks + its end offset, absolute in the cache array
+                first = torch.arange(ids.numel(), device=dev) * self.nb
+                rows = blk_off[(first.view(-1, 1) + torch.arange(self.nb + 1, device=dev).view(1, -1))]
+                offs[name].append(rows.to(torch.int64) + base[name])
+                base[name] += used
+            del b, s, m
+        for name in ("dst", "src"):
+            if base[name] > 2 ** 31 - 17:
+                raise ValueError("structure cache exceeds 2^31 entries; cache a smaller dataset")
+        self.ent_dst, self.ent_src = torch.cat(ents["dst"]), torch.cat(ents["src"])
+        self.blk_off_dst = torch.cat(offs["dst"]).to(torch.int32).contiguous()     # [S, nb + 1]
+        self.blk_off_src = torch.cat(offs["src"]).to(torch.int32).contiguous()
+        self.dis = torch.cat(dis).contiguous()                                     # [S, n]
+        self._static = {}
+
+    def static(self, b: int):
+        """Arrays that depend on the batch size only."""
+        if b not in self._static:
+            dev = self.dis.device
+            tile_ptr = (torch.arange(b + 1, device=dev, dtype=torch.int32) * self.n).contiguous()
+            tile_blk = (torch.arange(b + 1, device=dev, dtype=torch.int32) * (self.nb + 1)).contiguous()
+            node_graph = torch.arange(b, device=dev, dtype=torch.int32).repeat_interleave(self.n).contiguous()
+            self._static[b] = (tile_ptr, tile_blk, node_graph)
+        return self._static[b]
+
+
+class CachedStructure:
+    """What the fused per-tile GCN encoder asks of a batch structure, assembled from the cache."""
+
+    def __init__(self, cache: SubjectStructureCache, ids: torch.Tensor):
+        b = int(ids.numel())
+        self.cache = cache
+        self.num_graphs, self.num_nodes = b, b * cache.n
+        self.max_nodes_per_graph = cache.n
+        self.block_diagonal = True
+        tile_ptr, tile_blk, node_graph = cache.static(b)
+        self.gptr, self.node_graph = tile_ptr, node_graph
+        self._meta = FusedMeta(tile_ptr, tile_blk, cache.n, b * (cache.nb + 1),
+                               cache.blk_off_dst.index_select(0, ids).view(-1), cache.ent_dst,
+                               cache.blk_off_src.index_select(0, ids).view(-1), cache.ent_src, None)
+        self._dis = cache.dis.index_select(0, ids).view(-1)
+
+    # -- the interface fused.py / models.py use
+    def fused_meta(self, max_rows: int, num_workgroups: int, self_weight: float = 1.0) -> FusedMeta:
+        if max_rows != MAX_ROWS or self_weight != 1.0:
+            raise ValueError("cached structure serves the GCN tile path only")
+        return self._meta
+
+    def gcn_dis(self, meta: FusedMeta) -> torch.Tensor:
+        """Per-subject `dis`, gathered (a function of the subject's edge weights only)."""
+        return self._dis
+
+    def tiles_struct(self, meta: FusedMeta, dis: Optional[torch.Tensor] = None):
+        t = _lib.CgnnTiles()
+        t.num_nodes = self.num_nodes
+        t.num_tiles = self.num_graphs
+        t.max_tile_rows = meta.max_tile_rows
+        t.tile_ptr, t.tile_blk = meta.tile_ptr.data_ptr(), meta.tile_blk.data_ptr()
+        t.blk_off_dst, t.ent_dst = meta.blk_off_dst.data_ptr(), meta.ent_dst.data_ptr()
+        t.blk_off_src, t.ent_src = meta.blk_off_src.data_ptr(), meta.ent_src.data_ptr()
+        t.dis = dis.data_ptr() if dis is not None else None
+        return t
+
+    def tiled_ok(self, width: int) -> bool:
+        return False
+
+    def __getattr__(self, name):
+        raise AttributeError(f"CachedStructure has no '{name}': it serves the per-tile fused GCN encoder only "
+                             "(use a loader without structure_cache for other models)")
+
+
+class ResidentBatch(ConnectomeBatch):
+    """A ConnectomeBatch of a resident dataset whose structure comes from the subject cache and
+    whose COO fields are assembled on first access (bit-identical to ``assemble_batch``)."""
+
+    def __init__(self, cache: SubjectStructureCache, ids: torch.Tensor):
+        ds = cache.dataset
+        dev = ds.x.device
+        self._cache, self._ids = cache, ids.to(dev)
+        b, n = int(ids.numel()), cache.n
+        self.node_features = ds.x.index_select(0, self._ids).reshape(b * n, -1)
+        self.labels = ds.labels.index_select(0, self._ids)
+        self.ptr = torch.arange(b + 1, device=dev, dtype=torch.long) * n
+        self._coo = None
+        self._structure = CachedStructure(cache, self._ids)
+        self._structure_key = None
+        self._eptr = None
+
+    def _materialise(self):
+        if self._coo is None:
+            from .resident import assemble_batch
+            full = assemble_batch(self._cache.dataset, self._ids)
+            self._coo = (full.edge_index, full.edge_weight, full.batch)
+        return self._coo
+
+    edge_index = property(lambda self: self._materialise()[0])
+    edge_weight = property(lambda self: self._materialise()[1])
+    batch = property(lambda self: self._materialise()[2])
+
+    def structure(self):
+        return self._structure
+
+    def invalidate(self) -> None:
+        raise RuntimeError("a ResidentBatch's structure belongs to the subject cache")
+
+    def to(self, device) -> "ConnectomeBatch":
+        if torch.device(device).type == self.node_features.device.type:
+            return self
+        ei, ew, bt = self._materialise()
+        return ConnectomeBatch(self.node_features.to(device), ei.to(device), ew.to(device), bt.to(device),
+                               self.labels.to(device), self.ptr.to(device))

@@ -53,3 +53,46 @@ def test_trainer_graph_mode_matches_eager_on_cached_batches():
     torch.testing.assert_close(torch.tensor(hist["graph"]), torch.tensor(hist["eager"]), rtol=2e-5, atol=1e-6)
     with pytest.raises(ValueError):
         C.Trainer(C.GCNConnectome(5, 64), torch.optim.Adam(C.GCNConnectome(5, 64).parameters()), graph=True)
+
+
+def test_subject_structure_cache_equals_per_batch_build():
+    """ResidentDataLoader(structure_cache=True): a batch assembled from the per-subject cache
+    (blocked-ELL block offsets + `dis` gathered, entries never copied, COO fields lazy) trains
+    bit-identically to the same subjects through assemble_batch + the per-batch builders."""
+    import connectome_gnn_amd as C
+    from connectome_gnn_amd.resident import ResidentDataLoader, assemble_batch
+    from connectome_gnn_amd.structure_cache import ResidentBatch
+    from connectome_gnn_amd.synthetic import generate_packed
+    ds = generate_packed(24, 360, 14, seed=2).to("cuda")
+    torch.manual_seed(3)
+    ld = ResidentDataLoader(ds, batch_size=8, shuffle=True, structure_cache=True)
+    batches = list(ld)
+    assert len(batches) == 3 and all(isinstance(b, ResidentBatch) for b in batches)
+    outs = []
+    for use_cache in (True, False):
+        torch.manual_seed(0)
+        m = C.GCNConnectome(5, 64, dropout=0.3).to("cuda").train()
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+        res = []
+        for rb in batches:
+            b = rb if use_cache else assemble_batch(ds, rb._ids)
+            opt.zero_grad()
+            lg = m(b)
+            assert m.impl_used == "fused"
+            torch.nn.functional.cross_entropy(lg, b.labels).backward()
+            opt.step()
+            res.append(lg.detach().clone())
+        outs.append((res, [p.detach().clone() for p in m.parameters()]))
+    for a, c in zip(outs[0][0], outs[1][0]):
+        assert torch.equal(a, c)
+    for a, c in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(a, c)
+    # the lazily assembled COO is the ordinary one
+    ref = assemble_batch(ds, batches[0]._ids)
+    assert batches[0]._coo is None
+    assert torch.equal(batches[0].edge_index, ref.edge_index) and torch.equal(batches[0].batch, ref.batch)
+    # other models are refused loudly, not served a wrong structure
+    with pytest.raises((AttributeError, ValueError, RuntimeError)):
+        C.GraphSAGEConnectome(5, 64).to("cuda")(batches[1])
+    with pytest.raises(ValueError):
+        ResidentDataLoader(generate_packed(4, 84, 8, seed=1).to("cuda"), batch_size=2, structure_cache=True)
