@@ -18,9 +18,17 @@
 namespace {
 
 constexpr int TA_MAXR = CGNN_FUSED_MAX_ROWS;   // 384
-constexpr int TA_NW = 8;
+#ifndef CGNN_TA_NW
+#define CGNN_TA_NW 12
+#endif
+#ifndef CGNN_TA_G
+#define CGNN_TA_G 1
+#endif
+constexpr int TA_NW = CGNN_TA_NW;
 constexpr int TA_THR = TA_NW * 64;
-constexpr int TA_PF = TA_MAXR / 32;            // rows per thread in the staging pass
+constexpr int TA_RPP = TA_THR / 16;            // rows per staging pass (16 lanes per row)
+constexpr int TA_PF = (TA_MAXR + TA_RPP - 1) / TA_RPP;   // rows per thread in the staging pass
+constexpr int TA_NR = (TA_MAXR / 16 + TA_NW - 1) / TA_NW; // 16-row blocks per wave
 
 __global__ void __launch_bounds__(TA_THR) k_agg_tiled(
     cgnn_tiles t, int flags, const float* __restrict__ X, int64_t ldx, int nslices,
@@ -43,7 +51,7 @@ __global__ void __launch_bounds__(TA_THR) k_agg_tiled(
     const int nb = t.tile_ptr[tid], nn = t.tile_ptr[tid + 1] - nb;
 #pragma unroll
     for (int k = 0; k < TA_PF; ++k) {
-      const int row = (threadIdx.x >> 4) + 32 * k;
+      const int row = (threadIdx.x >> 4) + TA_RPP * k;
       pfx[k] = make_float4(0.f, 0.f, 0.f, 0.f);
       pfs[k] = 1.f;
       pfp[k] = 1.f;
@@ -62,9 +70,9 @@ __global__ void __launch_bounds__(TA_THR) k_agg_tiled(
     const int n = t.tile_ptr[tid + 1] - base;
     const int nblk = (n + 15) >> 4;
     const int gb0 = t.tile_blk[tid];
-    int boff[3] = {0, 0, 0}, bwid[3] = {0, 0, 0};
+    int boff[TA_NR + 1] = {}, bwid[TA_NR + 1] = {};
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < TA_NR; ++k) {
       const int bb = cgnn_uniform(wave) + TA_NW * k;
       if (bb < nblk) {
         boff[k] = blk_off[gb0 + bb];
@@ -78,7 +86,7 @@ __global__ void __launch_bounds__(TA_THR) k_agg_tiled(
     // ---- stage the slice (rows pre-scaled)
 #pragma unroll
     for (int k = 0; k < TA_PF; ++k) {
-      const int row = (threadIdx.x >> 4) + 32 * k;
+      const int row = (threadIdx.x >> 4) + TA_RPP * k;
       if (row < nblk * 16) {
         const float s = pre_div ? 1.0f / pfs[k] : pfs[k];
         st4(tile + row * 64 + 4 * j, pre_div ? make_float4(pfx[k].x / pfs[k], pfx[k].y / pfs[k],
@@ -94,7 +102,10 @@ __global__ void __launch_bounds__(TA_THR) k_agg_tiled(
     const float4 b4 = bias ? ld4(bias + 64 * slice + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int b = wave; b < nblk; b += TA_NW) {
       ++bk;
-      const int off1 = bk == 1 ? boff[1] : boff[2], width1 = bk == 1 ? bwid[1] : bwid[2];
+      int off1 = 0, width1 = 0;
+#pragma unroll
+      for (int k = 1; k < TA_NR; ++k)
+        if (bk == k) { off1 = boff[k]; width1 = bwid[k]; }
       float4 yo[4];
       if (accumulate) {
 #pragma unroll
@@ -105,7 +116,7 @@ __global__ void __launch_bounds__(TA_THR) k_agg_tiled(
         }
       }
       float4 ag[4];
-      agg_block<4, true>(tile, m, ent + (off0 >> 1), width, q, j, ag);
+      agg_block<CGNN_TA_G, true>(tile, m, ent + (off0 >> 1), width, q, j, ag);
       if (b + TA_NW < nblk) m = meta_issue<true>(ent + (off1 >> 1), width1, q, j);
       off0 = off1; width = width1;
 #pragma unroll

@@ -32,6 +32,7 @@
 // No atomics anywhere: per-workgroup partial sums go to slabs reduced in a fixed order.
 #include "common.h"
 #include "agg_block.h"
+#include "split_bf16.h"
 #include "l0src.h"
 
 // Diagnostic build only (-DCGNN_STAMPS, tools/stamp_probe.py): per-phase s_memtime shares.
@@ -385,34 +386,6 @@ __global__ void __launch_bounds__(NTHR) k_gcn_fwd(
 // of K = 4 for the same 16x16x64 product: 6 x 2 x 16 = 192 instead of 16 x 32 = 512 matrix-pipe
 // cycles per output tile (the fp32 pipe is 1/16 of the bf16 rate on gfx950).
 // ------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ uint32_t pack_hi16(float lo, float hi) {   // (bf16(lo), bf16(hi)), truncating
-  return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
-}
-__device__ __forceinline__ float trunc_bf16(float x) { return __uint_as_float(__float_as_uint(x) & 0xFFFF0000u); }
-
-struct Split8 { uint4 h, m, l; };     // 8 values (two float4) as three bf16x8 fragments
-
-__device__ __forceinline__ Split8 split8(const float4& a, const float4& b) {
-  const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-  uint32_t ph[4], pm[4], pl[4];
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const float x0 = x[2 * p], x1 = x[2 * p + 1];
-    const float r0 = x0 - trunc_bf16(x0), r1 = x1 - trunc_bf16(x1);
-    const float l0 = r0 - trunc_bf16(r0), l1 = r1 - trunc_bf16(r1);
-    ph[p] = pack_hi16(x0, x1);
-    pm[p] = pack_hi16(r0, r1);
-    pl[p] = pack_hi16(l0, l1);
-  }
-  Split8 s;
-  s.h = make_uint4(ph[0], ph[1], ph[2], ph[3]);
-  s.m = make_uint4(pm[0], pm[1], pm[2], pm[3]);
-  s.l = make_uint4(pl[0], pl[1], pl[2], pl[3]);
-  return s;
-}
-
 __device__ __forceinline__ f32x4 mfma_bf16(const uint4& a, const uint4& b, const f32x4& c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
                                                  c, 0, 0, 0);
