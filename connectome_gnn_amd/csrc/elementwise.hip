@@ -174,10 +174,20 @@ __device__ __forceinline__ void slab_colsum2(const double* __restrict__ slab, in
   sh[rg][cc][0] = a1;
   sh[rg][cc][1] = a2;
   __syncthreads();
+  // fixed-order two-level fold (a serial chain of FIN_G dependent LDS reads costs ~3 us)
+  __shared__ double sh2[FIN_G / 8][FIN_C][2];
+  if (rg < FIN_G / 8) {
+    double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { t1 += sh[8 * rg + k][cc][0]; t2 += sh[8 * rg + k][cc][1]; }
+    sh2[rg][cc][0] = t1;
+    sh2[rg][cc][1] = t2;
+  }
+  __syncthreads();
   S1 = S2 = 0.0;
   if (rg == 0) {
 #pragma unroll
-    for (int k = 0; k < FIN_G; ++k) { S1 += sh[k][cc][0]; S2 += sh[k][cc][1]; }
+    for (int k = 0; k < FIN_G / 8; ++k) { S1 += sh2[k][cc][0]; S2 += sh2[k][cc][1]; }
   }
 }
 
@@ -364,7 +374,7 @@ bool width_ok(int N) { return N >= 4 && N <= 1024 && (N & (N - 1)) == 0; }
 // pass is then bound by the latency of each block's own loads
 int stat_rows(int64_t M) {
   int r = ROWS;
-  while (r > 32 && (M + r - 1) / r < 2048) r >>= 1;
+  while (r > 32 && (M + r - 1) / r < 1024) r >>= 1;
   return r;
 }
 int stat_blocks(int64_t M) { const int r = stat_rows(M); return (int)((M + r - 1) / r); }

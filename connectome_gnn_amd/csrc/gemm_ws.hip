@@ -17,7 +17,7 @@
 //                     time, so the second read of a row block is an L2 hit.
 //   k_ws_bwd_weight : reduction over M; both operands stream from HBM/L1 directly into registers
 //                     (lane = column, 8 consecutive rows each), nothing goes through LDS, each
-//                     wave owns a [N x 32] strip of dW; per-workgroup partials are reduced in
+//                     wave owns a [N x 32] strip of dW; one partial per workgroup, reduced in
 //                     fixed order.
 //
 // v_mfma_f32_32x32x16_bf16 operand maps (cdna_hip_programming.md section 3):
@@ -316,14 +316,36 @@ __global__ void __launch_bounds__(WS_THR) k_ws_bwd_weight(
       bvv[e] = bn[e];
     }
   }
-  float* out = slab + piece * (int64_t)N * K + 32 * kt + j;
+  if (MS == 1) {
+    float* out = slab + (int64_t)blockIdx.x * N * K + 32 * kt + j;
+#pragma unroll
+    for (int t = 0; t < NTN; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * mh;
+        out[(int64_t)(NTN * i + t) * K] = acc[t][r];
+      }
+    return;
+  }
+  // several waves per strip (K < 256): fold their partials through LDS in fixed order, so that
+  // the workgroup leaves ONE [N x K] partial (K = 32: 2048 partials of 16 KB took longer to reduce
+  // than to produce)
+  __shared__ float red[WS_NW * N * 32];
 #pragma unroll
   for (int t = 0; t < NTN; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = (r & 3) + 8 * (r >> 2) + 4 * mh;
-      out[(int64_t)(NTN * i + t) * K] = acc[t][r];
+      red[wave * (N * 32) + (NTN * i + t) * 32 + j] = acc[t][r];
     }
+  __syncthreads();
+  float* out = slab + (int64_t)blockIdx.x * N * K;
+  for (int e = threadIdx.x; e < N * K; e += WS_THR) {
+    const int n = e / K, kc = e - n * K, strip = kc >> 5;
+    float v = 0.f;
+    for (int ms = 0; ms < MS; ++ms) v += red[(ms * TK + strip) * (N * 32) + n * 32 + (kc & 31)];
+    out[e] = v;
+  }
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -392,7 +414,7 @@ bool cgnn_ws_linear_bwd_input(const float* dY, int64_t lddy, const float* W, int
 int64_t cgnn_ws_bwd_weight_partials(int64_t M, int N, int K) {
   if (M < WS_MIN_ROWS || (N != 64 && N != 128)) return 0;
   if (K != 32 && K != 64 && K != 128 && K != 256) return 0;
-  return (int64_t)cgnn_fused_grid() * (WS_NW / (K / 32));
+  return (int64_t)cgnn_fused_grid();      // one per workgroup
 }
 
 bool cgnn_ws_linear_bwd_weight(const float* dY, int64_t lddy, const float* X1, int64_t ldx1, int K1,

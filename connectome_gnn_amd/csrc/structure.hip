@@ -294,18 +294,24 @@ __global__ void k_gcn_coef(const int64_t* __restrict__ src, const int64_t* __res
   coef_src[s] = dis[src[e]] * w[e] * dis[dst[e]];
 }
 
-__global__ void k_sage_den(const float* __restrict__ w, const int32_t* __restrict__ rowptr_dst,
-                           const int32_t* __restrict__ eid_dst, int64_t nn, float* den,
-                           float* w_dst) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nn) return;
+// 16 lanes per row: coalesced walks of the row's CSR slots, fixed-order fold of the 16 partials
+__global__ void __launch_bounds__(256) k_sage_den(const float* __restrict__ w, const int32_t* __restrict__ rowptr_dst,
+                                                  const int32_t* __restrict__ eid_dst, int64_t nn, float* den,
+                                                  float* w_dst) {
+  const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int l = threadIdx.x & 15;
   float sum = 0.f;
-  for (int s = rowptr_dst[i]; s < rowptr_dst[i + 1]; ++s) {
-    float v = w[eid_dst[s]];
-    w_dst[s] = v;
-    sum += v;
+  if (i < nn) {
+    const int e = rowptr_dst[i + 1];
+    for (int s = rowptr_dst[i] + l; s < e; s += 16) {
+      const float v = w[eid_dst[s]];
+      w_dst[s] = v;
+      sum += v;
+    }
   }
-  den[i] = sum + 1e-8f;                          // models.py:149
+#pragma unroll
+  for (int o = 8; o; o >>= 1) sum += __shfl_xor(sum, o, 16);
+  if (i < nn && l == 0) den[i] = sum + 1e-8f;    // models.py:149
 }
 
 __global__ void k_sage_coef_bwd(const int64_t* __restrict__ dst, const float* __restrict__ w,
@@ -552,7 +558,7 @@ int cgnn_sage_norm(const int64_t* edge_index, const float* w, int64_t nn, int64_
   (void)rowptr_src;
   hipStream_t st = cgnn_stream(stream);
   if (nn > 0) {
-    k_sage_den<<<blocks_for(nn, 256), 256, 0, st>>>(w, rowptr_dst, eid_dst, nn, den, w_dst);
+    k_sage_den<<<blocks_for(nn, 16), 256, 0, st>>>(w, rowptr_dst, eid_dst, nn, den, w_dst);
     CGNN_CHECK_LAUNCH();
   }
   if (ne > 0 && coef_src_bwd) {

@@ -183,12 +183,10 @@ class SageEncode(torch.autograd.Function):
                     # narrow input layer: pack [x0 | agg(x0) | 0] and the zero-padded weight into
                     # 32-wide panels so that the tall weight-stationary GEMMs apply (K = 10 would
                     # otherwise run the per-tile kernels at a few % of the matrix-core rate)
-                    xa = torch.zeros(n_nodes, PAD_K, dtype=torch.float32, device=dev)
-                    xa[:, :fin].copy_(x)
+                    xa = torch.nn.functional.pad(x, (0, PAD_K - fin))        # one pass: [x0 | 0]
                     agg = ops.aggregate_raw(s.rowptr_dst, s.col_dst, sv.norm.w_dst, None, sv.norm.den,
                                             None, x, out=xa[:, fin:2 * fin])
-                    wp = torch.zeros(hid, PAD_K, dtype=torch.float32, device=dev)
-                    wp[:, :2 * fin].copy_(w)
+                    wp = torch.nn.functional.pad(w, (0, PAD_K - 2 * fin))
                     sv.xa0 = xa
                     gemm_in = (xa, None, wp)
                 else:
