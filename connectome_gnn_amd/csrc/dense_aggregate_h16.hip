@@ -26,12 +26,18 @@ namespace {
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int D_NW = 8;
+#ifndef CGNN_D_NW
+#define CGNN_D_NW 12
+#endif
+#ifndef CGNN_D_AHEAD
+#define CGNN_D_AHEAD 16
+#endif
+constexpr int D_NW = CGNN_D_NW;
 constexpr int D_THR = D_NW * 64;
 constexpr int D_MAXP = 1024;
 constexpr int D_KPAD = 24;                      // halves of padding per transposed row (>= 16: the
                                                 // B prefetch reads one step past the last)
-constexpr int D_AHEAD = 16;                      // A fragments in flight per wave
+constexpr int D_AHEAD = CGNN_D_AHEAD;                    // A fragments in flight per wave
 
 // row pitch of the transposed slice: k is padded to whole pipeline rounds (zero-filled)
 __host__ __device__ inline int d_kp(int P) {

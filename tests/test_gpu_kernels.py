@@ -284,6 +284,31 @@ def test_linear_forward_backward(m, k1, k2, n, relu, bias):
                                        atol=1e-5 * float(want.abs().max()) + 1e-6)
 
 
+def test_ws_linear_split_bf16_product_is_fp32_accurate():
+    """gemm_ws.hip computes fp32 products as six bf16 partial products (split_bf16.h).  Against an
+    fp64 reference the error must sit at the fp32 ACCUMULATION level (96 fp32 additions per output
+    for K = 256: measured 17 x 2^-24 of sum |x||w| at worst over 590k outputs, an fmaf chain's
+    size) for operands spanning six orders of magnitude, in all three kernels; a dropped second-
+    order term of the split (2^-16 of a product) would show as ~250 x 2^-24."""
+    from connectome_gnn_amd import ops
+    g = torch.Generator().manual_seed(11)
+    m, k, n = 4608, 256, 128
+    mag = lambda *shape: torch.randn(*shape, generator=g) * torch.pow(10.0, torch.rand(*shape, generator=g) * 6 - 3)
+    x, w, dy = mag(m, k), mag(n, k), mag(m, n)
+    xd, wd, dyd = x.to(DEV), w.to(DEV), dy.to(DEV)
+    y = ops.linear_fwd_raw(xd[:, :128], xd[:, 128:], wd, None, False).cpu().double()
+    bound = x.double().abs() @ w.double().abs().t()
+    assert float(((y - x.double() @ w.double().t()).abs() / bound).max()) < 40 * 2.0 ** -24
+    dx = ops.linear_bwd_input_raw(dyd, wd, 0, k).cpu().double()
+    bound = dy.double().abs() @ w.double().abs()
+    assert float(((dx - dy.double() @ w.double()).abs() / bound).max()) < 40 * 2.0 ** -24
+    dw = torch.empty_like(wd)
+    ops.linear_bwd_weight_raw(dyd, xd, dw, 0)
+    bound = dy.double().abs().t() @ x.double().abs()
+    # reduction over 4608 rows in fp32: partial sums of ~18 rows per wave, then 256 partials
+    assert float(((dw.cpu().double() - dy.double().t() @ x.double()).abs() / bound).max()) < 100 * 2.0 ** -24
+
+
 def test_linear_a_identity_asymmetric_b():
     """MFMA layout check (guide section 3): A = I with an ASYMMETRIC B catches a transposed
     C-write that a symmetric B would hide."""
