@@ -1261,35 +1261,76 @@ __global__ void __launch_bounds__(256) k_bn_bwd_stats(const double* __restrict__
   }
 }
 
-// dW (f32 slab [rows][64*out_cols]) and db (f64 slab [rows][64]) in one launch:
-// one wave per output element, 4 elements per block.
+// dW (f32 slab [rows][64*out_cols]) and db (f64 slab [rows][64]) in one launch.  A block folds
+// RD_C consecutive output elements: thread (cc, rg) adds rows rg, rg + RD_G, ... of element cc
+// (every load instruction reads 64-byte row pieces, up to 16 in flight per thread; 64 row groups, since
+// the layer-0 slab has 2048 rows and the fold is a latency chain), then the RD_G partials are
+// combined in fixed order.  [one wave per element with lane = row touched 64 lines
+// per load: 32 us for the three layers of a step]
+constexpr int RD_C = 16, RD_G = 64;      // 1024 threads
+__host__ __device__ inline int dw_db_blocks(int out_cols) { return (HID * out_cols + HID) / RD_C; }
 __device__ __forceinline__ void dw_db_reduce_block(const float* __restrict__ dw_slab,
                                                    const double* __restrict__ db_slab, int rows,
                                                    int out_cols, int take_cols,
                                                    float* __restrict__ dW, int ldw,
                                                    float* __restrict__ db, int block) {
-  const int nw = HID * out_cols;
-  const int e = block * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (e >= nw + HID) return;
+  __shared__ double sh[RD_G][RD_C];
+  const int nw = HID * out_cols;                    // a multiple of RD_C: a block is all dW or all db
+  const int cc = threadIdx.x % RD_C, rg = threadIdx.x / RD_C;
+  const int e = block * RD_C + cc;
   double s = 0.0;
   if (e < nw) {
-    for (int r = lane; r < rows; r += 64) s += (double)dw_slab[(int64_t)r * nw + e];
+    int r = rg;
+    for (; r + 15 * RD_G < rows; r += 16 * RD_G) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = dw_slab[(int64_t)(r + u * RD_G) * nw + e];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += (double)v[u];
+    }
+    for (; r + 3 * RD_G < rows; r += 4 * RD_G) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = dw_slab[(int64_t)(r + u * RD_G) * nw + e];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s += (double)v[u];
+    }
+    for (; r < rows; r += RD_G) s += (double)dw_slab[(int64_t)r * nw + e];
   } else {
-    for (int r = lane; r < rows; r += 64) s += db_slab[(int64_t)r * HID + (e - nw)];
+    int r = rg;
+    for (; r + 7 * RD_G < rows; r += 8 * RD_G) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = db_slab[(int64_t)(r + u * RD_G) * HID + (e - nw)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; r < rows; r += RD_G) s += db_slab[(int64_t)r * HID + (e - nw)];
   }
-  s = cgnn_wave_sum(s);
-  if (lane == 0) {
+  sh[rg][cc] = s;
+  __syncthreads();
+  __shared__ double sh2[RD_G / 8][RD_C];
+  if (rg < RD_G / 8) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += sh[8 * rg + k][cc];
+    sh2[rg][cc] = t;
+  }
+  __syncthreads();
+  if (rg == 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < RD_G / 8; ++k) t += sh2[k][cc];
     if (e < nw) {
-      const int o = e / out_cols, cc = e % out_cols;
-      if (cc < take_cols) dW[(int64_t)o * ldw + cc] = (float)s;
+      const int o = e / out_cols, c2 = e % out_cols;
+      if (c2 < take_cols) dW[(int64_t)o * ldw + c2] = (float)t;
     } else {
-      db[e - nw] = (float)s;
+      db[e - nw] = (float)t;
     }
   }
 }
 
-__global__ void __launch_bounds__(256) k_dw_db_reduce(const float* __restrict__ dw_slab,
+__global__ void __launch_bounds__(RD_C * RD_G) k_dw_db_reduce(const float* __restrict__ dw_slab,
                                                       const double* __restrict__ db_slab, int rows,
                                                       int out_cols, int take_cols,
                                                       float* __restrict__ dW, int ldw,
@@ -1299,12 +1340,12 @@ __global__ void __launch_bounds__(256) k_dw_db_reduce(const float* __restrict__ 
 
 // several layers' slabs in ONE launch (the reductions do not feed the backward chain, so they can
 // all wait for its end: one launch instead of one per layer)
-__global__ void __launch_bounds__(256) k_dw_db_reduce_multi(cgnn_dw_jobs jobs) {
+__global__ void __launch_bounds__(RD_C * RD_G) k_dw_db_reduce_multi(cgnn_dw_jobs jobs) {
   int block = blockIdx.x;
 #pragma unroll
   for (int i = 0; i < CGNN_DW_MAX_JOBS; ++i) {
     if (i >= jobs.n) return;
-    const int nb = (HID * jobs.out_cols[i] + HID + 3) / 4;
+    const int nb = dw_db_blocks(jobs.out_cols[i]);
     if (block < nb) {
       dw_db_reduce_block(jobs.dw_slab[i], jobs.db_slab[i], jobs.rows[i], jobs.out_cols[i], jobs.take_cols[i],
                          jobs.dW[i], jobs.take_cols[i], jobs.db[i], block);
@@ -1558,8 +1599,7 @@ int cgnn_dw_db_reduce(const float* dw_slab, const double* db_slab, int32_t rows,
   if (!dw_slab || !db_slab || !dW || !db || rows <= 0 || out_cols <= 0 || take_cols <= 0 ||
       take_cols > out_cols || ld_dw < take_cols)
     return CGNN_EINVAL;
-  const int total = HID * out_cols + HID;
-  k_dw_db_reduce<<<(total + 3) / 4, 256, 0, cgnn_stream(stream)>>>(dw_slab, db_slab, rows, out_cols,
+  k_dw_db_reduce<<<(HID * out_cols + HID) / RD_C, RD_C * RD_G, 0, cgnn_stream(stream)>>>(dw_slab, db_slab, rows, out_cols,
                                                                  take_cols, dW, ld_dw, db);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
@@ -1572,9 +1612,9 @@ int cgnn_dw_db_reduce_multi(const cgnn_dw_jobs* jobs, void* stream) {
     if (!jobs->dw_slab[i] || !jobs->db_slab[i] || !jobs->dW[i] || !jobs->db[i] || jobs->rows[i] <= 0 ||
         jobs->out_cols[i] <= 0 || jobs->take_cols[i] <= 0 || jobs->take_cols[i] > jobs->out_cols[i])
       return CGNN_EINVAL;
-    total += (HID * jobs->out_cols[i] + HID + 3) / 4;
+    total += (HID * jobs->out_cols[i] + HID) / RD_C;
   }
-  k_dw_db_reduce_multi<<<total, 256, 0, cgnn_stream(stream)>>>(*jobs);
+  k_dw_db_reduce_multi<<<total, RD_C * RD_G, 0, cgnn_stream(stream)>>>(*jobs);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }
