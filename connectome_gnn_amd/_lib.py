@@ -119,7 +119,7 @@ PROTOTYPES = {
     "cgnn_bn_bwd_stats_finalize": (c_int, [P, I32, F64, I32, P, P, P, P]),
     "cgnn_dw_db_reduce": (c_int, [P, P, I32, I32, I32, P, I32, P, P]),
     "cgnn_dw_db_reduce_multi": (c_int, [ctypes.POINTER(CgnnDwJobs), P]),
-    "cgnn_l0_grid": (c_int, []),
+    "cgnn_l0_grid": (c_int, [c_int64]),
     "cgnn_gcn_l0_fwd": (c_int, [TP, P, I32, P, P, P, P, P, P]),
     "cgnn_gcn_l0_bwd": (c_int, [P, P, LP, P, P, P, I64, P, P, P]),
     "cgnn_slab_reduce_f32": (c_int, [P, I32, I32, I32, I32, P, I32, P]),

@@ -227,13 +227,18 @@ __global__ void __launch_bounds__(L0BTHR) k_l0_bwd(const float* __restrict__ dZ,
 #ifndef CGNN_L0_GRID_MULT
 #define CGNN_L0_GRID_MULT 8
 #endif
-int l0_grid() { return CGNN_L0_GRID_MULT * cgnn_fused_grid(); }     // workgroups (= slab rows) of both kernels
+// workgroups (= slab rows) of both kernels for a batch of `nn` nodes: one per 256 nodes, between
+// one and CGNN_L0_GRID_MULT per CU (a small batch leaves fewer slab rows to fold afterwards)
+int l0_grid(int64_t nn) {
+  const int64_t cus = cgnn_fused_grid(), want = (nn + 255) / 256;
+  return (int)(want < cus ? cus : (want > CGNN_L0_GRID_MULT * cus ? CGNN_L0_GRID_MULT * cus : want));
+}
 
 }  // namespace
 
 extern "C" {
 
-int cgnn_l0_grid(void) { return l0_grid(); }
+int cgnn_l0_grid(int64_t num_nodes) { return num_nodes < 0 ? CGNN_EINVAL : l0_grid(num_nodes); }
 
 int cgnn_gcn_l0_fwd(const cgnn_tiles* t, const float* X0, int32_t F0, const float* W0,
                     const float* bias, float* P0, float* Y, double* stat_slab, void* stream) {
@@ -242,7 +247,7 @@ int cgnn_gcn_l0_fwd(const cgnn_tiles* t, const float* X0, int32_t F0, const floa
   if (!X0 || !W0 || !bias || !P0 || !t->tile_ptr || !t->tile_blk || !t->blk_off_dst ||
       !t->ent_dst || !t->dis)
     return CGNN_EINVAL;
-  k_l0_fwd<<<l0_grid(), L0THR, 0, cgnn_stream(stream)>>>(*t, X0, F0, W0, bias, P0, Y, stat_slab);
+  k_l0_fwd<<<l0_grid(t->num_nodes), L0THR, 0, cgnn_stream(stream)>>>(*t, X0, F0, W0, bias, P0, Y, stat_slab);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }
@@ -253,10 +258,10 @@ int cgnn_gcn_l0_bwd(const float* dZ, const float* Y, const cgnn_l0src* l0, const
   if (num_nodes < 0 || !dZ || !bn || !bwc || !P0 || !dW_slab || !db_slab) return CGNN_EINVAL;
   if (!Y && !(l0 && l0->W0 && l0->b0 && l0->F0 >= 1 && l0->F0 <= FP)) return CGNN_EINVAL;
   if (Y)
-    k_l0_bwd<false><<<l0_grid(), L0BTHR, 0, cgnn_stream(stream)>>>(dZ, Y, cgnn_l0src{}, bn, bwc, P0,
+    k_l0_bwd<false><<<l0_grid(num_nodes), L0BTHR, 0, cgnn_stream(stream)>>>(dZ, Y, cgnn_l0src{}, bn, bwc, P0,
                                                                    num_nodes, dW_slab, db_slab);
   else
-    k_l0_bwd<true><<<l0_grid(), L0BTHR, 0, cgnn_stream(stream)>>>(dZ, nullptr, *l0, bn, bwc, P0,
+    k_l0_bwd<true><<<l0_grid(num_nodes), L0BTHR, 0, cgnn_stream(stream)>>>(dZ, nullptr, *l0, bn, bwc, P0,
                                                                   num_nodes, dW_slab, db_slab);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;

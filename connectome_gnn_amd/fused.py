@@ -114,7 +114,7 @@ class FusedGCNEncode(torch.autograd.Function):
                     p0 = torch.empty(nn_, 8, **f32)
                     l0src = _lib.CgnnL0Src(_lib.ptr(p0), _lib.ptr(w), _lib.ptr(b), int(x0.shape[1]))
                     l0keep = (w, b)                     # the struct holds raw pointers
-                    slab_rows = lib.cgnn_l0_grid()
+                    slab_rows = lib.cgnn_l0_grid(nn_)
                     slab = torch.empty(slab_rows, 128, dtype=torch.float64, device=dev) if training else None
                     with _lib.timed("cgnn_gcn_l0_fwd"):
                         _lib.check(lib.cgnn_gcn_l0_fwd(
@@ -268,7 +268,7 @@ class FusedGCNEncode(torch.autograd.Function):
             dw0, db0 = torch.empty(HID, c.f0, **f32), torch.empty(HID, **f32)
             if c.p0 is not None:
                 # dW0 = dY0^T P0, db0 = sum dY0: streaming, no aggregation (fused_gcn_l0.hip)
-                g0 = lib.cgnn_l0_grid()
+                g0 = lib.cgnn_l0_grid(nn_)
                 dw_slab0 = torch.empty(g0, HID * 8, **f32)
                 db_slab0 = torch.empty(g0, HID, **f64)
                 with _lib.timed("cgnn_gcn_l0_bwd"):

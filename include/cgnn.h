@@ -379,10 +379,10 @@ int cgnn_gcn_fused_bwd_first(const cgnn_tiles* t, const float* dZ, const float* 
 
 /* Layer 0, narrow form (F0 <= 8): Y0 = (A_hat X0) W0^T + b with P0 = A_hat X0 kept for backward
  * ([Nn,8] fp32, columns >= F0 zero); dW0 = dY0^T P0, db0 = sum dY0 need no aggregation.
- * Slabs have cgnn_l0_grid() rows: stat_slab [..][128] fp64, dW_slab [..][64*8] f32,
+ * Slabs have cgnn_l0_grid(num_nodes) rows: stat_slab [..][128] fp64, dW_slab [..][64*8] f32,
  * db_slab [..][64] fp64.  (cgnn_gcn_fused_fwd_first/bwd_first remain for 8 < F0 <= 16 and for
  * one-layer models.) */
-int cgnn_l0_grid(void);
+int cgnn_l0_grid(int64_t num_nodes);
 /* Y (forward) may be NULL: only P0 and the statistics are produced and every consumer rebuilds
  * Y0's rows from a cgnn_l0src.  Backward: Y == NULL -> rebuilt from P0 with l0->W0/b0/F0. */
 int cgnn_gcn_l0_fwd(const cgnn_tiles* t, const float* X0, int32_t F0, const float* W0,
