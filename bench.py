@@ -293,7 +293,7 @@ def main() -> None:
         else:
             opt.zero_grad(set_to_none=True)
         loss = loss_fn(model(b), b.labels)
-        loss.backward()
+        cops.backward_unit(loss)
         if sync is not None:
             sync(local_graphs=local_graphs)
         opt.step()

@@ -116,6 +116,8 @@ PROTOTYPES = {
     "cgnn_gcn_fused_bwd": (c_int, [TP, P, P, P, P, P, LP, P, F32, P, P, P, P, P, P, P, P, P, P, P]),
     "cgnn_gcn_fused_bwd_first": (c_int, [TP, P, P, P, P, P, I32, P, P, F32, P, P, P, P, P]),
     "cgnn_bn_stats_finalize": (c_int, [P, I32, F64, P, P, P, P, F32, F32, P, P, P]),
+    "cgnn_bn_stats_finalize_rng": (c_int, [P, I32, F64, P, P, P, P, F32, F32, P, P, P, I32, P]),
+    "cgnn_gcn_fused_pool_bwd_finalize": (c_int, [P, P, P, P, I32, F64, I32, P, P, P, P]),
     "cgnn_bn_bwd_stats_finalize": (c_int, [P, I32, F64, I32, P, P, P, P]),
     "cgnn_dw_db_reduce": (c_int, [P, P, I32, I32, I32, P, I32, P, P]),
     "cgnn_dw_db_reduce_multi": (c_int, [ctypes.POINTER(CgnnDwJobs), P]),

@@ -1068,6 +1068,36 @@ __global__ void __launch_bounds__(128) k_pool_bwd_sums(const float* __restrict__
   s_slab[(int64_t)blockIdx.x * 128 + threadIdx.x] = acc;
 }
 
+// The same sums folded over ALL graphs by one block per channel, finalised on the spot (per-rank
+// BatchNorm: no exchange between the sums and the coefficients) -- k_pool_bwd_sums +
+// k_bn_bwd_stats in one launch.
+__device__ __forceinline__ double block_sum256(double v, double* sh);
+__global__ void __launch_bounds__(256) k_pool_bwd_finalize(const float* __restrict__ dP,
+                                                           const float* __restrict__ F1,
+                                                           const float* __restrict__ F2,
+                                                           const int32_t* __restrict__ gptr, int B,
+                                                           double count, int zero_coef,
+                                                           float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta,
+                                                           float* __restrict__ bwc) {
+  __shared__ double sh[4];
+  const int c = blockIdx.x;
+  double a1 = 0.0, a2 = 0.0;
+  for (int g = threadIdx.x; g < B; g += 256) {
+    const float inv = 1.0f / ((float)(gptr[g + 1] - gptr[g]) + 1e-8f);
+    const double d = (double)(dP[(int64_t)g * HID + c] * inv);
+    a1 += d * (double)F1[(int64_t)g * HID + c];
+    a2 += d * (double)F2[(int64_t)g * HID + c];
+  }
+  const double S1 = block_sum256(a1, sh), S2 = block_sum256(a2, sh);
+  if (threadIdx.x == 0) {
+    dbeta[c] = (float)S1;
+    dgamma[c] = (float)S2;
+    bwc[c] = zero_coef ? 0.f : (float)(S1 / count);
+    bwc[HID + c] = zero_coef ? 0.f : (float)(S2 / count);
+  }
+}
+
 constexpr int PBTHR = 1024;  // readout backward: 64 row-lanes x 16 chunks (16 waves per CU)
 
 __global__ void __launch_bounds__(PBTHR) k_pool_bwd(const float* __restrict__ dP,
@@ -1213,9 +1243,14 @@ __device__ __forceinline__ double block_sum256(double v, double* sh) {
 __global__ void __launch_bounds__(256) k_bn_fwd_stats(
     const double* __restrict__ slab, int rows, double count, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
-    float momentum, float eps, long long* __restrict__ tracked, float* __restrict__ bn_out) {
+    float momentum, float eps, long long* __restrict__ tracked, float* __restrict__ bn_out,
+    uint32_t* __restrict__ rng_state, int rng_n) {
   __shared__ double sh[4];
   const int c = blockIdx.x;
+  // graph replay: refresh the device dropout words here (cgnn_rng_advance's arithmetic) -- this
+  // launch runs after every consumer of the previous step's words and before the first of this one
+  if (rng_state && c == 0 && (int)threadIdx.x < rng_n)
+    rng_state[threadIdx.x] = mix32(rng_state[threadIdx.x] + 0x9E3779B9u * (uint32_t)(threadIdx.x + 1));
   double a1 = 0.0, a2 = 0.0;
   for (int r = threadIdx.x; r < rows; r += 256) {
     a1 += slab[(int64_t)r * 128 + c];
@@ -1581,7 +1616,33 @@ int cgnn_bn_stats_finalize(const double* slab, int32_t rows, double count, const
     return CGNN_EINVAL;
   k_bn_fwd_stats<<<HID, 256, 0, cgnn_stream(stream)>>>(
       slab, rows, count, gamma, beta, running_mean, running_var, momentum, eps,
-      reinterpret_cast<long long*>(num_batches_tracked), bn_out);
+      reinterpret_cast<long long*>(num_batches_tracked), bn_out, nullptr, 0);
+  CGNN_CHECK_LAUNCH();
+  return CGNN_OK;
+}
+
+int cgnn_bn_stats_finalize_rng(const double* slab, int32_t rows, double count, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var,
+                               float momentum, float eps, int64_t* num_batches_tracked, float* bn_out,
+                               uint32_t* rng_state, int32_t rng_n, void* stream) {
+  if (!slab || rows <= 0 || count <= 0.0 || !gamma || !beta || !running_mean || !running_var || !bn_out)
+    return CGNN_EINVAL;
+  if (rng_n < 0 || rng_n > 64 || (rng_n > 0 && !rng_state)) return CGNN_EINVAL;
+  k_bn_fwd_stats<<<HID, 256, 0, cgnn_stream(stream)>>>(
+      slab, rows, count, gamma, beta, running_mean, running_var, momentum, eps,
+      reinterpret_cast<long long*>(num_batches_tracked), bn_out, rng_state, rng_n);
+  CGNN_CHECK_LAUNCH();
+  return CGNN_OK;
+}
+
+int cgnn_gcn_fused_pool_bwd_finalize(const float* dP, const float* F1, const float* F2,
+                                     const int32_t* gptr, int32_t num_graphs, double count,
+                                     int32_t zero_coef, float* dgamma, float* dbeta, float* bwc,
+                                     void* stream) {
+  if (num_graphs < 0 || count <= 0.0 || !dP || !F1 || !F2 || !gptr || !dgamma || !dbeta || !bwc)
+    return CGNN_EINVAL;
+  k_pool_bwd_finalize<<<HID, 256, 0, cgnn_stream(stream)>>>(dP, F1, F2, gptr, num_graphs, count, zero_coef,
+                                                           dgamma, dbeta, bwc);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }

@@ -99,8 +99,11 @@ class FusedGCNEncode(torch.autograd.Function):
         def rng_ptr(i: int):
             return None if rng is None or p <= 0 else rng.data_ptr() + 4 * i
 
+        # graph replay: the device dropout words are refreshed once per step -- inside layer 0's
+        # BatchNorm finalisation when that is the single-launch form, else by a launch of its own
+        rng_in_finalize = rng is not None and p > 0 and training and sync_group is None
         with _lib.device_guard(dev):
-            if rng is not None and p > 0:
+            if rng is not None and p > 0 and not rng_in_finalize:
                 _lib.check(lib.cgnn_rng_advance(_lib.ptr(rng), L + 1, st()), "cgnn_rng_advance")
             for l in range(L):
                 w, b, gamma, beta = (t.contiguous() for t in params[4 * l:4 * l + 4])
@@ -140,12 +143,14 @@ class FusedGCNEncode(torch.autograd.Function):
                 cnt = count
                 if training and sync_group is None:
                     # one launch: reduce partials, finalise, update running stats and the counter
-                    _lib.check(lib.cgnn_bn_stats_finalize(
+                    adv = rng_in_finalize and l == 0
+                    _lib.check(lib.cgnn_bn_stats_finalize_rng(
                         _lib.ptr(slab), slab_rows, cnt, _lib.ptr(gamma), _lib.ptr(beta),
                         _lib.ptr(bn_mod.running_mean), _lib.ptr(bn_mod.running_var),
                         float(bn_mod.momentum), float(bn_mod.eps),
-                        _lib.ptr(bn_mod.num_batches_tracked), _lib.ptr(bn), st()),
-                        "cgnn_bn_stats_finalize")
+                        _lib.ptr(bn_mod.num_batches_tracked), _lib.ptr(bn),
+                        _lib.ptr(rng) if adv else None, L + 1 if adv else 0, st()),
+                        "cgnn_bn_stats_finalize_rng")
                 else:
                     cnt_dev = None
                     if training:
@@ -238,16 +243,25 @@ class FusedGCNEncode(torch.autograd.Function):
         pool_args = (_lib.ptr(d_pooled), _lib.ptr(s.node_graph), _lib.ptr(s.gptr), _lib.ptr(c.masks[-1]))
         none_args = (None, None, None, None)
         with _lib.device_guard(dev):
-            if c.fsum is not None:
-                _lib.check(lib.cgnn_gcn_fused_pool_bwd_sums(
+            if c.fsum is not None and c.sync_group is None:
+                # per-rank BatchNorm: the sums over all graphs and the coefficients in one launch
+                dgamma, dbeta, bwc = torch.empty(HID, **f32), torch.empty(HID, **f32), torch.empty(2 * HID, **f32)
+                _lib.check(lib.cgnn_gcn_fused_pool_bwd_finalize(
                     _lib.ptr(d_pooled), _lib.ptr(c.fsum), c.fsum.data_ptr() + 4 * B * HID, _lib.ptr(s.gptr), B,
-                    _lib.ptr(s_slab), st()), "cgnn_gcn_fused_pool_bwd_sums")
+                    c.count, int(not c.training), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(bwc), st()),
+                    "cgnn_gcn_fused_pool_bwd_finalize")
+                grads[4 * (L - 1) + 2], grads[4 * (L - 1) + 3] = dgamma, dbeta
             else:
-                _lib.check(lib.cgnn_gcn_fused_pool_bwd(
-                    _lib.ptr(d_pooled), _lib.ptr(c.ys[-1]), _lib.ptr(c.bns[-1]), c.p,
-                    _lib.ptr(c.masks[-1]), _lib.ptr(s.gptr), B, None, _lib.ptr(s_slab), st()),
-                    "cgnn_gcn_fused_pool_bwd")
-            bwc = bn_backward(L - 1)
+                if c.fsum is not None:
+                    _lib.check(lib.cgnn_gcn_fused_pool_bwd_sums(
+                        _lib.ptr(d_pooled), _lib.ptr(c.fsum), c.fsum.data_ptr() + 4 * B * HID, _lib.ptr(s.gptr), B,
+                        _lib.ptr(s_slab), st()), "cgnn_gcn_fused_pool_bwd_sums")
+                else:
+                    _lib.check(lib.cgnn_gcn_fused_pool_bwd(
+                        _lib.ptr(d_pooled), _lib.ptr(c.ys[-1]), _lib.ptr(c.bns[-1]), c.p,
+                        _lib.ptr(c.masks[-1]), _lib.ptr(s.gptr), B, None, _lib.ptr(s_slab), st()),
+                        "cgnn_gcn_fused_pool_bwd")
+                bwc = bn_backward(L - 1)
             for l in range(L - 1, 0, -1):
                 w = params[4 * l].contiguous()
                 extra = pool_args if l == L - 1 else none_args

@@ -35,6 +35,8 @@ from typing import Callable, Optional
 
 import torch
 
+from . import ops
+
 
 class GraphedTrainStep:
     """``step = GraphedTrainStep(model, optimizer, batch); loss = step()`` replays the captured
@@ -103,7 +105,7 @@ class GraphedTrainStep:
     def _fwd_bwd(self) -> torch.Tensor:
         self._zero()
         loss = self.loss_fn(self.model(self.batch), self.batch.labels)
-        loss.backward()
+        ops.backward_unit(loss)
         return loss.detach()
 
     def _exchange(self) -> None:

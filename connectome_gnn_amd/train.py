@@ -135,7 +135,7 @@ class Trainer:
         else:
             self.optimizer.zero_grad()
         loss = self.loss_fn(self.model(batch), batch.labels)
-        loss.backward()
+        ops.backward_unit(loss)
         if isinstance(self.grad_sync, cdist.GradSync):
             self.grad_sync(local_graphs=batch.num_graphs)     # exact with unequal shards
         elif self.grad_sync is not None:

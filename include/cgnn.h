@@ -344,6 +344,13 @@ int cgnn_gcn_fused_pool_fwd(const float* Y, const float* bn, float p_drop, uint6
 int cgnn_gcn_fused_pool_bwd_sums(const float* dP, const float* F1, const float* F2,
                                  const int32_t* gptr, int32_t num_graphs, double* s_slab,
                                  void* stream);
+/* (cgnn_gcn_fused_pool_bwd_sums + cgnn_bn_bwd_stats_finalize) in one launch: dgamma/dbeta [64] and
+ * the c1|c2 block bwc [128] of the last layer, for per-rank BatchNorm statistics (no exchange
+ * between the sums and the coefficients).  count = rows of the batch. */
+int cgnn_gcn_fused_pool_bwd_finalize(const float* dP, const float* F1, const float* F2,
+                                     const int32_t* gptr, int32_t num_graphs, double count,
+                                     int32_t zero_coef, float* dgamma, float* dbeta, float* bwc,
+                                     void* stream);
 
 /* Backward of the readout through dropout/ReLU: dZ = dP[g]/(n_g+1e-8) * drop' * relu';
  * also the BatchNorm-backward sums of the last layer: s_slab [grid][128] = sum dZ | sum dZ*xhat.
@@ -420,6 +427,12 @@ int cgnn_bn_stats_finalize(const double* slab, int32_t rows, double count, const
                            const float* beta, float* running_mean, float* running_var,
                            float momentum, float eps, int64_t* num_batches_tracked, float* bn_out,
                            void* stream);
+/* the same, also refreshing the rng_n (<= 64) device dropout words of a graph-captured step
+ * (cgnn_rng_advance's arithmetic) in the same launch; rng_state NULL / rng_n 0: no refresh */
+int cgnn_bn_stats_finalize_rng(const double* slab, int32_t rows, double count, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var,
+                               float momentum, float eps, int64_t* num_batches_tracked, float* bn_out,
+                               uint32_t* rng_state, int32_t rng_n, void* stream);
 int cgnn_bn_bwd_stats_finalize(const double* slab, int32_t rows, double count, int32_t zero_coef,
                                float* dgamma, float* dbeta, float* bwc, void* stream);
 int cgnn_dw_db_reduce(const float* dw_slab, const double* db_slab, int32_t rows, int32_t out_cols,
