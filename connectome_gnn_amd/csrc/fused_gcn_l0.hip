@@ -29,7 +29,11 @@ constexpr int L0BTHR = 256;           // backward (streaming)
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
 
-__global__ void __launch_bounds__(L0THR, 5) k_l0_fwd(cgnn_tiles t, const float* __restrict__ X0, int F0,
+#ifndef CGNN_L0_MINW
+#define CGNN_L0_MINW 8
+#endif
+template <bool WRITE_Y>
+__global__ void __launch_bounds__(L0THR, WRITE_Y ? 5 : CGNN_L0_MINW) k_l0_fwd(cgnn_tiles t, const float* __restrict__ X0, int F0,
                                                   const float* __restrict__ W0,
                                                   const float* __restrict__ bias,
                                                   float* __restrict__ P0, float* __restrict__ Y,
@@ -42,8 +46,22 @@ __global__ void __launch_bounds__(L0THR, 5) k_l0_fwd(cgnn_tiles t, const float* 
   const uint2* ent = static_cast<const uint2*>(t.ent_dst);
   // W0^T in LDS: wl[k][col] = W0[col][k] (zero for k >= F0); occupancy matters more here than
   // 32 registers of weights (the row gather is hidden by many resident waves, not by ILP)
-  __shared__ __attribute__((aligned(16))) float wl[L0_LDS_FLOATS];
-  l0_stage(wl, cgnn_l0src{nullptr, W0, bias, F0}, L0THR);
+  __shared__ __attribute__((aligned(16))) float wl[WRITE_Y ? L0_LDS_FLOATS : 4];
+  if (WRITE_Y) l0_stage(wl, cgnn_l0src{nullptr, W0, bias, F0}, L0THR);
+  // WRITE_Y = false (the fused path: Y0 is never written): the BatchNorm sums of Y0 = P0 W0^T + b
+  // come from the second moments of P0 -- M[k][l] = sum_rows p_k p_l over the 9 "columns"
+  // (p_0..p_7, 1) -- accumulated on the matrix pipe (v_mfma_f32_16x16x4_f32, A = B = a 4-row
+  // slice of P0, an exact fmaf chain), flushed to fp64 after every tile, and turned into
+  // sum y / sum y^2 once per workgroup at the end.  No per-element VALU work, no W reads, 12
+  // registers: the kernel fits 64 VGPRs = 8 waves per SIMD (the Y0-rebuilding form below needs 89
+  // and was LDS-bound on its W reads: 158 -> see DESIGN 5).
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  // per-wave fp64 accumulators of the 9 x 9 moments live in LDS (4 KB): registers are what caps
+  // the occupancy of this kernel
+  constexpr int NM = FP + 1, NWV = L0THR / 64;
+  __shared__ double macc[WRITE_Y ? 1 : NWV * NM * NM];
+  if (!WRITE_Y)
+    for (int i = threadIdx.x; i < NWV * NM * NM; i += L0THR) macc[i] = 0.0;
   // per-thread partial sums stay fp32 (a thread sees <= ~16 rows per tile, a few tiles); the
   // cross-thread / cross-workgroup combination is fp64
   float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
@@ -54,19 +72,23 @@ __global__ void __launch_bounds__(L0THR, 5) k_l0_fwd(cgnn_tiles t, const float* 
     const int gb0 = t.tile_blk[tid];
     // 1. dis * X0 -> LDS (zero-padded to 8 columns)
     {
-      constexpr int NI = MAXR * FP / L0THR;            // 8 elements per thread, all loads first
-      float xv[NI], dvv[NI];
+      constexpr int NI = MAXR * FP / L0THR;            // 8 elements per thread
+      constexpr int NB = WRITE_Y ? NI : NI / 2;         // loads in flight (register budget)
 #pragma unroll
-      for (int u = 0; u < NI; ++u) {
-        const int idx = threadIdx.x + L0THR * u, r = idx >> 3, k = idx & 7;
-        xv[u] = dvv[u] = 0.f;
-        if (r < n && k < F0) {
-          xv[u] = X0[(int64_t)(base + r) * F0 + k];
-          dvv[u] = t.dis[base + r];
+      for (int u0 = 0; u0 < NI; u0 += NB) {
+        float xv[NB], dvv[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          const int idx = threadIdx.x + L0THR * (u0 + u), r = idx >> 3, k = idx & 7;
+          xv[u] = dvv[u] = 0.f;
+          if (r < n && k < F0) {
+            xv[u] = X0[(int64_t)(base + r) * F0 + k];
+            dvv[u] = t.dis[base + r];
+          }
         }
-      }
 #pragma unroll
-      for (int u = 0; u < NI; ++u) xs[threadIdx.x + L0THR * u] = xv[u] * dvv[u];
+        for (int u = 0; u < NB; ++u) xs[threadIdx.x + L0THR * (u0 + u)] = xv[u] * dvv[u];
+      }
     }
     __syncthreads();
     // 2. narrow aggregate, one thread per destination row (entries of 16 rows are contiguous)
@@ -77,7 +99,10 @@ __global__ void __launch_bounds__(L0THR, 5) k_l0_fwd(cgnn_tiles t, const float* 
       float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
       const uint2* e = ent + off0 + i;
       // entries stream from HBM: fetch EB steps at a time (independent loads), then consume
-      constexpr int EB = 6;
+#ifndef CGNN_L0_EB
+#define CGNN_L0_EB 2
+#endif
+      constexpr int EB = WRITE_Y ? 6 : CGNN_L0_EB;
       for (int s0 = 0; s0 < width; s0 += EB) {
         uint2 eb[EB];
 #pragma unroll
@@ -98,6 +123,29 @@ __global__ void __launch_bounds__(L0THR, 5) k_l0_fwd(cgnn_tiles t, const float* 
       st4(P0 + (int64_t)(base + r) * FP, a0); st4(P0 + (int64_t)(base + r) * FP + 4, a1);
     }
     __syncthreads();
+    if (!WRITE_Y) {
+      // 3. second moments of this tile's P0 rows: wave w takes the 16-row blocks w, w + 6, ...
+      if (stat_slab) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ci = lane & 15, kq = lane >> 4;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int rb = wave; 16 * rb < n; rb += L0THR / 64) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int row = 16 * rb + 4 * g + kq;
+            float v = 0.f;
+            if (row < n) v = ci < FP ? ps[row * FP + ci] : (ci == FP ? 1.f : 0.f);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v, v, acc, 0, 0, 0);
+          }
+        }
+        // lane (ci, kq) holds M[4*kq + r][ci], r = 0..3 (wave-private slots: plain read-add-write)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = 4 * kq + r;
+          if (m < NM && ci < NM) macc[(wave * NM + m) * NM + ci] += (double)acc[r];
+        }
+      }
+      continue;                                      // (the next tile's phase-1 barrier orders ps)
+    }
     // 3. Y0 = P0 W0^T + b: thread (row rr + 16*it, columns 4j..4j+3)
     // (two rows per pass share every W0^T read: this phase is LDS-bound)
     constexpr int RS = L0THR / 16;                   // 24 row lanes
@@ -109,12 +157,12 @@ __global__ void __launch_bounds__(L0THR, 5) k_l0_fwd(cgnn_tiles t, const float* 
       const float4 q1 = two ? ld4(ps + r2 * FP + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
       const float4 y = l0_rebuild4(p0, p1, wl, 4 * j, F0);
       const float4 z = l0_rebuild4(q0, q1, wl, 4 * j, F0);
-      if (Y) st4(Y + (int64_t)(base + r) * HID + 4 * j, y);
+      st4(Y + (int64_t)(base + r) * HID + 4 * j, y);
       s1[0] += y.x; s1[1] += y.y; s1[2] += y.z; s1[3] += y.w;
       s2[0] = fmaf(y.x, y.x, s2[0]); s2[1] = fmaf(y.y, y.y, s2[1]);
       s2[2] = fmaf(y.z, y.z, s2[2]); s2[3] = fmaf(y.w, y.w, s2[3]);
       if (two) {
-        if (Y) st4(Y + (int64_t)(base + r2) * HID + 4 * j, z);
+        st4(Y + (int64_t)(base + r2) * HID + 4 * j, z);
         s1[0] += z.x; s1[1] += z.y; s1[2] += z.z; s1[3] += z.w;
         s2[0] = fmaf(z.x, z.x, s2[0]); s2[1] = fmaf(z.y, z.y, s2[1]);
         s2[2] = fmaf(z.z, z.z, s2[2]); s2[3] = fmaf(z.w, z.w, s2[3]);
@@ -122,20 +170,53 @@ __global__ void __launch_bounds__(L0THR, 5) k_l0_fwd(cgnn_tiles t, const float* 
     }
     __syncthreads();
   }
-  if (stat_slab) {
-    __syncthreads();
+  if (!stat_slab) return;
+  __syncthreads();
+  if (!WRITE_Y) {
+    // moments -> sums: the waves' accumulators folded in fixed order, then
+    //   S1[c] = sum_k W[c][k] M[k][8] + M[8][8] b[c]
+    //   S2[c] = sum_kl W[c][k] W[c][l] M[k][l] + 2 b[c] sum_k W[c][k] M[k][8] + M[8][8] b[c]^2
+    if (threadIdx.x < NM * NM) {
+      double tsum = 0.0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      red[rr * 128 + 4 * j + i] = (double)s1[i];
-      red[rr * 128 + 64 + 4 * j + i] = (double)s2[i];
+      for (int w2 = 0; w2 < NWV; ++w2) tsum += macc[w2 * NM * NM + threadIdx.x];
+      red[threadIdx.x] = tsum;                       // M[k][l] at red[k * NM + l]
     }
     __syncthreads();
     if (threadIdx.x < 128) {
-      double tot = 0.0;
-#pragma unroll
-      for (int k = 0; k < L0THR / 16; ++k) tot += red[k * 128 + threadIdx.x];
-      stat_slab[(int64_t)blockIdx.x * 128 + threadIdx.x] = tot;
+      const int c = threadIdx.x & 63;
+      const double bc = (double)bias[c], cnt = red[FP * NM + FP];
+      const float* wc = W0 + c * F0;
+      double lin = 0.0;                              // sum_k W[c][k] M1[k]
+#pragma unroll 1
+      for (int k = 0; k < F0; ++k) lin += (double)wc[k] * red[k * NM + FP];
+      double out = lin + cnt * bc;
+      if (threadIdx.x >= 64) {
+        double quad = 0.0;
+#pragma unroll 1
+        for (int k = 0; k < F0; ++k) {
+          double rowsum = 0.0;
+#pragma unroll 1
+          for (int l = 0; l < F0; ++l) rowsum += (double)wc[l] * red[k * NM + l];
+          quad += (double)wc[k] * rowsum;
+        }
+        out = quad + 2.0 * bc * lin + cnt * bc * bc;
+      }
+      stat_slab[(int64_t)blockIdx.x * 128 + threadIdx.x] = out;
     }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    red[rr * 128 + 4 * j + i] = (double)s1[i];
+    red[rr * 128 + 64 + 4 * j + i] = (double)s2[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    double tot = 0.0;
+#pragma unroll
+    for (int k = 0; k < L0THR / 16; ++k) tot += red[k * 128 + threadIdx.x];
+    stat_slab[(int64_t)blockIdx.x * 128 + threadIdx.x] = tot;
   }
 }
 
@@ -247,7 +328,10 @@ int cgnn_gcn_l0_fwd(const cgnn_tiles* t, const float* X0, int32_t F0, const floa
   if (!X0 || !W0 || !bias || !P0 || !t->tile_ptr || !t->tile_blk || !t->blk_off_dst ||
       !t->ent_dst || !t->dis)
     return CGNN_EINVAL;
-  k_l0_fwd<<<l0_grid(t->num_nodes), L0THR, 0, cgnn_stream(stream)>>>(*t, X0, F0, W0, bias, P0, Y, stat_slab);
+  if (Y)
+    k_l0_fwd<true><<<l0_grid(t->num_nodes), L0THR, 0, cgnn_stream(stream)>>>(*t, X0, F0, W0, bias, P0, Y, stat_slab);
+  else
+    k_l0_fwd<false><<<l0_grid(t->num_nodes), L0THR, 0, cgnn_stream(stream)>>>(*t, X0, F0, W0, bias, P0, Y, stat_slab);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }
