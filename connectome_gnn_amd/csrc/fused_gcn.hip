@@ -468,16 +468,22 @@ __global__ void __launch_bounds__(PF_NTHR) k_gcn_fwd_pf(
   const uint4* ent = static_cast<const uint4*>(t.ent_dst);
   constexpr int BPW = (MAXR / 16 + PF_NW - 1) / PF_NW;        // blocks per wave and tile (2)
 
-  __shared__ __attribute__((aligned(16))) float wl0[FROM_P0 ? L0_LDS_FLOATS : 4];
+  // FROM_P0: rows of Y0 = P0 W0^T + b0 are rebuilt on the fp32 matrix pipe (l0src.h): D[col][row]
+  // puts columns 16c + 4q .. +3 of row j in lane (q, j), the layout phase A works in
+  __shared__ __attribute__((aligned(16))) float b0l[FROM_P0 ? HID : 4];
   stage_split_weight<false>(wsp, W, PF_NTHR);
   for (int i = threadIdx.x; i < 2 * HID; i += PF_NTHR) bnab[i] = bn_prev[i];
-  if (FROM_P0) l0_stage(wl0, l0, PF_NTHR);
+  L0W w0;
+  if (FROM_P0) {
+    w0 = l0w_cols(l0, lane);
+    for (int i = threadIdx.x; i < HID; i += PF_NTHR) b0l[i] = l0.b0[i];
+  }
   const float4 bias4 = ld4(bias + 4 * j);
   double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
 
   // operand rows of the NEXT tile: block u of this wave, row j, columns 16c + 4q .. +3
-  // (FROM_P0: the row's narrow aggregate, px[u][0..1])
-  constexpr int NPX = FROM_P0 ? 2 : 4;
+  // (FROM_P0: elements q and 4 + q of the row's narrow aggregate, in px[u][0].x / .y)
+  constexpr int NPX = FROM_P0 ? 1 : 4;
   float4 px[BPW][NPX];
   float pd[BPW];
   // block u of tile `tid`: issued right after the previous tile's block u has been consumed, so
@@ -490,9 +496,9 @@ __global__ void __launch_bounds__(PF_NTHR) k_gcn_fwd_pf(
     for (int c = 0; c < NPX; ++c) px[u][c] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row < nn2) {
       if (FROM_P0) {
-        const float* src = l0.P0 + (int64_t)(nb2 + row) * L0_FP;
-#pragma unroll
-        for (int c = 0; c < NPX; ++c) px[u][c] = ld4(src + 4 * c);
+        const float* src = l0.P0 + (int64_t)(nb2 + row) * L0_FP + q;
+        px[u][0].x = src[0];
+        px[u][0].y = src[4];
       } else {
         const float* src = Xin + (int64_t)(nb2 + row) * HID + 4 * q;
 #pragma unroll
@@ -549,8 +555,12 @@ __global__ void __launch_bounds__(PF_NTHR) k_gcn_fwd_pf(
           }
 #endif
           float4 f;
-          const float4 yraw = FROM_P0 ? l0_rebuild4(px[u][0], px[u][NPX > 1 ? 1 : 0], wl0, 16 * c + 4 * q, l0.F0)
-                                      : px[u][c < NPX ? c : 0];
+          float4 yraw = px[u][c < NPX ? c : 0];
+          if (FROM_P0) {
+            const float4 bq = ld4(b0l + 16 * c + 4 * q);
+            const l0_f32x4 y0 = l0_mfma(w0.a[c], w0.b[c], px[u][0].x, px[u][0].y, l0_f32x4{bq.x, bq.y, bq.z, bq.w});
+            yraw = make_float4(y0[0], y0[1], y0[2], y0[3]);
+          }
           xc[h2] = scale4(act4(yraw, ld4(bnab + 16 * c + 4 * q), ld4(bnab + HID + 16 * c + 4 * q),
                                keep, drop.scale, f), pd[u]);
         }
@@ -659,8 +669,13 @@ __global__ void __launch_bounds__(NW * 64) k_gcn_bwd(
   if (!FIRST) {
     for (int i = threadIdx.x; i < 4 * HID; i += (NW * 64)) bnl[i] = bn_prev[i];
   }
-  __shared__ __attribute__((aligned(16))) float wl0[XP0 ? L0_LDS_FLOATS : 4];
-  if (XP0) l0_stage(wl0, l0, (NW * 64));
+  // XP0: rows of Y0 rebuilt on the fp32 matrix pipe (l0src.h): D_t[row][col 4j + t]
+  L0W w0;
+  float4 b0q = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (XP0) {
+    w0 = l0w_quad(l0, threadIdx.x & 63);
+    b0q = ld4(l0.b0 + 4 * (threadIdx.x & 15));
+  }
   // dW accumulators: FIRST: dw[ti][0] only (16 input columns); else dw[ti][tj].
   f32x4 dw[4][FIRST ? 1 : 4];
 #pragma unroll
@@ -772,7 +787,7 @@ __global__ void __launch_bounds__(NW * 64) k_gcn_bwd(
     // --------------------- phase B: dT = A_hat^T dY per block; dW += dT^T X; dZprev = ...
     for (int b = wave; b < nblk; b += NW) {
       float4 yp[4];
-      float4 pr[XP0 ? 4 : 1][2];                // XP0: narrow aggregates of rows 4q+r
+      float p0a = 0.f, p0b = 0.f;               // XP0: P0[row 16b + j][q], [4 + q] (MFMA operand)
       uint32_t keeps = 0u;                      // byte r: keep bits of row 4q+r (0 = no such row)
       {
         int off1 = 0, width1 = 0;
@@ -793,19 +808,18 @@ __global__ void __launch_bounds__(NW * 64) k_gcn_bwd(
           for (int r = 0; r < 4; ++r) {
             const int row = 16 * b + 4 * q + r;
             yp[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (XP0) pr[XP0 ? r : 0][0] = pr[XP0 ? r : 0][1] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row < n) {
-                if (XP0) {
-                  pr[XP0 ? r : 0][0] = ld4(l0.P0 + (int64_t)(base + row) * L0_FP);
-                  pr[XP0 ? r : 0][1] = ld4(l0.P0 + (int64_t)(base + row) * L0_FP + 4);
-                } else {
-                  yp[r] = ld4(Xprev + (int64_t)(base + row) * HID + 4 * j);
-                }
+                if (!XP0) yp[r] = ld4(Xprev + (int64_t)(base + row) * HID + 4 * j);
                 uint32_t kb = 0xFu;
                 if (use_drop) kb = mask_prev[(int64_t)(base + row) * 16 + j];
                 keeps |= kb << (8 * r);
             }
           }
+        }
+        if (!FIRST && XP0 && 16 * b + j < n) {
+          const float* src = l0.P0 + (int64_t)(base + 16 * b + j) * L0_FP + q;
+          p0a = src[0];
+          p0b = src[4];
         }
         float4 ag[4];
 #ifdef BW_DIAG_SKIP_AGG
@@ -817,8 +831,14 @@ __global__ void __launch_bounds__(NW * 64) k_gcn_bwd(
         CGNN_STAMP(3)
         if (XP0) {
           // rows outside the tile rebuild to b0, harmless: their keep byte is 0 -> x = f = 0
+          l0_f32x4 yt[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) yp[r] = l0_rebuild4(pr[XP0 ? r : 0][0], pr[XP0 ? r : 0][1], wl0, 4 * j, l0.F0);
+          for (int tq = 0; tq < 4; ++tq) {
+            const float bt = tq == 0 ? b0q.x : tq == 1 ? b0q.y : tq == 2 ? b0q.z : b0q.w;
+            yt[tq] = l0_mfma(p0a, p0b, w0.a[tq], w0.b[tq], l0_f32x4{bt, bt, bt, bt});
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) yp[r] = make_float4(yt[0][r], yt[1][r], yt[2][r], yt[3][r]);
         }
 #pragma unroll
         for (int it = 0; it < 4; ++it)
