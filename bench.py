@@ -151,7 +151,8 @@ def end_to_end(C, ds, model, opt, bsz: int, epochs: int = 6) -> dict:
     # per-SUBJECT cache (structure_cache.py; one graph per tile, per-tile GCN path)
     n = int(big.x.shape[1])
     if 192 < n <= 384 and getattr(model, "_fused_kind", None) == "tile":
-        ld3 = ResidentDataLoader(big, batch_size=bsz, shuffle=True, structure_cache=True)
+        ld3 = ResidentDataLoader(big, batch_size=bsz, shuffle=True, structure_cache=True, prefetch=True,
+                                 prepare=model.prepare_batch)
         tr.train_epoch(ld3)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -161,7 +162,7 @@ def end_to_end(C, ds, model, opt, bsz: int, epochs: int = 6) -> dict:
         dt3 = time.perf_counter() - t0
         out["subject_cache"] = {"graphs_per_s": steps * bsz / dt3, "ms_per_step": dt3 / steps * 1e3,
                                 "what": "fresh shuffled batch every step; blocked-ELL / dis of every "
-                                        "subject built once, a batch's structure = three gathers"}
+                                        "subject built once, a batch's structure = three gathers on the side stream"}
     return out
 
 

@@ -95,9 +95,12 @@ class ResidentDataLoader:
     def __iter__(self):
         if self.structure_cache is not None and not self.cache_batches:
             from .structure_cache import ResidentBatch
-            for chunk in self._chunks():
-                yield ResidentBatch(self.structure_cache, chunk)
-            return
+
+            def build(chunk):                       # three gathers; the structure is the cache's
+                return ResidentBatch(self.structure_cache, chunk)
+        else:
+            def build(chunk):
+                return assemble_batch(self.dataset, chunk)
         if self.cache_batches:
             if self._cache is None:
                 self._cache = []
@@ -113,7 +116,7 @@ class ResidentDataLoader:
             return
         if not self.prefetch or self.dataset.x.device.type != "cuda":
             for chunk in self._chunks():
-                b = assemble_batch(self.dataset, chunk)
+                b = build(chunk)
                 if self.prepare is not None:
                     self.prepare(b)
                 yield b
@@ -130,7 +133,7 @@ class ResidentDataLoader:
             if after is not None:
                 side.wait_event(after)
             with torch.cuda.stream(side):
-                b = assemble_batch(self.dataset, chunk)
+                b = build(chunk)
                 b.structure()
                 if self.prepare is not None:
                     self.prepare(b)
