@@ -330,7 +330,9 @@ __global__ void __launch_bounds__(PTHR) k_bn_act_pool_fwd(
   for (int g = blockIdx.x; g < B; g += gridDim.x) {
     const int rbeg = gptr[g], rend = gptr[g + 1];
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    constexpr int U = 4;                             // rows in flight per thread
+    // rows in flight per thread: a block owns a whole graph, so with few graphs (64 x 1000-ROI)
+    // only that many CUs work and each is bound by its own load latency
+    constexpr int U = 8;
     for (int row0 = rbeg + rr; row0 < rend; row0 += U * rpp) {
       float4 yb[U];
 #pragma unroll

@@ -124,9 +124,11 @@ class GcnHalfEncode(torch.autograd.Function):
                     x0h = torch.zeros(n_nodes, P0_COLS, dtype=torch.float16, device=dev)
                     x0h[:, :f0] = x0
                     sv.p0 = ops.dense_aggregate_f16_raw(s, mf, x0h)        # [Nn, 64] half, cols >= F0 zero
-                    y = torch.addmm(b.half(), sv.p0[:, :f0], w.half().t())
+                    wh = w.half()
+                    y = torch.addmm(b.half(), sv.p0[:, :f0], wh.t())
                 else:
-                    t = torch.matmul(x, w.half().t())                      # half GEMM, fp32 accumulate
+                    wh = w.half()
+                    t = torch.matmul(x, wh.t())                            # half GEMM, fp32 accumulate
                     y = ops.dense_aggregate_f16_raw(s, mf, t, b)
                 slab = None
                 if training:
@@ -142,7 +144,7 @@ class GcnHalfEncode(torch.autograd.Function):
                     "cgnn_bn_act_finalize")
                 mask = torch.empty(n_nodes * (hid // 4), dtype=torch.uint8, device=dev) if p > 0 else None
                 seed = _lib.next_seed(dev) if p > 0 else 0
-                sv.xs.append(x); sv.ys.append(y); sv.coefs.append(coef); sv.masks.append(mask); sv.ws.append(w)
+                sv.xs.append(x); sv.ys.append(y); sv.coefs.append(coef); sv.masks.append(mask); sv.ws.append((w, wh))
                 if li == L - 1:
                     pooled = _f32(dev, B, hid)
                     _lib.check(lib.cgnn_bn_act_pool_fwd_f16(_lib.ptr(y), _lib.ptr(coef), 1, p, seed, None,
@@ -173,7 +175,7 @@ class GcnHalfEncode(torch.autograd.Function):
             rows = int(lib.cgnn_bn_act_slab_rows(n_nodes))
             dx = None                           # last layer: gradient rebuilt from dP inside the kernels
             for li in range(L - 1, -1, -1):
-                x, y, coef, mask, w = sv.xs[li], sv.ys[li], sv.coefs[li], sv.masks[li], sv.ws[li]
+                x, y, coef, mask, (w, wh) = sv.xs[li], sv.ys[li], sv.coefs[li], sv.masks[li], sv.ws[li]
                 hid = w.shape[0]
                 pool = (_lib.ptr(dP), _lib.ptr(s.node_graph), _lib.ptr(s.gptr)) if li == L - 1 else (None, None, None)
                 slab = torch.empty(rows, 2 * hid, dtype=torch.float64, device=dev)
@@ -200,7 +202,7 @@ class GcnHalfEncode(torch.autograd.Function):
                     break
                 dt = ops.dense_aggregate_f16_raw(s, sv.mb, dy)             # dT = A_hat^T dY
                 grads[4 * li:4 * li + 4] = [_weight_grad(dt, x), db, dgamma, dbeta]
-                dx = torch.matmul(dt, w.half())                            # dX = dT W
+                dx = torch.matmul(dt, wh)                                  # dX = dT W
         ctx.sv = None
         return (None, None, *grads)
 
