@@ -732,3 +732,60 @@ def test_cfg5_fp16_storage_gcn_vs_fp32_oracle(dropout):
     assert torch.equal(e1, e2) and torch.isfinite(e1).all()
     with pytest.raises(ValueError):
         C.GraphSAGEConnectome(5, 64, storage="fp16")
+
+
+@pytest.mark.parametrize("offset,scale", [(0.0, 1.0), (3.0, 1.0), (-2.0, 0.25)])
+def test_fused_gcn_layer0_moment_statistics_with_offset_features(offset, scale):
+    """Layer 0's BatchNorm sums come from the second moments of P0 = A_hat X0 (fused_gcn_l0.hip):
+    sum y^2 is a quadratic form of moments that cancel when the features sit far from zero.
+    Node features with a mean of several standard deviations must still give the oracle's
+    logits, loss, gradients and running statistics at the usual tolerances."""
+    import connectome_gnn_amd as C
+    graphs = C.generate_dataset(12, 360, 14, seed=5)
+    b = C.collate_graphs(graphs)
+    b.node_features = b.node_features * scale + offset
+    torch.manual_seed(11)
+    m = _model("gcn", 5, 64, dropout=0.0)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    lo, loss_o, g32, stats_o = P.oracle_run("gcn", sd0, b)
+    _, _, g64, _ = P.oracle_run("gcn", sd0, b, dtype=torch.float64)
+    m = m.to(DEV).train()
+    bd = b.to(DEV)
+    lg = m(bd)
+    assert m.impl_used == "fused"
+    loss_g = torch.nn.functional.cross_entropy(lg, bd.labels)
+    loss_g.backward()
+    torch.testing.assert_close(lg.cpu(), lo, **TOL)
+    torch.testing.assert_close(loss_g.cpu(), loss_o, **TOL)
+    floor = P.NoiseFloor("gcn", sd0, b)
+    for k_, p in m.named_parameters():
+        P.assert_grad(k_, p.grad, g32[k_], g64[k_], f"offset{offset}", floor)
+    sd = m.state_dict()
+    for k_, v in stats_o.items():
+        torch.testing.assert_close(sd[k_].cpu(), v, rtol=2e-5, atol=1e-6, msg=lambda s: f"{k_}: {s}")
+
+
+def test_backward_unit_equals_backward():
+    """ops.backward_unit (cached unit root gradient, no multiply in cross_entropy's backward) gives
+    bit-identical gradients to loss.backward()."""
+    import connectome_gnn_amd as C
+    from connectome_gnn_amd import ops
+    b = C.collate_graphs(C.generate_dataset(16, 84, 8, seed=9)).to(DEV)
+    grads = []
+    for unit in (False, True):
+        torch.manual_seed(3)
+        m = _model("gcn", 5, 64, dropout=0.3).to(DEV).train()
+        torch.manual_seed(4)
+        loss = ops.cross_entropy(m(b), b.labels)
+        assert loss.dim() == 0
+        (ops.backward_unit if unit else torch.Tensor.backward)(loss)
+        grads.append([p.grad.clone() for p in m.parameters()])
+    for a, c in zip(*grads):
+        assert torch.equal(a, c)
+    # a non-unit root gradient still scales
+    torch.manual_seed(3)
+    m = _model("gcn", 5, 64, dropout=0.3).to(DEV).train()
+    torch.manual_seed(4)
+    (2.0 * ops.cross_entropy(m(b), b.labels)).backward()
+    for a, p in zip(grads[0], m.parameters()):
+        torch.testing.assert_close(p.grad, 2.0 * a, rtol=1e-6, atol=1e-9)
