@@ -79,14 +79,18 @@ class GraphedTrainStep:
         self._zero()
         self.graph = torch.cuda.CUDAGraph()
         self.graph_tail = None
+        # with a process group alive, its watchdog thread polls events while we capture: only THIS
+        # thread's calls are part of the capture
+        import torch.distributed as dist
+        mode = {"capture_error_mode": "thread_local"} if dist.is_available() and dist.is_initialized() else {}
         if split:
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, **mode):
                 self.loss = self._fwd_bwd()
             self.graph_tail = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_tail, pool=self.graph.pool()):
+            with torch.cuda.graph(self.graph_tail, pool=self.graph.pool(), **mode):
                 self.optimizer.step()
         else:
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, **mode):
                 self.loss = self._fwd_bwd()
                 self._exchange()
                 self.optimizer.step()
