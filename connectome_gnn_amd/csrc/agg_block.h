@@ -41,6 +41,13 @@ __device__ __forceinline__ float4 ldsrow(const char* tb, uint32_t off) {
 // only LDS traffic is the neighbour rows themselves and every row-read address is available
 // without a memory round trip.  Steps >= 32 (very high degree) come from global memory.
 struct MetaRegs { uint4 a0, a1, b0, b1; };
+// blocked-ELL entries: default cache policy.  They are read once per LAUNCH but by several launches
+// of a step (212 MB, within reach of the 256 MB MALL): non-temporal loads cost the forward kernel 9 us
+#ifdef CGNN_META_NT
+#define CGNN_META_LD(p) ldnt(p)
+#else
+#define CGNN_META_LD(p) (*(p))
+#endif
 
 // AHEAD2: also prefetch batch 1 a block ahead (8 more live VGPRs); otherwise batch 1 is
 // requested at the start of its own block's aggregation and lands while batch 0 is processed.
@@ -48,8 +55,11 @@ template <bool AHEAD2>
 __device__ __forceinline__ MetaRegs meta_issue(const uint4* __restrict__ mp, int width, int q, int j) {
   const uint4 z = make_uint4(0u, 0u, 0u, 0u);
   MetaRegs m{z, z, z, z};
-  if (j < width) { m.a0 = mp[8 * j + 2 * q]; m.a1 = mp[8 * j + 2 * q + 1]; }
-  if (AHEAD2 && 16 + j < width) { m.b0 = mp[8 * (16 + j) + 2 * q]; m.b1 = mp[8 * (16 + j) + 2 * q + 1]; }
+  if (j < width) { m.a0 = CGNN_META_LD(mp + 8 * j + 2 * q); m.a1 = CGNN_META_LD(mp + 8 * j + 2 * q + 1); }
+  if (AHEAD2 && 16 + j < width) {
+    m.b0 = CGNN_META_LD(mp + 8 * (16 + j) + 2 * q);
+    m.b1 = CGNN_META_LD(mp + 8 * (16 + j) + 2 * q + 1);
+  }
   return m;
 }
 
@@ -98,7 +108,10 @@ __device__ __forceinline__ void agg_block(const float* __restrict__ tile, MetaRe
                                           const uint4* __restrict__ mp, int width, int q, int j,
                                           float4 (&acc)[4]) {
   const char* tb = reinterpret_cast<const char*>(tile) + 16 * j;
-  if (!AHEAD2 && 16 + j < width) { m.b0 = mp[8 * (16 + j) + 2 * q]; m.b1 = mp[8 * (16 + j) + 2 * q + 1]; }
+  if (!AHEAD2 && 16 + j < width) {
+    m.b0 = CGNN_META_LD(mp + 8 * (16 + j) + 2 * q);
+    m.b1 = CGNN_META_LD(mp + 8 * (16 + j) + 2 * q + 1);
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (G == 1) {

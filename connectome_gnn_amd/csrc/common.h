@@ -37,3 +37,27 @@ __device__ __forceinline__ double cgnn_wave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+
+// Streamed data -- arrays a kernel reads or writes exactly once -- goes through non-temporal
+// accesses: they do not allocate in the cache hierarchy the way default loads/stores do, and a
+// streaming pass over 0.4 GB ran 24 % faster with them (k_pool_fwd 98 -> 74 us).  NOT for data
+// that is re-read (tiles staged in LDS are fine: they are read from HBM once).
+typedef float cgnn_f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t cgnn_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t cgnn_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 ldnt4(const float* p) {
+  const cgnn_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const cgnn_f32x4*>(p));
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void stnt4(float* p, const float4& v) {
+  __builtin_nontemporal_store(cgnn_f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<cgnn_f32x4*>(p));
+}
+__device__ __forceinline__ float ldnt(const float* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ uint4 ldnt(const uint4* p) {
+  const cgnn_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const cgnn_u32x4*>(p));
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ uint2 ldnt(const uint2* p) {
+  const cgnn_u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const cgnn_u32x2*>(p));
+  return make_uint2(v[0], v[1]);
+}

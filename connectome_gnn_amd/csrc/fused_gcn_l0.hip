@@ -27,6 +27,15 @@ constexpr int L0THR = 384;            // forward: one thread per row of a <=384-
 constexpr int L0BTHR = 256;           // backward (streaming)
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+#ifdef L0_NO_NT
+#define L0NT ld4
+#define L0NTE(p) (*(p))
+#define L0STNT st4
+#else
+#define L0NT ldnt4
+#define L0NTE(p) ldnt(p)
+#define L0STNT stnt4
+#endif
 __device__ __forceinline__ void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
 
 #ifndef CGNN_L0_MINW
@@ -106,7 +115,7 @@ __global__ void __launch_bounds__(L0THR, WRITE_Y ? 5 : CGNN_L0_MINW) k_l0_fwd(cg
       for (int s0 = 0; s0 < width; s0 += EB) {
         uint2 eb[EB];
 #pragma unroll
-        for (int u = 0; u < EB; ++u) eb[u] = s0 + u < width ? e[16 * (s0 + u)] : make_uint2(0u, 0u);
+        for (int u = 0; u < EB; ++u) eb[u] = s0 + u < width ? L0NTE(e + 16 * (s0 + u)) : make_uint2(0u, 0u);
 #pragma unroll
         for (int u = 0; u < EB; ++u) {
           const float w = __uint_as_float(eb[u].y);          // padding: weight 0, row 0
@@ -120,7 +129,7 @@ __global__ void __launch_bounds__(L0THR, WRITE_Y ? 5 : CGNN_L0_MINW) k_l0_fwd(cg
       a0 = make_float4(a0.x * dv, a0.y * dv, a0.z * dv, a0.w * dv);
       a1 = make_float4(a1.x * dv, a1.y * dv, a1.z * dv, a1.w * dv);
       st4(ps + r * FP, a0); st4(ps + r * FP + 4, a1);
-      st4(P0 + (int64_t)(base + r) * FP, a0); st4(P0 + (int64_t)(base + r) * FP + 4, a1);
+      L0STNT(P0 + (int64_t)(base + r) * FP, a0); L0STNT(P0 + (int64_t)(base + r) * FP + 4, a1);
     }
     __syncthreads();
     if (!WRITE_Y) {
@@ -257,10 +266,10 @@ __global__ void __launch_bounds__(L0BTHR) k_l0_bwd(const float* __restrict__ dZ,
       const int64_t row = row0 + stride * u;
       zb[u] = yb[u] = pa[u] = pb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row < nn) {
-        zb[u] = ld4(dZ + row * HID + 4 * j);
+        zb[u] = L0NT(dZ + row * HID + 4 * j);
         if (!REBUILD) yb[u] = ld4(Y + row * HID + 4 * j);
-        pa[u] = ld4(P0 + row * FP);
-        pb[u] = ld4(P0 + row * FP + 4);
+        pa[u] = L0NT(P0 + row * FP);
+        pb[u] = L0NT(P0 + row * FP + 4);
       }
     }
 #pragma unroll

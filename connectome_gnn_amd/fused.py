@@ -175,10 +175,11 @@ class FusedGCNEncode(torch.autograd.Function):
             # per-graph factor sums: the readout backward needs no second pass over Y
             want_grad = any(ctx.needs_input_grad[2:])
             fsum = torch.empty(2, B, HID, **f32) if want_grad else None
-            _lib.check(lib.cgnn_gcn_fused_pool_fwd(
-                _lib.ptr(ys[-1]), _lib.ptr(bns[-1]), p, seed, rng_ptr(L), _lib.ptr(mask), _lib.ptr(s.gptr), B,
-                _lib.ptr(pooled), _lib.ptr(fsum), None if fsum is None else fsum.data_ptr() + 4 * B * HID,
-                st()), "cgnn_gcn_fused_pool_fwd")
+            with _lib.timed("cgnn_gcn_fused_pool_fwd"):
+                _lib.check(lib.cgnn_gcn_fused_pool_fwd(
+                    _lib.ptr(ys[-1]), _lib.ptr(bns[-1]), p, seed, rng_ptr(L), _lib.ptr(mask), _lib.ptr(s.gptr), B,
+                    _lib.ptr(pooled), _lib.ptr(fsum), None if fsum is None else fsum.data_ptr() + 4 * B * HID,
+                    st()), "cgnn_gcn_fused_pool_fwd")
             masks.append(mask)
         c = _Ctx()
         c.s, c.meta, c.dis, c.tiles, c.grid = s, fmeta, dis, tiles, grid

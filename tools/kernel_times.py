@@ -8,7 +8,7 @@ ds = generate_packed(512, 360, 14, seed=1).to("cuda")
 b = assemble_batch(ds, torch.arange(4096) % 512)
 torch.manual_seed(0)
 m = C.GCNConnectome(5, 64, impl="fused").to("cuda").train()
-names = ["cgnn_gcn_l0_fwd", "cgnn_gcn_l0_bwd", "cgnn_gcn_fused_fwd", "cgnn_gcn_fused_bwd"]
+names = ["cgnn_gcn_l0_fwd", "cgnn_gcn_l0_bwd", "cgnn_gcn_fused_fwd", "cgnn_gcn_fused_bwd", "cgnn_gcn_fused_pool_fwd"]
 for _ in range(3): m(b).sum().backward()
 _lib.TIMER = _lib.KernelTimer(names)
 for _ in range(10): m(b).sum().backward()
