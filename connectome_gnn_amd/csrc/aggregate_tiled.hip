@@ -17,6 +17,17 @@
 
 namespace {
 
+#ifdef TA_NT_LD
+#define TA_LD ldnt4
+#else
+#define TA_LD ld4
+#endif
+#ifdef TA_NT_ST
+#define TA_ST stnt4
+#else
+#define TA_ST st4
+#endif
+
 constexpr int TA_MAXR = CGNN_FUSED_MAX_ROWS;   // 384
 #ifndef CGNN_TA_NW
 #define CGNN_TA_NW 12
@@ -56,7 +67,7 @@ __global__ void __launch_bounds__(TA_THR) k_agg_tiled(
       pfs[k] = 1.f;
       pfp[k] = 1.f;
       if (row < nn) {
-        pfx[k] = ld4(X + (int64_t)(nb + row) * ldx + 64 * slice + 4 * j);
+        pfx[k] = TA_LD(X + (int64_t)(nb + row) * ldx + 64 * slice + 4 * j);
         if (pre) pfs[k] = pre[nb + row];
         if (post) pfp[k] = post[nb + row];
       }
@@ -111,7 +122,7 @@ __global__ void __launch_bounds__(TA_THR) k_agg_tiled(
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
           const int row = 16 * b + 4 * q + it;
-          yo[it] = row < n ? ld4(Yadd + (int64_t)(base + row) * ldadd + 64 * slice + 4 * j)
+          yo[it] = row < n ? TA_LD(Yadd + (int64_t)(base + row) * ldadd + 64 * slice + 4 * j)
                            : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
@@ -128,7 +139,7 @@ __global__ void __launch_bounds__(TA_THR) k_agg_tiled(
                               : scale4(ag[it], p);
           v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
           if (accumulate) { v.x += yo[it].x; v.y += yo[it].y; v.z += yo[it].z; v.w += yo[it].w; }
-          st4(Y + (int64_t)(base + row) * ldy + 64 * slice + 4 * j, v);
+          TA_ST(Y + (int64_t)(base + row) * ldy + 64 * slice + 4 * j, v);
         }
       }
     }

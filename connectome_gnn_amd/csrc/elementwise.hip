@@ -66,6 +66,36 @@ __device__ __forceinline__ void st4(_Float16* p, const float4& v) {
   *reinterpret_cast<h4*>(p) = h;
 }
 
+// streamed activation arrays (common.h: non-temporal); knobs for the A/B builds
+using ::ldnt4;
+using ::stnt4;
+__device__ __forceinline__ float4 ldnt4(const _Float16* p) {
+  const h4 v = __builtin_nontemporal_load(reinterpret_cast<const h4*>(p));
+  return make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
+}
+__device__ __forceinline__ void stnt4(_Float16* p, const float4& v) {
+  h4 h;
+  h.x = (_Float16)v.x; h.y = (_Float16)v.y; h.z = (_Float16)v.z; h.w = (_Float16)v.w;
+  __builtin_nontemporal_store(h, reinterpret_cast<h4*>(p));
+}
+// (measured on cfg3: non-temporal loads in the apply passes -4 us per launch; in the statistics
+// passes they take the array away from the apply pass that re-reads it, +4 us there)
+#ifdef EW_NT_STATS
+#define EW_LDS ldnt4
+#else
+#define EW_LDS ld4
+#endif
+#ifdef EW_NO_NT_LD
+#define EW_LD ld4
+#else
+#define EW_LD ldnt4
+#endif
+#ifdef EW_NT_ST
+#define EW_ST stnt4
+#else
+#define EW_ST st4
+#endif
+
 // Readout gradient in place of a stored dX' (models.py:57-59 backward): the row's gradient is
 // dP[graph] / (n_graph + 1e-8), rebuilt on the fly instead of written out and read back.
 struct PoolGrad {
@@ -102,13 +132,13 @@ __global__ void __launch_bounds__(THR) k_colstats(
   }
   if (rr < rpp) {
     for (int64_t r = rbeg + rr; r < rend; r += rpp) {
-      const float4 a = (BWD && pg.dP) ? pool_grad(pg, r, N, c) : ld4(A + r * N + 4 * c);
+      const float4 a = (BWD && pg.dP) ? pool_grad(pg, r, N, c) : EW_LDS(A + r * N + 4 * c);
       if (!BWD) {
         s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
         s2.x = fmaf(a.x, a.x, s2.x); s2.y = fmaf(a.y, a.y, s2.y);
         s2.z = fmaf(a.z, a.z, s2.z); s2.w = fmaf(a.w, a.w, s2.w);
       } else {
-        const float4 y = ld4(Y + r * N + 4 * c);
+        const float4 y = EW_LDS(Y + r * N + 4 * c);
         const uint32_t kb = use_drop ? mask[r * nch + c] : 0xFu;
         const float zx = fmaf(ca.x, y.x, cb.x), zy = fmaf(ca.y, y.y, cb.y);
         const float zz = fmaf(ca.z, y.z, cb.z), zw = fmaf(ca.w, y.w, cb.w);
@@ -265,7 +295,7 @@ __global__ void __launch_bounds__(256) k_bn_act_apply(
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % nch);
-    const float4 y = ld4(Y + 4 * i);
+    const float4 y = EW_LD(Y + 4 * i);
     const float4 ca = ld4(coef + 4 * c), cb = ld4(coef + N + 4 * c);
     const float zx = fmaf(ca.x, y.x, cb.x), zy = fmaf(ca.y, y.y, cb.y);
     const float zz = fmaf(ca.z, y.z, cb.z), zw = fmaf(ca.w, y.w, cb.w);
@@ -282,9 +312,9 @@ __global__ void __launch_bounds__(256) k_bn_act_apply(
     const float fz = ((!relu || zz > 0.f) && (kb & 4u)) ? drop.scale : 0.f;
     const float fw = ((!relu || zw > 0.f) && (kb & 8u)) ? drop.scale : 0.f;
     if (!BWD) {
-      st4(out + 4 * i, make_float4(zx * fx, zy * fy, zz * fz, zw * fw));
+      EW_ST(out + 4 * i, make_float4(zx * fx, zy * fy, zz * fz, zw * fw));
     } else {
-      const float4 g = pg.dP ? pool_grad(pg, i / nch, N, c) : ld4(dXp + 4 * i);
+      const float4 g = pg.dP ? pool_grad(pg, i / nch, N, c) : EW_LD(dXp + 4 * i);
       const float4 cm = ld4(coef + 2 * N + 4 * c), ci = ld4(coef + 3 * N + 4 * c);
       const float4 c1 = ld4(bwc + 4 * c), c2 = ld4(bwc + N + 4 * c);
       float4 d = make_float4(ca.x * (g.x * fx - c1.x - (y.x - cm.x) * ci.x * c2.x),
@@ -295,7 +325,7 @@ __global__ void __launch_bounds__(256) k_bn_act_apply(
         d.x = y.x > 0.f ? d.x : 0.f; d.y = y.y > 0.f ? d.y : 0.f;
         d.z = y.z > 0.f ? d.z : 0.f; d.w = y.w > 0.f ? d.w : 0.f;
       }
-      st4(out + 4 * i, d);
+      EW_ST(out + 4 * i, d);
       cs.x += d.x; cs.y += d.y; cs.z += d.z; cs.w += d.w;
     }
   }
@@ -338,7 +368,7 @@ __global__ void __launch_bounds__(PTHR) k_bn_act_pool_fwd(
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int row = row0 + u * rpp;
-        yb[u] = row < rend ? ld4(Y + ((int64_t)row * nch + c) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        yb[u] = row < rend ? ldnt4(Y + ((int64_t)row * nch + c) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {

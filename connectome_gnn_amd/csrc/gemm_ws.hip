@@ -45,6 +45,18 @@ constexpr int WS_PANEL_FRAGS = 6144;     // 96 KB of 16-byte B fragments: (K/16)
 constexpr int WS_SLD = 36;               // row stride (floats) of a wave's 32 x 32 staging slab
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+#ifdef WS_NT_LD
+#define WS_LD ldnt4
+#else
+#define WS_LD ldg4
+#endif
+#ifdef WS_NT_BW
+#define WS_LDW ldnt4
+#define WS_LDS(p) ldnt(p)
+#else
+#define WS_LDW ldg4
+#define WS_LDS(p) (*(p))
+#endif
 
 __device__ __forceinline__ f32x16 mfma32(const uint4& a, const uint4& b, const f32x16& c) {
 #ifdef WS_DIAG_NOMFMA
@@ -145,7 +157,7 @@ __global__ void __launch_bounds__(FW_THR) k_ws(
     for (int u = 0; u < 4; ++u) {
       int64_t row = rb * 32 + 8 * u + lrow;
       if (row >= M) row = M - 1;                       // clamp: loads stay in bounds, rows unused
-      buf[u] = ldg4(base + row * ld + 4 * lpc);
+      buf[u] = WS_LD(base + row * ld + 4 * lpc);
     }
   };
 
@@ -284,13 +296,13 @@ __global__ void __launch_bounds__(WS_THR) k_ws_bwd_weight(
       const int64_t m = m0 + 8 * mh + e;
       if (m < mend) {
         if (NTN == 4) {
-          const float4 v = ldg4(ap + m * lddy);
+          const float4 v = WS_LDW(ap + m * lddy);
           a[e][0] = v.x; a[e][1] = v.y; a[e][NTN > 2 ? 2 : 0] = v.z; a[e][NTN > 3 ? 3 : 0] = v.w;
         } else {
           const float2 v = *reinterpret_cast<const float2*>(ap + m * lddy);
           a[e][0] = v.x; a[e][1] = v.y;
         }
-        b[e] = bp[m * ldx];
+        b[e] = WS_LDS(bp + m * ldx);
       } else {
 #pragma unroll
         for (int t = 0; t < NTN; ++t) a[e][t] = 0.f;
