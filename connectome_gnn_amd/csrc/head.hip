@@ -12,7 +12,8 @@
 namespace {
 
 constexpr int HTHR = 256;
-constexpr int HEAD_MAX_H = 128;          // input width (wider heads stay on the generic GEMMs)
+constexpr int HEAD_MAX_H = 256;          // input width (wider heads stay on the generic GEMMs);
+                                         // 256: W1 [128 x 256] is 128 KB of the 160 KB LDS
 constexpr int HEAD_MAX_C = 16;           // classes
 
 __device__ __forceinline__ uint32_t hmix32(uint32_t x) {
@@ -187,11 +188,14 @@ __global__ void __launch_bounds__(256) k_head_bwd_t(
     const float* __restrict__ fac, int B, const float* __restrict__ W1, const float* __restrict__ W2,
     float* __restrict__ dP, float* __restrict__ slab) {
   constexpr int KT = H / 16, JT = H2 / 16;
-  static_assert(H % 16 == 0 && H2 % 16 == 0 && KT % 2 == 0 && C * H2 + H2 + C <= 256, "head shape");
+  constexpr int HBR = H > 128 ? 8 : HB_R;             // rows per chunk (H = 256: W1 alone is 128 KB of LDS)
+  constexpr int TPR = 256 / HBR;                      // threads per row in the dP pass
+  constexpr int NSM = H2 + C * H2 + C;                // db1 | dW2 | db2: up to two per thread
+  static_assert(H % 16 == 0 && H2 % 16 == 0 && KT % 2 == 0 && NSM <= 512, "head shape");
   __shared__ __attribute__((aligned(16))) float w1[H2 * H];
   __shared__ float w2[C * H2];
-  __shared__ __attribute__((aligned(16))) float pl[HB_R * H];
-  __shared__ float dh[HB_R * H2], hl[HB_R * H2], dl[HB_R * C];
+  __shared__ __attribute__((aligned(16))) float pl[HBR * H];
+  __shared__ float dh[HBR * H2], hl[HBR * H2], dl[HBR * C];
   const int t = threadIdx.x;
   for (int i = t; i < H2 * H; i += 256) w1[i] = W1[i];
   for (int i = t; i < C * H2; i += 256) w2[i] = W2[i];
@@ -201,21 +205,21 @@ __global__ void __launch_bounds__(256) k_head_bwd_t(
   for (int a = 0; a < JT; ++a)
 #pragma unroll
     for (int b = 0; b < KT; ++b) gw1[a][b] = 0.f;
-  float gsm = 0.f;                                     // one of db1[j] / dW2[c][j] / db2[c] per thread
-  for (int r0 = blockIdx.x * HB_R; r0 < B; r0 += gridDim.x * HB_R) {
+  float gsm[2] = {0.f, 0.f};                           // elements t and t + 256 of db1 | dW2 | db2
+  for (int r0 = blockIdx.x * HBR; r0 < B; r0 += gridDim.x * HBR) {
     __syncthreads();
-    for (int i = t; i < HB_R * H / 4; i += 256) {
+    for (int i = t; i < HBR * H / 4; i += 256) {
       const int r = r0 + i / (H / 4);
       *reinterpret_cast<float4*>(pl + 4 * i) =
           r < B ? *reinterpret_cast<const float4*>(P + (int64_t)r0 * H + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int i = t; i < HB_R * H2; i += 256) {
+    for (int i = t; i < HBR * H2; i += 256) {
       const int r = r0 + i / H2;
       hl[i] = r < B ? H1[(int64_t)r0 * H2 + i] : 0.f;
     }
-    for (int i = t; i < HB_R * C; i += 256) dl[i] = (r0 + i / C) < B ? dL[(int64_t)r0 * C + i] : 0.f;
+    for (int i = t; i < HBR * C; i += 256) dl[i] = (r0 + i / C) < B ? dL[(int64_t)r0 * C + i] : 0.f;
     __syncthreads();
-    for (int i = t; i < HB_R * H2; i += 256) {
+    for (int i = t; i < HBR * H2; i += 256) {
       const int rl = i / H2, j = i % H2, r = r0 + rl;
       float d = 0.f;
       if (r < B) {
@@ -226,10 +230,10 @@ __global__ void __launch_bounds__(256) k_head_bwd_t(
       dh[i] = d;
     }
     __syncthreads();
-    // dP[r][4k4..] = sum_j dh[r][j] W1[j][4k4..]: thread (row, 4-column piece), H/64 pieces each
+    // dP[r][4k4..] = sum_j dh[r][j] W1[j][4k4..]: thread (row, 4-column piece)
 #pragma unroll
-    for (int pc = 0; pc < (H / 4 + 15) / 16; ++pc) {
-      const int rl = t >> 4, k4 = (t & 15) + 16 * pc;
+    for (int pc = 0; pc < (H / 4 + TPR - 1) / TPR; ++pc) {
+      const int rl = t / TPR, k4 = (t % TPR) + TPR * pc;
       if (r0 + rl < B && k4 < H / 4) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 8
@@ -243,7 +247,7 @@ __global__ void __launch_bounds__(256) k_head_bwd_t(
     }
     // parameter gradients of this chunk (rows past B contribute zeros: dh, dl, hl are zero there)
 #pragma unroll 4
-    for (int rl = 0; rl < HB_R; ++rl) {
+    for (int rl = 0; rl < HBR; ++rl) {
       float dv[JT], pv[KT];
 #pragma unroll
       for (int a = 0; a < JT; ++a) dv[a] = dh[rl * H2 + JT * tj + a];
@@ -257,28 +261,35 @@ __global__ void __launch_bounds__(256) k_head_bwd_t(
 #pragma unroll
         for (int b = 0; b < KT; ++b) gw1[a][b] = fmaf(dv[a], pv[b], gw1[a][b]);
     }
-    if (t < H2) {
-      for (int rl = 0; rl < HB_R; ++rl) gsm += dh[rl * H2 + t];
-    } else if (t < H2 + C * H2) {
-      const int q = t - H2, c = q / H2, j = q % H2;
-      for (int rl = 0; rl < HB_R; ++rl) gsm = fmaf(dl[rl * C + c], hl[rl * H2 + j], gsm);
-    } else if (t < H2 + C * H2 + C) {
-      const int c = t - H2 - C * H2;
-      for (int rl = 0; rl < HB_R; ++rl) gsm += dl[rl * C + c];
+#pragma unroll
+    for (int u = 0; u < (NSM + 255) / 256; ++u) {
+      const int e = t + 256 * u;
+      if (e < H2) {
+        for (int rl = 0; rl < HBR; ++rl) gsm[u] += dh[rl * H2 + e];
+      } else if (e < H2 + C * H2) {
+        const int q = e - H2, c = q / H2, j = q % H2;
+        for (int rl = 0; rl < HBR; ++rl) gsm[u] = fmaf(dl[rl * C + c], hl[rl * H2 + j], gsm[u]);
+      } else if (e < NSM) {
+        const int c = e - H2 - C * H2;
+        for (int rl = 0; rl < HBR; ++rl) gsm[u] += dl[rl * C + c];
+      }
     }
   }
-  float* out = slab + (int64_t)blockIdx.x * (H2 * H + H2 + C * H2 + C);
+  float* out = slab + (int64_t)blockIdx.x * (H2 * H + NSM);
 #pragma unroll
   for (int a = 0; a < JT; ++a)
 #pragma unroll
     for (int b = 0; b < KT; ++b) out[(JT * tj + a) * H + KT * tk + b] = gw1[a][b];
-  if (t < H2 + C * H2 + C) out[H2 * H + t] = gsm;      // db1 | dW2 | db2 follow dW1 in this order
+#pragma unroll
+  for (int u = 0; u < (NSM + 255) / 256; ++u)
+    if (t + 256 * u < NSM) out[H2 * H + t + 256 * u] = gsm[u];   // db1 | dW2 | db2 follow dW1 in this order
 }
 
-bool head_tiled(int H, int H2, int C) { return C == 2 && H == 2 * H2 && (H == 32 || H == 64 || H == 128); }
+bool head_tiled(int H, int H2, int C) { return C == 2 && H == 2 * H2 && (H == 32 || H == 64 || H == 128 || H == 256); }
 int head_bwd_grid(int B, int H, int H2, int C) {
   if (!head_tiled(H, H2, C)) return -1;
-  const int g = (B + HB_R - 1) / HB_R;
+  const int rows = H > 128 ? 8 : HB_R;               // = HBR of k_head_bwd_t
+  const int g = (B + rows - 1) / rows;
   return g < 1 ? 1 : (g > HB_MAX_GRID ? HB_MAX_GRID : g);
 }
 
@@ -348,9 +359,32 @@ __global__ void __launch_bounds__(CETHR) k_ce_fwd(const float* __restrict__ logi
   }
 }
 
+constexpr size_t HEAD_LDS_MAX = 160 * 1024;
+size_t head_fwd_lds(int H, int H2) {
+  const int RB = HTHR / H2;
+  return sizeof(float) * ((size_t)H2 * (H + 1) + (size_t)RB * H + (size_t)RB * H2);
+}
+size_t head_bwd_lds(int H, int H2, int C) {
+  const int RB = HTHR / H2;
+  return sizeof(float) * ((size_t)H2 * H + (size_t)RB * H + 2 * (size_t)RB * H2 + (size_t)RB * C);
+}
 bool head_ok(int H, int H2, int C) {
   return H >= 1 && H <= HEAD_MAX_H && H2 >= 1 && H2 <= HEAD_MAX_H / 2 && HTHR % H2 == 0 && C >= 1 &&
-         C <= HEAD_MAX_C;
+         C <= HEAD_MAX_C && head_fwd_lds(H, H2) <= HEAD_LDS_MAX && head_bwd_lds(H, H2, C) <= HEAD_LDS_MAX;
+}
+// dynamic LDS above 64 KB has to be allowed per kernel (once per device)
+bool head_allow_lds() {
+  static bool done[CGNN_MAX_DEVICES] = {};
+  bool& d = done[cgnn_device_ordinal()];
+  if (!d) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_head_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)HEAD_LDS_MAX) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_head_bwd), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)HEAD_LDS_MAX) != hipSuccess)
+      return false;
+    d = true;
+  }
+  return true;
 }
 
 int head_grid(int B, int H2) {
@@ -390,8 +424,8 @@ int cgnn_head_fwd_f32(const float* P, int32_t B, int32_t H, int32_t H2, int32_t 
   d.key0 = (uint32_t)(seed & 0xFFFFFFFFu) * 0x9E3779B9u + 0x7F4A7C15u;
   d.key1 = (uint32_t)(seed >> 32) ^ 0x94D049BBu;
   d.dev_key = seed_dev;
-  const int RB = HTHR / H2;
-  const size_t lds = sizeof(float) * ((size_t)H2 * (H + 1) + (size_t)RB * H + (size_t)RB * H2);
+  const size_t lds = head_fwd_lds(H, H2);
+  if (lds > 64 * 1024 && !head_allow_lds()) return CGNN_ELAUNCH;
   k_head_fwd<<<head_grid(B, H2), HTHR, lds, cgnn_stream(stream)>>>(
       P, B, H, H2, C, W1, b1, W2, b2, d, p_drop > 0.f ? 1 : 0, H1, fac, logits);
   CGNN_CHECK_LAUNCH();
@@ -416,12 +450,13 @@ int cgnn_head_bwd_f32(const float* dlogits, const float* P, const float* H1, con
   if (tg > 0) {
     if (H == 64) k_head_bwd_t<64, 32, 2><<<tg, 256, 0, cgnn_stream(stream)>>>(dlogits, P, H1, fac, B, W1, W2, dP, slab);
     else if (H == 128) k_head_bwd_t<128, 64, 2><<<tg, 256, 0, cgnn_stream(stream)>>>(dlogits, P, H1, fac, B, W1, W2, dP, slab);
+    else if (H == 256) k_head_bwd_t<256, 128, 2><<<tg, 256, 0, cgnn_stream(stream)>>>(dlogits, P, H1, fac, B, W1, W2, dP, slab);
     else k_head_bwd_t<32, 16, 2><<<tg, 256, 0, cgnn_stream(stream)>>>(dlogits, P, H1, fac, B, W1, W2, dP, slab);
     CGNN_CHECK_LAUNCH();
     return CGNN_OK;
   }
-  const int RB = HTHR / H2;
-  const size_t lds = sizeof(float) * ((size_t)H2 * H + (size_t)RB * H + 2 * (size_t)RB * H2 + (size_t)RB * C);
+  const size_t lds = head_bwd_lds(H, H2, C);
+  if (lds > 64 * 1024 && !head_allow_lds()) return CGNN_ELAUNCH;
   k_head_bwd<<<head_grid(B, H2), HTHR, lds, cgnn_stream(stream)>>>(dlogits, P, H1, fac, B, H, H2, C, W1,
                                                                  W2, dP, slab);
   CGNN_CHECK_LAUNCH();

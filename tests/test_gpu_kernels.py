@@ -435,7 +435,7 @@ def test_cross_entropy_ignore_index_and_bad_labels():
     assert torch.isnan(ops.CrossEntropyLoss()(lgd, lab.to(DEV)))
 
 
-@pytest.mark.parametrize("h,c,p", [(64, 2, 0.0), (128, 3, 0.0), (32, 2, 0.0), (64, 2, 0.4)])
+@pytest.mark.parametrize("h,c,p", [(64, 2, 0.0), (128, 3, 0.0), (32, 2, 0.0), (64, 2, 0.4), (256, 2, 0.0), (256, 2, 0.3)])
 def test_fused_head_matches_torch(h, c, p):
     """cgnn_head_fwd/bwd against the torch modules of the reference's classifier (models.py:196-201)."""
     import torch.nn as nn
