@@ -201,6 +201,8 @@ def main() -> None:
     ap.add_argument("--graph", action="store_true", help="same as --launch graph")
     ap.add_argument("--collectives", default="split", choices=["split", "captured"],
                     help="graph launch at N > 1: all-reduce between two graphs, or captured inside one")
+    ap.add_argument("--optimizer", default="cgnn", choices=["cgnn", "torch"],
+                    help="cgnn: connectome_gnn_amd.optim.Adam (one launch); torch: torch.optim.Adam(fused=True)")
     ap.add_argument("--no-end-to-end", action="store_true",
                     help="skip the fresh-batch (assemble + structure build + step) measurement")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
@@ -271,8 +273,12 @@ def main() -> None:
     collectives = args.collectives
     if use_graph and world > 1 and args.sync_bn:
         collectives = "captured"          # sync-BN exchanges sit inside forward/backward
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4, fused=True,
-                           capturable=use_graph)
+    if args.optimizer == "torch":
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4, fused=True,
+                               capturable=use_graph)
+    else:
+        from connectome_gnn_amd.optim import Adam      # torch.optim.Adam's update as one launch
+        opt = Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
     from connectome_gnn_amd import ops as cops
     loss_fn = cops.CrossEntropyLoss()        # the Trainer's criterion: CrossEntropyLoss defaults
     graphed = None
@@ -384,7 +390,7 @@ def main() -> None:
             "config": {"workload": args.workload, "model": model_kind, "rois": n, "ws_k": k,
                        "edges_per_graph": e, "hidden": hidden, "layers": 3,
                        "graphs_per_gpu": bsz, "global_batch": global_batch, "dropout": 0.3,
-                       "optimizer": "Adam lr1e-3 wd1e-4", "impl": impl_used,
+                       "optimizer": "Adam lr1e-3 wd1e-4" + (" (torch fused)" if args.optimizer == "torch" else " (optim.Adam)"), "impl": impl_used,
                        "launch": ("hip-graph replay" + (f" ({collectives} all-reduce)" if world > 1 else ""))
                        if graphed is not None else "eager",
                        "bn": "sync" if (world > 1 and args.sync_bn) else "per-rank",

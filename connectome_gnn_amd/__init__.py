@@ -3,7 +3,7 @@ rebuilt for AMD Instinct MI355X (gfx950): hand-written HIP kernels behind the re
 Python API.  The package exposes the reference's ten public names
 (connectome_gnn/__init__.py:29-40), so ``import connectome_gnn_amd as connectome_gnn`` is the
 whole migration for a script that trains on a ROCm device; the MI355X-specific extras
-(``resident``, ``graphed``, ``dist``, ``ops``) are reached as submodules.
+(``resident``, ``graphed``, ``dist``, ``ops``, ``optim``) are reached as submodules.
 """
 from . import graph as _graph
 from . import models as _models

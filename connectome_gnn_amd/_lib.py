@@ -53,6 +53,16 @@ class CgnnDwJobs(ctypes.Structure):
                 ("take_cols", c_int32 * DW_MAX_JOBS), ("dW", c_void_p * DW_MAX_JOBS),
                 ("db", c_void_p * DW_MAX_JOBS)]
 
+ADAM_MAX_JOBS = 32
+
+
+class CgnnAdamJobs(ctypes.Structure):
+    """Mirror of `struct cgnn_adam_jobs` (include/cgnn.h): the tensors of one optimizer launch."""
+    _fields_ = [("n", c_int32), ("numel", c_int64 * ADAM_MAX_JOBS), ("param", c_void_p * ADAM_MAX_JOBS),
+                ("grad", c_void_p * ADAM_MAX_JOBS), ("exp_avg", c_void_p * ADAM_MAX_JOBS),
+                ("exp_avg_sq", c_void_p * ADAM_MAX_JOBS)]
+
+
 # name -> (restype, argtypes).  Order and meaning follow include/cgnn.h exactly.
 PROTOTYPES = {
     "cgnn_abi_version": (c_int, []),
@@ -121,6 +131,7 @@ PROTOTYPES = {
     "cgnn_bn_bwd_stats_finalize": (c_int, [P, I32, F64, I32, P, P, P, P]),
     "cgnn_dw_db_reduce": (c_int, [P, P, I32, I32, I32, P, I32, P, P]),
     "cgnn_dw_db_reduce_multi": (c_int, [ctypes.POINTER(CgnnDwJobs), P]),
+    "cgnn_adam_step": (c_int, [ctypes.POINTER(CgnnAdamJobs), P, P, I32, F64, F64, F64, F64, F64, P]),
     "cgnn_l0_grid": (c_int, [c_int64]),
     "cgnn_gcn_l0_fwd": (c_int, [TP, P, I32, P, P, P, P, P, P]),
     "cgnn_gcn_l0_bwd": (c_int, [P, P, LP, P, P, P, I64, P, P, P]),

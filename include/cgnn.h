@@ -419,6 +419,23 @@ int cgnn_bn_act_bwd_apply_f16(const void* dX, const void* Y, const uint8_t* mask
                               double* colsum_slab, void* dY, int64_t M, int32_t N, const float* dP,
                               const int32_t* node_graph, const int32_t* gptr, void* stream);
 
+/* ---- optimizer: torch.optim.Adam's update (L2 weight decay, no amsgrad) for up to
+ * CGNN_ADAM_MAX_JOBS fp32 tensors in ONE launch (reference: torch.optim.Adam in demo.py:105-134).
+ * `step` is the shared fp32 step counter on the device (t = *step + 1 is used); with advance != 0
+ * the same launch stores *step + 1 once every workgroup has read it (`arrivals`: a zeroed uint32
+ * the launch leaves zero again).  Graph-capturable: nothing comes from the host but lr/betas. */
+#define CGNN_ADAM_MAX_JOBS 32
+typedef struct cgnn_adam_jobs {
+  int32_t n;
+  int64_t numel[CGNN_ADAM_MAX_JOBS];
+  float* param[CGNN_ADAM_MAX_JOBS];
+  const float* grad[CGNN_ADAM_MAX_JOBS];
+  float* exp_avg[CGNN_ADAM_MAX_JOBS];
+  float* exp_avg_sq[CGNN_ADAM_MAX_JOBS];
+} cgnn_adam_jobs;
+int cgnn_adam_step(const cgnn_adam_jobs* jobs, float* step, uint32_t* arrivals, int32_t advance,
+                   double lr, double beta1, double beta2, double eps, double weight_decay, void* stream);
+
 /* Single-launch forms of (cgnn_bn_reduce + cgnn_bn_finalize [+ num_batches_tracked += 1]),
  * (cgnn_bn_reduce + cgnn_bn_bwd_finalize) and (cgnn_slab_reduce_f32 + cgnn_slab_reduce_f64):
  * used when no cross-rank exchange sits between the reduction and the finalisation.

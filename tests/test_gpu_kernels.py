@@ -526,3 +526,54 @@ def test_csr_build_grouped_is_bit_identical_to_generic(sizes, deg):
         s3 = BatchStructure.build(b2)
         assert not s3.block_diagonal
         assert torch.equal(s3.eid_dst, BatchStructure.build(b2, force_generic=True).eid_dst)
+
+
+@pytest.mark.parametrize("wd", [0.0, 1e-4])
+def test_optim_adam_matches_torch_adam(wd):
+    """connectome_gnn_amd.optim.Adam (one launch, device step counter) follows torch.optim.Adam
+    step for step, its state_dict loads into torch's and back, and it runs under graph capture."""
+    from connectome_gnn_amd.optim import Adam
+    torch.manual_seed(0)
+    shapes = [(64, 5), (64,), (64, 64), (1,), (300, 7), (2, 32)]
+    ps_a = [torch.randn(*s, device=DEV).requires_grad_(True) for s in shapes]
+    ps_b = [p.detach().clone().requires_grad_(True) for p in ps_a]
+    oa = Adam(ps_a, lr=1e-2, weight_decay=wd)
+    ob = torch.optim.Adam(ps_b, lr=1e-2, weight_decay=wd)
+    for it in range(7):
+        gs = [torch.randn_like(p) * (1.0 + it) for p in ps_a]
+        for p, q, g in zip(ps_a, ps_b, gs):
+            p.grad, q.grad = g.clone(), g.clone()
+        oa.step()
+        ob.step()
+        if it == 3:                      # checkpoint round trip through torch's format, both ways
+            import copy                  # (load_state_dict aliases tensors that already fit: copy)
+            ob2 = torch.optim.Adam(ps_b, lr=1e-2, weight_decay=wd)
+            ob2.load_state_dict(copy.deepcopy(oa.state_dict()))
+            assert float(ob2.state[ps_b[0]]["step"]) == 4.0
+            oa.load_state_dict(copy.deepcopy(ob.state_dict()))
+    for p, q in zip(ps_a, ps_b):
+        torch.testing.assert_close(p, q, rtol=2e-6, atol=1e-7)
+    assert float(oa.state[ps_a[0]]["step"]) == 7.0
+    for p, q in zip(ps_a, ps_b):
+        torch.testing.assert_close(oa.state[p]["exp_avg_sq"], ob.state[q]["exp_avg_sq"], rtol=2e-6, atol=1e-12)
+    # graph capture: three replays = three more steps
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    fixed = [torch.randn_like(p) for p in ps_a]
+    for p, q, f in zip(ps_a, ps_b, fixed):
+        p.grad.copy_(f)
+        q.grad = f.clone()
+    with torch.cuda.stream(side):
+        oa.step()
+    torch.cuda.current_stream().wait_stream(side)
+    ob.step()
+    with torch.cuda.graph(g):
+        oa.step()
+    for _ in range(3):
+        g.replay()
+        ob.step()
+    torch.cuda.synchronize()
+    assert float(oa.state[ps_a[0]]["step"]) == 11.0
+    for p, q in zip(ps_a, ps_b):
+        torch.testing.assert_close(p, q, rtol=5e-6, atol=1e-7)
