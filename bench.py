@@ -325,10 +325,13 @@ def main() -> None:
         f"cgnn_aggregate_f32[F={hidden}]": agg_bytes,           # gather form (graphs > 384 nodes)
         # fp16 storage: the dense per-graph aggregate, priced at the SPARSE operator's bytes (s = 2)
         f"cgnn_dense_aggregate_f16[F={hidden}]": lambda nn_, ee: 2.0 * nn_ * hidden * 2 + 8.0 * ee + 4.0 * (nn_ + 1),
+        f"cgnn_dense_aggregate_c16[F={hidden}]": lambda nn_, ee: 2.0 * nn_ * hidden * 2 + 8.0 * ee + 4.0 * (nn_ + 1),
     }
     fused_kind = getattr(model, "_fused_kind", None) if impl_used == "fused" else None
     if fused_kind == "half":
-        dom = f"cgnn_dense_aggregate_f16[F={hidden}]"
+        from connectome_gnn_amd import gcn_half_path, ops as _ops
+        packed = isinstance(gcn_half_path.dense_operators(batches[0].structure())[0], _ops.DensePack)
+        dom = f"cgnn_dense_aggregate_{'c16' if packed else 'f16'}[F={hidden}]"
     elif fused_kind == "tile":
         dom = "cgnn_gcn_fused_bwd"
     elif batches[0].structure().tiled_ok(hidden):

@@ -54,13 +54,33 @@ def eligible(model, batch, structure: BatchStructure) -> Optional[str]:
     return None
 
 
+def _agg(s, m, x, bias=None):
+    if isinstance(m, ops.DensePack):
+        return ops.dense_aggregate_c16_raw(s, m, x, bias)
+    return ops.dense_aggregate_f16_raw(s, m, x, bias)
+
+
+PACK_BELOW = 0.6       # use the per-fragment operator when it is at most this fraction of the dense bytes
+
+
+def _operator(s: BatchStructure, coef, selfc, transposed: bool):
+    """The dense operator of one ordering in the smaller of its two forms: per MFMA fragment
+    (ops.DensePack: nearly full fragments dense, the others as entry lists) when that is clearly
+    smaller -- the aggregate is bound by the operator's bytes, which come from HBM on each of
+    the five launches of a step -- else the plain dense [B, P, P] half matrix."""
+    pk = ops.dense_pack_f16(s, coef, selfc, transposed)
+    pitch = pk.pitch
+    if pk.nbytes() <= PACK_BELOW * (2.0 * s.num_graphs * pitch * pitch):
+        return pk
+    return ops.dense_adj_f16(s, coef, selfc, transposed)
+
+
 def dense_operators(s: BatchStructure):
-    """(Mf, Mb): dense normalised operator and its transpose, built once per batch structure."""
+    """(Mf, Mb): normalised operator and its transpose, built once per batch structure."""
     cached = s.__dict__.get("_dense_f16")
     if cached is None:
         norm = s.gcn_norm()
-        cached = (ops.dense_adj_f16(s, norm.coef_dst, norm.selfc, False),
-                  ops.dense_adj_f16(s, norm.coef_src, norm.selfc, True))
+        cached = (_operator(s, norm.coef_dst, norm.selfc, False), _operator(s, norm.coef_src, norm.selfc, True))
         s.__dict__["_dense_f16"] = cached
     return cached
 
@@ -123,13 +143,13 @@ class GcnHalfEncode(torch.autograd.Function):
                     f0 = x0.shape[1]
                     x0h = torch.zeros(n_nodes, P0_COLS, dtype=torch.float16, device=dev)
                     x0h[:, :f0] = x0
-                    sv.p0 = ops.dense_aggregate_f16_raw(s, mf, x0h)        # [Nn, 64] half, cols >= F0 zero
+                    sv.p0 = _agg(s, mf, x0h)        # [Nn, 64] half, cols >= F0 zero
                     wh = w.half()
                     y = torch.addmm(b.half(), sv.p0[:, :f0], wh.t())
                 else:
                     wh = w.half()
                     t = torch.matmul(x, wh.t())                            # half GEMM, fp32 accumulate
-                    y = ops.dense_aggregate_f16_raw(s, mf, t, b)
+                    y = _agg(s, mf, t, b)
                 slab = None
                 if training:
                     slab = torch.empty(rows, 2 * hid, dtype=torch.float64, device=dev)
@@ -200,7 +220,7 @@ class GcnHalfEncode(torch.autograd.Function):
                     dw = _weight_grad(dy, sv.p0)[:, :w.shape[1]].contiguous()
                     grads[0:4] = [dw, db, dgamma, dbeta]
                     break
-                dt = ops.dense_aggregate_f16_raw(s, sv.mb, dy)             # dT = A_hat^T dY
+                dt = _agg(s, sv.mb, dy)             # dT = A_hat^T dY
                 grads[4 * li:4 * li + 4] = [_weight_grad(dt, x), db, dgamma, dbeta]
                 dx = torch.matmul(dt, wh)                                  # dX = dT W
         ctx.sv = None

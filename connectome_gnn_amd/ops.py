@@ -183,6 +183,76 @@ def dense_aggregate_f16_raw(structure, m, x, bias=None) -> torch.Tensor:
     return y
 
 
+class DensePack:
+    """A dense per-graph operator of one CSR ordering stored per MFMA fragment (cgnn_dense_pack_*):
+    nearly full fragments dense, the others as lists of their non-zero entries, empty ones not at
+    all.  Static per batch, like the CSR it is built from."""
+    __slots__ = ("dfrag", "dstep", "doff", "sent", "sstep", "soff", "pitch", "nnz", "num_dense", "num_sparse")
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in (self.dfrag, self.dstep, self.doff, self.sent,
+                                                          self.sstep, self.soff))
+
+
+def dense_pack_f16(structure, coef, selfc, transposed: bool = False) -> DensePack:
+    lib = _lib.load()
+    s = structure
+    dev = coef.device
+    pitch = (s.max_nodes_per_graph + 63) // 64 * 64
+    steps, nrows = pitch // 16, s.num_graphs * (pitch // 32)
+    rowptr, col = (s.rowptr_src, s.col_src) if transposed else (s.rowptr_dst, s.col_dst)
+    counts = torch.empty(nrows * steps, dtype=torch.int32, device=dev)
+    args = (_lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(coef), _lib.ptr(selfc), _lib.ptr(s.gptr), s.num_graphs, pitch)
+    pk = DensePack()
+    with _lib.device_guard(dev):
+        _lib.check(lib.cgnn_dense_pack_count(*args, _lib.ptr(counts), _lib.stream_ptr()), "cgnn_dense_pack_count")
+        cnt = counts.view(nrows, steps).to(torch.int64)
+        is_d, is_s = cnt > 64, (cnt > 0) & (cnt <= 64)
+        nd, ns = is_d.sum(1), is_s.sum(1)
+        ns4 = (ns + 3) // 4 * 4                              # the aggregate loads four chunks at a time
+        doff = torch.zeros(nrows + 1, dtype=torch.int64, device=dev)
+        soff = torch.zeros(nrows + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(nd, 0, out=doff[1:])
+        torch.cumsum(ns4, 0, out=soff[1:])
+        tot_d, tot_s = int(doff[-1]), int(soff[-1])          # host sync: collate-time, outside the step
+        if max(tot_d, tot_s) >= 2 ** 30:
+            raise ValueError("dense operator too large to pack")
+        rank_d = torch.cumsum(is_d, 1) - is_d.to(torch.int64) + doff[:-1, None]
+        rank_s = torch.cumsum(is_s, 1) - is_s.to(torch.int64) + soff[:-1, None]
+        fpos = torch.full_like(cnt, 0xFFFFFFFF)
+        fpos = torch.where(is_d, rank_d | 0x80000000, fpos)
+        fpos = torch.where(is_s, rank_s, fpos)
+        fpos = torch.where(fpos >= 2 ** 31, fpos - 2 ** 32, fpos).to(torch.int32)    # uint32 bit patterns
+        pk.dfrag = torch.empty(max(tot_d, 1) * 512, dtype=torch.float16, device=dev)
+        pk.dstep = torch.zeros(max(tot_d, 1), dtype=torch.int32, device=dev)
+        pk.sent = torch.full((max(tot_s, 4) * 64,), 0xFFFF, dtype=torch.int32, device=dev)
+        pk.sstep = torch.zeros(max(tot_s, 4), dtype=torch.int32, device=dev)
+        pk.doff, pk.soff = doff.to(torch.int32), soff.to(torch.int32)
+        _lib.check(lib.cgnn_dense_pack_fill(*args, _lib.ptr(fpos.contiguous()), _lib.ptr(pk.dfrag), _lib.ptr(pk.dstep),
+                                            _lib.ptr(pk.sent), _lib.ptr(pk.sstep), _lib.stream_ptr()),
+                   "cgnn_dense_pack_fill")
+        torch.cuda.current_stream(dev).synchronize()        # fpos is a temporary of this call
+    pk.pitch, pk.nnz, pk.num_dense, pk.num_sparse = pitch, int(counts.sum()), tot_d, int(ns.sum())
+    return pk
+
+
+def dense_aggregate_c16_raw(structure, pack: DensePack, x, bias=None) -> torch.Tensor:
+    """Y_g = M_g X_g from the per-fragment operator (cgnn_dense_aggregate_c16); x, result half."""
+    lib = _lib.load()
+    _require_device(x, "x")
+    if x.dtype != torch.float16:
+        raise TypeError("x must be float16")
+    n, f = x.shape
+    y = torch.empty(n, f, dtype=torch.float16, device=x.device)
+    with _lib.device_guard(x.device), _lib.timed("cgnn_dense_aggregate_c16", f"F={f}"):
+        _lib.check(lib.cgnn_dense_aggregate_c16(
+            _lib.ptr(pack.dfrag), _lib.ptr(pack.dstep), _lib.ptr(pack.doff), _lib.ptr(pack.sent),
+            _lib.ptr(pack.sstep), _lib.ptr(pack.soff), pack.pitch, _lib.ptr(structure.gptr),
+            structure.num_graphs, _lib.ptr(x), x.stride(0), f, _lib.ptr(bias), _lib.ptr(y), y.stride(0),
+            _lib.stream_ptr()), "cgnn_dense_aggregate_c16")
+    return y
+
+
 class _AggregateTiled(torch.autograd.Function):
     """Y = post * A(pre * X) + bias on the blocked-ELL tiles; backward = the transposed ELL with
     pre and post swapped."""

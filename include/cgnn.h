@@ -302,6 +302,32 @@ int cgnn_dense_aggregate_f16(const void* M, int32_t P, const int32_t* gptr, int3
                              const void* X, int64_t ldx, int32_t F, const float* bias, void* Y,
                              int64_t ldy, void* stream);
 
+/* The same operator stored per MFMA A fragment (32 rows x 16 sources) in the form that fits it:
+ * fragments with more than 64 non-zeros in a DENSE list (1 KB each, operand-major, `dfrag`), those
+ * with 1..64 in a SPARSE list (one chunk of 64 (slot | half value << 16) words each, padding slot
+ * 0xFFFF, four chunks interleaved per lane, `sent`), empty ones nowhere; `dstep` / `sstep` hold the
+ * k-step of every item, `doff` / `soff` [num_graphs * P/32 + 1] the item ranges of the (graph, row
+ * block)s (sparse ranges are multiples of four chunks).  Building (P as above):
+ *   1. cgnn_dense_pack_count: counts[num_graphs * P/32 * P/16] <- non-zeros per fragment;
+ *   2. the caller classifies, forms doff / soff and fpos[fragment] (list position; | 0x80000000 for
+ *      the dense list; 0xFFFFFFFF = empty), allocates dfrag / sent (sent pre-filled with 0xFFFF
+ *      words, sstep with 0) and calls cgnn_dense_pack_fill.
+ * cgnn_dense_aggregate_c16 computes what cgnn_dense_aggregate_f16 computes with the same MFMAs,
+ * accumulated dense-list-first (equal up to the order of the fp32 accumulation).  On small-world
+ * graphs at 10 % density the operator shrinks ~3x and the dense form is HBM-bound on it. */
+int cgnn_dense_pack_count(const int32_t* rowptr, const int32_t* col, const float* coef,
+                          const float* selfc, const int32_t* gptr, int32_t num_graphs, int32_t P,
+                          uint32_t* counts, void* stream);
+int cgnn_dense_pack_fill(const int32_t* rowptr, const int32_t* col, const float* coef,
+                         const float* selfc, const int32_t* gptr, int32_t num_graphs, int32_t P,
+                         const uint32_t* fpos, void* dfrag, int32_t* dstep, uint32_t* sent,
+                         int32_t* sstep, void* stream);
+int cgnn_dense_aggregate_c16(const void* dfrag, const int32_t* dstep, const uint32_t* doff,
+                             const uint32_t* sent, const int32_t* sstep, const uint32_t* soff,
+                             int32_t P, const int32_t* gptr, int32_t num_graphs, const void* X,
+                             int64_t ldx, int32_t F, const float* bias, void* Y, int64_t ldy,
+                             void* stream);
+
 /* Layer 0 forward.  X0 [Nn,F0] (F0 <= 16), W0 [64,F0], bias [64] -> Y [Nn,64];
  * stat_slab [grid][128] fp64 (sum(y) | sum(y^2)) or NULL (eval). */
 int cgnn_gcn_fused_fwd_first(const cgnn_tiles* t, const float* X0, int32_t F0, const float* W0,

@@ -577,3 +577,31 @@ def test_optim_adam_matches_torch_adam(wd):
     assert float(oa.state[ps_a[0]]["step"]) == 11.0
     for p, q in zip(ps_a, ps_b):
         torch.testing.assert_close(p, q, rtol=5e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("sizes,deg", [([1000, 37, 500], 60), ([84] * 5, 8), ([1024], 100), ([64, 1, 200], 3),
+                                       ([1008, 3], 130), ([40, 33], 30)])
+def test_dense_per_fragment_operator_matches_dense(sizes, deg):
+    """cgnn_dense_pack_* + cgnn_dense_aggregate_c16 (nearly full MFMA fragments dense, the others as
+    entry lists, empty ones skipped) against the dense operator: the same MFMAs accumulated
+    dense-list-first, so equal up to the order of the fp32 accumulation -- and bit for bit when no
+    row block mixes the two kinds.  Forward and transposed, with a bias and without."""
+    from connectome_gnn_amd import ops
+    ei, w, ptr, bid, nn_ = _rand_graph_batch(sizes, deg, 17)
+    b = _batch(ei, w, ptr, bid, nn_, 128).to(DEV)
+    s = b.structure()
+    norm = s.gcn_norm()
+    x = b.node_features.half()
+    bias = torch.randn(128, generator=torch.Generator().manual_seed(1)).to(DEV)
+    for coef, tr in ((norm.coef_dst, False), (norm.coef_src, True)):
+        m = ops.dense_adj_f16(s, coef, norm.selfc, tr)
+        pk = ops.dense_pack_f16(s, coef, norm.selfc, tr)
+        assert pk.nnz == int((m != 0).sum())
+        for bb in (None, bias):
+            want = ops.dense_aggregate_f16_raw(s, m, x, bb)
+            got = ops.dense_aggregate_c16_raw(s, pk, x, bb)
+            if pk.num_dense == 0 or pk.num_sparse == 0:
+                assert torch.equal(got, want)
+            scale = float(want.float().abs().max())
+            torch.testing.assert_close(got.float(), want.float(), rtol=2e-3, atol=1e-3 * scale)
+            assert torch.equal(got, ops.dense_aggregate_c16_raw(s, pk, x, bb))      # deterministic

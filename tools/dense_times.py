@@ -17,17 +17,22 @@ s = b.structure()
 norm = s.gcn_norm()
 x16 = torch.randn(s.num_nodes, 256, device="cuda").half()
 mden = ops.dense_adj_f16(s, norm.coef_dst, norm.selfc)
+pk = ops.dense_pack_f16(s, norm.coef_dst, norm.selfc)
+print(f"  dense M {mden.numel() * 2 / 1e6:.1f} MB; per-fragment form {pk.nbytes() / 1e6:.1f} MB "
+      f"({pk.num_dense} dense + {pk.num_sparse} sparse fragments of {mden.numel() // 512})")
 junk = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
-for cold in (False, True):
-    ts = []
-    for _ in range(12):
-        if cold:
-            junk.fill_(1)
-        a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        ops.dense_aggregate_f16_raw(s, mden, x16)
-        e.record()
-        torch.cuda.synchronize()
-        ts.append(a.elapsed_time(e) * 1e3)
-    ts = sorted(ts[2:])
-    print(f"  dense_agg {'cold' if cold else 'warm'}: median {ts[len(ts) // 2]:7.1f} us")
+for name, fn in (("dense_agg ", lambda: ops.dense_aggregate_f16_raw(s, mden, x16)),
+                 ("packed_agg", lambda: ops.dense_aggregate_c16_raw(s, pk, x16))):
+    for cold in (False, True):
+        ts = []
+        for _ in range(12):
+            if cold:
+                junk.fill_(1)
+            a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            e.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(e) * 1e3)
+        ts = sorted(ts[2:])
+        print(f"  {name} {'cold' if cold else 'warm'}: median {ts[len(ts) // 2]:7.1f} us")

@@ -44,7 +44,11 @@ def alg_bytes(sz):
 out = {"workload": f"cfg5 scatter: {B} x {N}-ROI graphs, k={K} ({s.num_edges // B} edges/graph), hidden {H}",
        "hbm_peak_GBps": 8000.0, "results": []}
 mden = ops.dense_adj_f16(s, norm.coef_dst, norm.selfc)
+mpk = ops.dense_pack_f16(s, norm.coef_dst, norm.selfc)
+out["operator_MB"] = {"dense": round(mden.numel() * 2 / 1e6, 1), "per_fragment": round(mpk.nbytes() / 1e6, 1)}
 for name, fn, sz in (
+        ("cgnn_dense_aggregate_c16 (fp16 storage, per-fragment operator on the fp16 matrix cores)",
+         lambda: ops.dense_aggregate_c16_raw(s, mpk, x16), 2),
         ("cgnn_dense_aggregate_f16 (fp16 storage, dense M_g on the fp16 matrix cores)",
          lambda: ops.dense_aggregate_f16_raw(s, mden, x16), 2),
         ("cgnn_aggregate_tiled_f16 (fp16 storage, LDS tiles)",
