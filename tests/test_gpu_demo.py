@@ -87,6 +87,12 @@ def test_subject_structure_cache_equals_per_batch_build():
         assert torch.equal(a, c)
     for a, c in zip(outs[0][1], outs[1][1]):
         assert torch.equal(a, c)
+    # prefetched on the side stream (as Trainer.train_epoch consumes it): the same batches
+    torch.manual_seed(3)
+    ld2 = ResidentDataLoader(ds, batch_size=8, shuffle=True, structure_cache=True, prefetch=True)
+    for rb, rb2 in zip(batches, ld2):
+        assert torch.equal(rb._ids, rb2._ids) and torch.equal(rb.node_features, rb2.node_features)
+        assert torch.equal(rb.structure().gcn_dis(None), rb2.structure().gcn_dis(None))
     # the lazily assembled COO is the ordinary one
     ref = assemble_batch(ds, batches[0]._ids)
     assert batches[0]._coo is None
