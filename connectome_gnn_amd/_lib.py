@@ -80,10 +80,10 @@ PROTOTYPES = {
     "cgnn_head_bwd_f32": (c_int, [P, P, P, P, I32, I32, I32, I32, P, P, P, P, P]),
     "cgnn_cross_entropy_f32": (c_int, [P, P, I32, I32, P, P, P]),
     "cgnn_dense_adj_f16": (c_int, [P, P, P, P, P, I32, I32, P, P]),
-    "cgnn_dense_aggregate_f16": (c_int, [P, I32, P, I32, P, I64, I32, P, P, I64, P]),
+    "cgnn_dense_aggregate_f16": (c_int, [P, I32, P, I32, P, I64, I32, P, P, I64, P, P]),
     "cgnn_dense_pack_count": (c_int, [P, P, P, P, P, I32, I32, P, P]),
     "cgnn_dense_pack_fill": (c_int, [P, P, P, P, P, I32, I32, P, P, P, P, P, P]),
-    "cgnn_dense_aggregate_c16": (c_int, [P, P, P, P, P, P, I32, P, I32, P, I64, I32, P, P, I64, P]),
+    "cgnn_dense_aggregate_c16": (c_int, [P, P, P, P, P, P, I32, P, I32, P, I64, I32, P, P, I64, P, P]),
     "cgnn_linear_fwd_f32": (c_int, [P, I64, I32, P, I64, I32, P, P, I32, P, I64, I64, I32, P]),
     "cgnn_linear_fwd_stats_f32": (c_int, [P, I64, I32, P, I64, I32, P, P, I32, P, I64, I64, I32, P, P]),
     "cgnn_linear_bwd_input_f32": (c_int, [P, I64, P, I32, I32, P, I64, I64, I32, I32, P]),

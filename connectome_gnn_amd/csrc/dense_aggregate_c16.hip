@@ -123,8 +123,9 @@ __global__ void __launch_bounds__(C_THR) k_dense_agg_c(
     const __half* __restrict__ dfrag, const int32_t* __restrict__ dstep, const uint32_t* __restrict__ doff,
     const uint32_t* __restrict__ sent, const int32_t* __restrict__ sstep, const uint32_t* __restrict__ soff,
     int P, const int32_t* __restrict__ gptr, int B, const __half* __restrict__ X, int64_t ldx,
-    int nslices, const float* __restrict__ bias, __half* __restrict__ Y, int64_t ldy) {
-  extern __shared__ __attribute__((aligned(16))) __half Xt[];       // [64][KP], then the fragment slabs
+    int nslices, const float* __restrict__ bias, __half* __restrict__ Y, int64_t ldy,
+    double* __restrict__ stat_slab) {
+  extern __shared__ __attribute__((aligned(16))) __half Xt[];       // [64][KP], the fragment slabs, wacc
   const int KP = c_kp(P);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   __half* frag2 = Xt + 64 * KP + wave * 1024;                        // this wave's two [64 lanes][8] slabs
@@ -133,6 +134,12 @@ __global__ void __launch_bounds__(C_THR) k_dense_agg_c(
   // the slabs start (and are always left) all zero
   *reinterpret_cast<uint4*>(frag2 + 8 * lane) = make_uint4(0u, 0u, 0u, 0u);
   *reinterpret_cast<uint4*>(frag2 + 512 + 8 * lane) = make_uint4(0u, 0u, 0u, 0u);
+  // BatchNorm statistics of the (half-rounded) output, optional: per-wave partials go through the
+  // slab area (zero again afterwards), the workgroup's running column sums sit behind it
+  double* red = reinterpret_cast<double*>(Xt + 64 * KP);             // [C_NW][128] = the 24 KB of slabs
+  double* wacc = reinterpret_cast<double*>(Xt + 64 * KP + C_NW * 1024);   // [2][64 * nslices]
+  if (stat_slab)
+    for (int i = threadIdx.x; i < 128 * nslices; i += C_THR) wacc[i] = 0.0;
   for (int u = blockIdx.x; u < units; u += gridDim.x) {
     const int g = u / nslices, slice = u - g * nslices;
     const int base = gptr[g], n = gptr[g + 1] - base;
@@ -167,6 +174,7 @@ __global__ void __launch_bounds__(C_THR) k_dense_agg_c(
     }
     __syncthreads();
 
+    double st1[2] = {0.0, 0.0}, st2[2] = {0.0, 0.0};
     for (int rb = wave; 32 * rb < n; rb += C_NW) {
       const int64_t row = (int64_t)g * NRB + rb;
       const __half* b0 = Xt + r * KP + 8 * h;       // column 2r   (LDS row c/2 + 32*(c%2))
@@ -250,15 +258,46 @@ __global__ void __launch_bounds__(C_THR) k_dense_agg_c(
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int orow = 32 * rb + (q & 3) + 8 * (q >> 2) + 4 * h;
-        if (orow < n)
-          *reinterpret_cast<__half2*>(Y + (int64_t)(base + orow) * ldy + 64 * slice + 2 * r) =
-              __floats2half2_rn(acc0[q] + bia.x, acc1[q] + bia.y);
+        if (orow < n) {
+          const __half2 hv = __floats2half2_rn(acc0[q] + bia.x, acc1[q] + bia.y);
+          *reinterpret_cast<__half2*>(Y + (int64_t)(base + orow) * ldy + 64 * slice + 2 * r) = hv;
+          if (stat_slab) {
+            const float2 fv = __half22float2(hv);
+            st1[0] += fv.x; st1[1] += fv.y;
+            st2[0] += (double)fv.x * fv.x; st2[1] += (double)fv.y * fv.y;
+          }
+        }
       }
     }
+    if (stat_slab) {
+      __syncthreads();                               // every wave is done with its slabs
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        st1[t] += __shfl_xor(st1[t], 32, 64);
+        st2[t] += __shfl_xor(st2[t], 32, 64);
+        if (h == 0) { red[wave * 128 + 2 * r + t] = st1[t]; red[wave * 128 + 64 + 2 * r + t] = st2[t]; }
+      }
+      __syncthreads();
+      if (threadIdx.x < 128) {
+        double tot = 0.0;
+#pragma unroll
+        for (int w2 = 0; w2 < C_NW; ++w2) tot += red[w2 * 128 + threadIdx.x];
+        wacc[(threadIdx.x >> 6) * 64 * nslices + 64 * slice + (threadIdx.x & 63)] += tot;
+      }
+      __syncthreads();
+      *reinterpret_cast<uint4*>(frag2 + 8 * lane) = make_uint4(0u, 0u, 0u, 0u);        // slabs zero again
+      *reinterpret_cast<uint4*>(frag2 + 512 + 8 * lane) = make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
+  if (stat_slab) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 128 * nslices; i += C_THR) stat_slab[(int64_t)blockIdx.x * 128 * nslices + i] = wacc[i];
   }
 }
 
-size_t c_lds(int P) { return ((size_t)64 * c_kp(P) + (size_t)C_NW * 1024) * sizeof(__half); }
+size_t c_lds(int P, int F) {
+  return ((size_t)64 * c_kp(P) + (size_t)C_NW * 1024) * sizeof(__half) + (size_t)2 * F * sizeof(double);
+}
 
 bool pack_attr() {
   static bool done[CGNN_MAX_DEVICES] = {};
@@ -269,7 +308,7 @@ bool pack_attr() {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_dense_pack<true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 32 * C_MAXP * 4) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_dense_agg_c),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)c_lds(C_MAXP)) != hipSuccess)
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return false;
     d = true;
   }
@@ -315,16 +354,16 @@ int cgnn_dense_aggregate_c16(const void* dfrag, const int32_t* dstep, const uint
                              const uint32_t* sent, const int32_t* sstep, const uint32_t* soff,
                              int32_t P, const int32_t* gptr, int32_t num_graphs, const void* X,
                              int64_t ldx, int32_t F, const float* bias, void* Y, int64_t ldy,
-                             void* stream) {
+                             double* stat_slab, void* stream) {
   if (num_graphs < 0 || P <= 0 || F <= 0 || ldx < F || ldy < F) return CGNN_EINVAL;
-  if (P > C_MAXP || P % 64 || F % 64 || ldx % 8) return CGNN_EUNSUPPORTED;
+  if (P > C_MAXP || P % 64 || F % 64 || ldx % 8 || c_lds(P, F) > 160 * 1024) return CGNN_EUNSUPPORTED;
   if (reinterpret_cast<uintptr_t>(X) & 15) return CGNN_EUNSUPPORTED;
   if (num_graphs == 0) return CGNN_OK;
   if (!dfrag || !dstep || !doff || !sent || !sstep || !soff || !gptr || !X || !Y) return CGNN_EINVAL;
   if (!pack_attr()) return CGNN_ELAUNCH;
-  k_dense_agg_c<<<cgnn_fused_grid(), C_THR, c_lds(P), cgnn_stream(stream)>>>(
+  k_dense_agg_c<<<cgnn_fused_grid(), C_THR, c_lds(P, F), cgnn_stream(stream)>>>(
       static_cast<const __half*>(dfrag), dstep, doff, sent, sstep, soff, P, gptr, num_graphs,
-      static_cast<const __half*>(X), ldx, F / 64, bias, static_cast<__half*>(Y), ldy);
+      static_cast<const __half*>(X), ldx, F / 64, bias, static_cast<__half*>(Y), ldy, stat_slab);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }

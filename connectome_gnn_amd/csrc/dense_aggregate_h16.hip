@@ -85,9 +85,15 @@ __global__ void __launch_bounds__(256) k_dense_adj(
 __global__ void __launch_bounds__(D_THR) k_dense_agg(
     const __half* __restrict__ M, int P, const int32_t* __restrict__ gptr, int B,
     const __half* __restrict__ X, int64_t ldx, int nslices, const float* __restrict__ bias,
-    __half* __restrict__ Y, int64_t ldy) {
-  extern __shared__ __attribute__((aligned(16))) __half Xt[];       // [64][KP]
+    __half* __restrict__ Y, int64_t ldy, double* __restrict__ stat_slab) {
+  extern __shared__ __attribute__((aligned(16))) __half Xt[];       // [64][KP] (+ statistics scratch)
   const int KP = d_kp(P);
+  // BatchNorm statistics of the (half-rounded) output, optional: per-wave partials -> red, the
+  // workgroup's running column sums -> wacc [2][64 * nslices], one slab row per workgroup at the end
+  double* red = reinterpret_cast<double*>(Xt + 64 * KP);             // [D_NW][128]
+  double* wacc = red + D_NW * 128;                                   // [2][64 * nslices]
+  if (stat_slab)
+    for (int i = threadIdx.x; i < 128 * nslices; i += D_THR) wacc[i] = 0.0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int units = B * nslices;
   // unit order: the slices of one graph sit on workgroups of the same XCD (blockIdx % 8)
@@ -140,6 +146,7 @@ __global__ void __launch_bounds__(D_THR) k_dense_agg(
     __syncthreads();
 
     const __half* Mg = M + (int64_t)g * P * P;
+    double st1[2] = {0.0, 0.0}, st2[2] = {0.0, 0.0};
     for (int rb = wave; 32 * rb < n; rb += D_NW) {
       // rows >= n of M are zero
       // M is stored fragment-major: the A operand of (row block rb, step s) is 1 KB contiguous,
@@ -180,11 +187,37 @@ __global__ void __launch_bounds__(D_THR) k_dense_agg(
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int row = 32 * rb + (q & 3) + 8 * (q >> 2) + 4 * h;
-        if (row < n)
-          *reinterpret_cast<__half2*>(Y + (int64_t)(base + row) * ldy + 64 * slice + 2 * r) =
-              __floats2half2_rn(acc0[q] + bia.x, acc1[q] + bia.y);
+        if (row < n) {
+          const __half2 hv = __floats2half2_rn(acc0[q] + bia.x, acc1[q] + bia.y);
+          *reinterpret_cast<__half2*>(Y + (int64_t)(base + row) * ldy + 64 * slice + 2 * r) = hv;
+          if (stat_slab) {
+            const float2 fv = __half22float2(hv);
+            st1[0] += fv.x; st1[1] += fv.y;
+            st2[0] += (double)fv.x * fv.x; st2[1] += (double)fv.y * fv.y;
+          }
+        }
       }
     }
+    if (stat_slab) {
+      // fold the two row halves, the waves (fixed order), then add to the workgroup's sums
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        st1[t] += __shfl_xor(st1[t], 32, 64);
+        st2[t] += __shfl_xor(st2[t], 32, 64);
+        if (h == 0) { red[wave * 128 + 2 * r + t] = st1[t]; red[wave * 128 + 64 + 2 * r + t] = st2[t]; }
+      }
+      __syncthreads();
+      if (threadIdx.x < 128) {
+        double tot = 0.0;
+#pragma unroll
+        for (int w2 = 0; w2 < D_NW; ++w2) tot += red[w2 * 128 + threadIdx.x];
+        wacc[(threadIdx.x >> 6) * 64 * nslices + 64 * slice + (threadIdx.x & 63)] += tot;
+      }
+    }
+  }
+  if (stat_slab) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 128 * nslices; i += D_THR) stat_slab[(int64_t)blockIdx.x * 128 * nslices + i] = wacc[i];
   }
 }
 
@@ -207,24 +240,26 @@ int cgnn_dense_adj_f16(const int32_t* rowptr, const int32_t* col, const float* c
 
 int cgnn_dense_aggregate_f16(const void* M, int32_t P, const int32_t* gptr, int32_t num_graphs,
                              const void* X, int64_t ldx, int32_t F, const float* bias, void* Y,
-                             int64_t ldy, void* stream) {
+                             int64_t ldy, double* stat_slab, void* stream) {
   if (num_graphs < 0 || P <= 0 || F <= 0 || ldx < F || ldy < F) return CGNN_EINVAL;
   if (P > D_MAXP || P % 64 || F % 64 || ldx % 8) return CGNN_EUNSUPPORTED;
+  if ((size_t)64 * d_kp(P) * sizeof(__half) + (size_t)(D_NW * 128 + 2 * F) * sizeof(double) > 160 * 1024)
+    return CGNN_EUNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(M)) & 15) return CGNN_EUNSUPPORTED;
   if (num_graphs == 0) return CGNN_OK;
   if (!M || !gptr || !X || !Y) return CGNN_EINVAL;
-  const size_t lds = (size_t)64 * d_kp(P) * sizeof(__half);
+  const size_t lds = (size_t)64 * d_kp(P) * sizeof(__half) + (size_t)(D_NW * 128 + 2 * F) * sizeof(double);
   static bool attr_set_dev[CGNN_MAX_DEVICES] = {};
   bool& attr_set = attr_set_dev[cgnn_device_ordinal()];
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_dense_agg),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 64 * d_kp(D_MAXP) * 2) != hipSuccess)
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return CGNN_ELAUNCH;
     attr_set = true;
   }
   k_dense_agg<<<cgnn_fused_grid(), D_THR, lds, cgnn_stream(stream)>>>(
       static_cast<const __half*>(M), P, gptr, num_graphs, static_cast<const __half*>(X), ldx, F / 64,
-      bias, static_cast<__half*>(Y), ldy);
+      bias, static_cast<__half*>(Y), ldy, stat_slab);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }

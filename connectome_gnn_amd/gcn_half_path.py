@@ -54,10 +54,10 @@ def eligible(model, batch, structure: BatchStructure) -> Optional[str]:
     return None
 
 
-def _agg(s, m, x, bias=None):
+def _agg(s, m, x, bias=None, stat_slab=None):
     if isinstance(m, ops.DensePack):
-        return ops.dense_aggregate_c16_raw(s, m, x, bias)
-    return ops.dense_aggregate_f16_raw(s, m, x, bias)
+        return ops.dense_aggregate_c16_raw(s, m, x, bias, stat_slab)
+    return ops.dense_aggregate_f16_raw(s, m, x, bias, stat_slab)
 
 
 PACK_BELOW = 0.6       # use the per-fragment operator when it is at most this fraction of the dense bytes
@@ -146,19 +146,22 @@ class GcnHalfEncode(torch.autograd.Function):
                     sv.p0 = _agg(s, mf, x0h)        # [Nn, 64] half, cols >= F0 zero
                     wh = w.half()
                     y = torch.addmm(b.half(), sv.p0[:, :f0], wh.t())
-                else:
+                slab, srows = None, rows
+                if li > 0:
                     wh = w.half()
                     t = torch.matmul(x, wh.t())                            # half GEMM, fp32 accumulate
-                    y = _agg(s, mf, t, b)
-                slab = None
-                if training:
+                    if training:                                           # statistics in the epilogue
+                        srows = int(lib.cgnn_fused_grid())
+                        slab = torch.empty(srows, 2 * hid, dtype=torch.float64, device=dev)
+                    y = _agg(s, mf, t, b, slab)
+                if training and slab is None:
                     slab = torch.empty(rows, 2 * hid, dtype=torch.float64, device=dev)
                     _lib.check(lib.cgnn_bn_act_fwd_stats_f16(_lib.ptr(y), n_nodes, hid, _lib.ptr(slab), sp),
                                "cgnn_bn_act_fwd_stats_f16")
                 bn = bns_mod[li]
                 coef = _f32(dev, 4 * hid)
                 _lib.check(lib.cgnn_bn_act_finalize(
-                    _lib.ptr(slab), rows, hid, float(max(n_nodes, 1)), None, int(training), _lib.ptr(gamma),
+                    _lib.ptr(slab), srows, hid, float(max(n_nodes, 1)), None, int(training), _lib.ptr(gamma),
                     _lib.ptr(beta), _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var), float(bn.momentum),
                     float(bn.eps), _lib.ptr(bn.num_batches_tracked) if training else None, _lib.ptr(coef), sp),
                     "cgnn_bn_act_finalize")

@@ -167,8 +167,9 @@ def dense_adj_f16(structure, coef, selfc, transposed: bool = False) -> torch.Ten
     return m
 
 
-def dense_aggregate_f16_raw(structure, m, x, bias=None) -> torch.Tensor:
-    """Y_g = M_g X_g on the fp16 matrix cores (cgnn_dense_aggregate_f16); x, result half."""
+def dense_aggregate_f16_raw(structure, m, x, bias=None, stat_slab=None) -> torch.Tensor:
+    """Y_g = M_g X_g on the fp16 matrix cores (cgnn_dense_aggregate_f16); x, result half.
+    stat_slab: optional fp64 [cgnn_fused_grid(), 2F] for the result's BatchNorm sums."""
     lib = _lib.load()
     _require_device(x, "x")
     if x.dtype != torch.float16 or m.dtype != torch.float16:
@@ -178,7 +179,7 @@ def dense_aggregate_f16_raw(structure, m, x, bias=None) -> torch.Tensor:
     with _lib.device_guard(x.device), _lib.timed("cgnn_dense_aggregate_f16", f"F={f}"):
         _lib.check(lib.cgnn_dense_aggregate_f16(
             _lib.ptr(m), m.shape[1], _lib.ptr(structure.gptr), structure.num_graphs, _lib.ptr(x),
-            x.stride(0), f, _lib.ptr(bias), _lib.ptr(y), y.stride(0), _lib.stream_ptr()),
+            x.stride(0), f, _lib.ptr(bias), _lib.ptr(y), y.stride(0), _lib.ptr(stat_slab), _lib.stream_ptr()),
             "cgnn_dense_aggregate_f16")
     return y
 
@@ -236,7 +237,7 @@ def dense_pack_f16(structure, coef, selfc, transposed: bool = False) -> DensePac
     return pk
 
 
-def dense_aggregate_c16_raw(structure, pack: DensePack, x, bias=None) -> torch.Tensor:
+def dense_aggregate_c16_raw(structure, pack: DensePack, x, bias=None, stat_slab=None) -> torch.Tensor:
     """Y_g = M_g X_g from the per-fragment operator (cgnn_dense_aggregate_c16); x, result half."""
     lib = _lib.load()
     _require_device(x, "x")
@@ -249,7 +250,7 @@ def dense_aggregate_c16_raw(structure, pack: DensePack, x, bias=None) -> torch.T
             _lib.ptr(pack.dfrag), _lib.ptr(pack.dstep), _lib.ptr(pack.doff), _lib.ptr(pack.sent),
             _lib.ptr(pack.sstep), _lib.ptr(pack.soff), pack.pitch, _lib.ptr(structure.gptr),
             structure.num_graphs, _lib.ptr(x), x.stride(0), f, _lib.ptr(bias), _lib.ptr(y), y.stride(0),
-            _lib.stream_ptr()), "cgnn_dense_aggregate_c16")
+            _lib.ptr(stat_slab), _lib.stream_ptr()), "cgnn_dense_aggregate_c16")
     return y
 
 

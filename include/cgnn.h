@@ -300,8 +300,11 @@ int cgnn_dense_adj_f16(const int32_t* rowptr, const int32_t* col, const float* c
                        void* M, void* stream);
 int cgnn_dense_aggregate_f16(const void* M, int32_t P, const int32_t* gptr, int32_t num_graphs,
                              const void* X, int64_t ldx, int32_t F, const float* bias, void* Y,
-                             int64_t ldy, void* stream);
+                             int64_t ldy, double* stat_slab, void* stream);
 
+/* stat_slab (both aggregates; NULL = none): [cgnn_fused_grid()][2 * F] fp64 per-workgroup column sums
+ * and sums of squares of the half-rounded result (BatchNorm statistics in the epilogue; finalise with
+ * cgnn_bn_act_finalize(slab, cgnn_fused_grid(), F, ...)). */
 /* The same operator stored per MFMA A fragment (32 rows x 16 sources) in the form that fits it:
  * fragments with more than 64 non-zeros in a DENSE list (1 KB each, operand-major, `dfrag`), those
  * with 1..64 in a SPARSE list (one chunk of 64 (slot | half value << 16) words each, padding slot
@@ -326,7 +329,7 @@ int cgnn_dense_aggregate_c16(const void* dfrag, const int32_t* dstep, const uint
                              const uint32_t* sent, const int32_t* sstep, const uint32_t* soff,
                              int32_t P, const int32_t* gptr, int32_t num_graphs, const void* X,
                              int64_t ldx, int32_t F, const float* bias, void* Y, int64_t ldy,
-                             void* stream);
+                             double* stat_slab, void* stream);
 
 /* Layer 0 forward.  X0 [Nn,F0] (F0 <= 16), W0 [64,F0], bias [64] -> Y [Nn,64];
  * stat_slab [grid][128] fp64 (sum(y) | sum(y^2)) or NULL (eval). */

@@ -605,3 +605,13 @@ def test_dense_per_fragment_operator_matches_dense(sizes, deg):
             scale = float(want.float().abs().max())
             torch.testing.assert_close(got.float(), want.float(), rtol=2e-3, atol=1e-3 * scale)
             assert torch.equal(got, ops.dense_aggregate_c16_raw(s, pk, x, bb))      # deterministic
+        # BatchNorm statistics in the epilogue: column sums / sums of squares of the half result
+        from connectome_gnn_amd import _lib
+        grid = int(_lib.load().cgnn_fused_grid())
+        for fn, op in ((ops.dense_aggregate_f16_raw, m), (ops.dense_aggregate_c16_raw, pk)):
+            slab = torch.full((grid, 2 * 128), float("nan"), dtype=torch.float64, device=DEV)
+            y = fn(s, op, x, bias, slab)
+            assert torch.equal(y, fn(s, op, x, bias))
+            yd = y.double()
+            torch.testing.assert_close(slab.sum(0)[:128], yd.sum(0), rtol=1e-9, atol=1e-7)
+            torch.testing.assert_close(slab.sum(0)[128:], (yd * yd).sum(0), rtol=1e-9, atol=1e-7)
