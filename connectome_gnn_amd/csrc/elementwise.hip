@@ -347,36 +347,37 @@ __global__ void __launch_bounds__(256) k_bn_act_apply(
 // One 1024-thread block per graph at a time; X' itself is never written.
 constexpr int PTHR = 1024;
 
+// grid = num_graphs * CS workgroups (capped): workgroup (g, cs) pools columns [cs, cs + 1) * N / CS of
+// graph g -- with few large graphs (64 x 1000-ROI) one workgroup per graph leaves most CUs idle
 template <typename T>
 __global__ void __launch_bounds__(PTHR) k_bn_act_pool_fwd(
     const T* __restrict__ Y, const float* __restrict__ coef, int relu, DropCfg drop, int use_drop,
     uint8_t* __restrict__ mask_out, const int32_t* __restrict__ gptr, int B, float* __restrict__ P,
-    int N) {
+    int N, int CS) {
   if (drop.dev_key) drop.key1 ^= drop.dev_key[0];
-  extern __shared__ float pred[];                    // [rpp][N]
-  const int nch = N >> 2;
-  const int c = threadIdx.x % nch, rr = threadIdx.x / nch, rpp = PTHR / nch;
-  const float4 ca = ld4(coef + 4 * c), cb = ld4(coef + N + 4 * c);
-  for (int g = blockIdx.x; g < B; g += gridDim.x) {
+  extern __shared__ float pred[];                    // [rpp][N / CS]
+  const int nch = N >> 2, nchb = nch / CS, NB = N / CS;
+  const int cl = threadIdx.x % nchb, rr = threadIdx.x / nchb, rpp = PTHR / nchb;
+  for (int u = blockIdx.x; u < B * CS; u += gridDim.x) {
+    const int g = u / CS, c = (u - g * CS) * nchb + cl;
+    const float4 ca = ld4(coef + 4 * c), cb = ld4(coef + N + 4 * c);
     const int rbeg = gptr[g], rend = gptr[g + 1];
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    // rows in flight per thread: a block owns a whole graph, so with few graphs (64 x 1000-ROI)
-    // only that many CUs work and each is bound by its own load latency
-    constexpr int U = 8;
+    constexpr int U = 8;                             // rows in flight per thread
     for (int row0 = rbeg + rr; row0 < rend; row0 += U * rpp) {
       float4 yb[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int row = row0 + u * rpp;
-        yb[u] = row < rend ? ldnt4(Y + ((int64_t)row * nch + c) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int u2 = 0; u2 < U; ++u2) {
+        const int row = row0 + u2 * rpp;
+        yb[u2] = row < rend ? ldnt4(Y + ((int64_t)row * nch + c) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int row = row0 + u * rpp;
+      for (int u2 = 0; u2 < U; ++u2) {
+        const int row = row0 + u2 * rpp;
         if (row < rend) {
           const int64_t i = (int64_t)row * nch + c;
-          const float zx = fmaf(ca.x, yb[u].x, cb.x), zy = fmaf(ca.y, yb[u].y, cb.y);
-          const float zz = fmaf(ca.z, yb[u].z, cb.z), zw = fmaf(ca.w, yb[u].w, cb.w);
+          const float zx = fmaf(ca.x, yb[u2].x, cb.x), zy = fmaf(ca.y, yb[u2].y, cb.y);
+          const float zz = fmaf(ca.z, yb[u2].z, cb.z), zw = fmaf(ca.w, yb[u2].w, cb.w);
           uint32_t kb = 0xFu;
           if (use_drop) {
             kb = drop_bits(drop, (uint32_t)i);
@@ -389,12 +390,12 @@ __global__ void __launch_bounds__(PTHR) k_bn_act_pool_fwd(
         }
       }
     }
-    if (rr < rpp) st4(pred + rr * N + 4 * c, s);
+    if (rr < rpp) st4(pred + rr * NB + 4 * cl, s);
     __syncthreads();
-    for (int e = threadIdx.x; e < N; e += PTHR) {
+    for (int e = threadIdx.x; e < NB; e += PTHR) {
       float tot = 0.f;
-      for (int k = 0; k < rpp; ++k) tot += pred[k * N + e];
-      P[(int64_t)g * N + e] = tot / ((float)(rend - rbeg) + 1e-8f);
+      for (int k = 0; k < rpp; ++k) tot += pred[k * NB + e];
+      P[(int64_t)g * N + (u - g * CS) * NB + e] = tot / ((float)(rend - rbeg) + 1e-8f);
     }
     __syncthreads();
   }
@@ -464,10 +465,14 @@ int bn_act_pool_fwd_t(const T* Y, const float* coef, int32_t relu, float p_drop,
   int use_drop;
   DropCfg d = make_drop(p_drop, seed, &use_drop);
   d.dev_key = seed_dev;
-  const int rpp = PTHR / (N >> 2);
-  const unsigned grid = (unsigned)(num_graphs < 2048 ? num_graphs : 2048);
-  k_bn_act_pool_fwd<T><<<grid, PTHR, (size_t)rpp * N * sizeof(float), cgnn_stream(stream)>>>(
-      Y, coef, relu, d, use_drop, mask_out, gptr, num_graphs, P, N);
+  // column splits: enough workgroups to fill the chip when the batch has few graphs
+  int cs = 1;
+  while (cs < 8 && num_graphs * cs < cgnn_fused_grid() && (N >> 2) / (2 * cs) >= 4) cs *= 2;
+  const int rpp = PTHR / ((N >> 2) / cs);
+  const int64_t units = (int64_t)num_graphs * cs;
+  const unsigned grid = (unsigned)(units < 2048 ? units : 2048);
+  k_bn_act_pool_fwd<T><<<grid, PTHR, (size_t)rpp * (N / cs) * sizeof(float), cgnn_stream(stream)>>>(
+      Y, coef, relu, d, use_drop, mask_out, gptr, num_graphs, P, N, cs);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }

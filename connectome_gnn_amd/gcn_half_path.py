@@ -99,7 +99,7 @@ def _weight_grad(dt: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     per = rows // chunks
     part = torch.bmm(dt[:rows].view(chunks, per, dt.shape[1]).transpose(1, 2),
                      x[:rows].view(chunks, per, x.shape[1]))
-    dw = part.float().sum(0)
+    dw = torch.sum(part, 0, dtype=torch.float32)       # fp32 accumulation, no separate cast pass
     if rows < n:
         dw += torch.matmul(dt[rows:].t(), x[rows:]).float()
     return dw
