@@ -407,7 +407,10 @@ bool width_ok(int N) { return N >= 4 && N <= 1024 && (N & (N - 1)) == 0; }
 // pass is then bound by the latency of each block's own loads
 int stat_rows(int64_t M) {
   int r = ROWS;
-  while (r > 32 && (M + r - 1) / r < 1024) r >>= 1;
+#ifndef EW_STAT_BLOCKS
+#define EW_STAT_BLOCKS 1024
+#endif
+  while (r > 32 && (M + r - 1) / r < EW_STAT_BLOCKS) r >>= 1;
   return r;
 }
 int stat_blocks(int64_t M) { const int r = stat_rows(M); return (int)((M + r - 1) / r); }
