@@ -789,3 +789,34 @@ def test_backward_unit_equals_backward():
     (2.0 * ops.cross_entropy(m(b), b.labels)).backward()
     for a, p in zip(grads[0], m.parameters()):
         torch.testing.assert_close(p.grad, 2.0 * a, rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("kind", ["gcn", "sage"])
+def test_relabel_by_degree_is_an_invariance(kind):
+    """PackedDataset.relabel_by_degree renumbers every subject's nodes; logits, loss and gradients
+    of both models are those of the original numbering up to the order of the sums."""
+    from connectome_gnn_amd.resident import assemble_batch
+    from connectome_gnn_amd.synthetic import generate_packed
+    ds = generate_packed(6, 360, 14, seed=8).to(DEV)
+    ds2 = ds.relabel_by_degree()
+    ids = torch.arange(6, device=DEV)
+    outs = []
+    for d in (ds, ds2):
+        torch.manual_seed(5)
+        m = _model(kind, 5, 64, dropout=0.0).to(DEV).train()
+        b = assemble_batch(d, ids)
+        lg = m(b)
+        loss = torch.nn.functional.cross_entropy(lg, b.labels)
+        loss.backward()
+        outs.append((lg.detach(), loss.detach(), [p.grad.clone() for p in m.parameters()]))
+    # the same multiset of degrees per subject, now non-increasing along the node index
+    def degrees(d):
+        z = torch.zeros(6, 360, dtype=torch.long, device=DEV)
+        return z.scatter_add_(1, d.edge_local[:, 1], torch.ones_like(d.edge_local[:, 1])) \
+                .scatter_add_(1, d.edge_local[:, 0], torch.ones_like(d.edge_local[:, 0]))
+    d1, d2 = degrees(ds), degrees(ds2)
+    assert bool((d2[:, 1:] <= d2[:, :-1]).all()) and torch.equal(d1.sort(1).values, d2.sort(1).values)
+    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(outs[0][1], outs[1][1], rtol=2e-5, atol=2e-6)
+    for a, c in zip(outs[0][2], outs[1][2]):
+        torch.testing.assert_close(a, c, rtol=1e-3, atol=1e-5 * float(a.abs().max()) + 2e-6)
