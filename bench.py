@@ -201,6 +201,8 @@ def main() -> None:
     ap.add_argument("--graph", action="store_true", help="same as --launch graph")
     ap.add_argument("--collectives", default="split", choices=["split", "captured"],
                     help="graph launch at N > 1: all-reduce between two graphs, or captured inside one")
+    ap.add_argument("--node-order", default="dataset", choices=["dataset", "degree"],
+                    help="degree: PackedDataset.relabel_by_degree() before batching (an invariance of the models)")
     ap.add_argument("--optimizer", default="cgnn", choices=["cgnn", "torch"],
                     help="cgnn: connectome_gnn_amd.optim.Adam (one launch); torch: torch.optim.Adam(fused=True)")
     ap.add_argument("--no-end-to-end", action="store_true",
@@ -248,6 +250,8 @@ def main() -> None:
 
     # ---- data: this rank's shard of the synthetic dataset, resident in HBM ------------------
     ds = generate_packed(bsz, n, k, seed=42 + rank).to(dev)
+    if args.node_order == "degree":
+        ds = ds.relabel_by_degree()
     g = torch.Generator().manual_seed(1234 + rank)
     batches = []
     for _ in range(max(1, args.nbuf)):
@@ -391,7 +395,7 @@ def main() -> None:
             "dtype": "f16" if storage == "fp16" else "f32",
             "data": "synthetic",
             "config": {"workload": args.workload, "model": model_kind, "rois": n, "ws_k": k,
-                       "edges_per_graph": e, "hidden": hidden, "layers": 3,
+                       "edges_per_graph": e, "hidden": hidden, "layers": 3, "node_order": args.node_order,
                        "graphs_per_gpu": bsz, "global_batch": global_batch, "dropout": 0.3,
                        "optimizer": "Adam lr1e-3 wd1e-4" + (" (torch fused)" if args.optimizer == "torch" else " (optim.Adam)"), "impl": impl_used,
                        "launch": ("hip-graph replay" + (f" ({collectives} all-reduce)" if world > 1 else ""))
@@ -408,7 +412,8 @@ def main() -> None:
                          "algorithmic_bytes_per_launch": dom_bytes},
             "final_loss": final_loss,
         }
-        if world == 1 and not args.no_end_to_end and graphed is None and fused_kind == "tile":
+        if world == 1 and not args.no_end_to_end and graphed is None and fused_kind == "tile" \
+                and args.node_order == "dataset":
             # the same step on the same graphs with every subject's nodes renumbered by degree
             # (PackedDataset.relabel_by_degree: a one-off preprocessing of the dataset; the models
             # are invariant under it): less blocked-ELL padding for the tile kernels to walk
