@@ -114,6 +114,7 @@ PROTOTYPES = {
     "cgnn_bell_plan": (c_int, [P, P, I32, I32, P, P, P, P]),
     "cgnn_bell_fill": (c_int, [P, P, I32, P, P, P, P, F32, P, P, P]),
     "cgnn_aggregate_tiled_f32": (c_int, [TP, I32, P, I64, I32, P, P, P, P, I64, P, I64, P]),
+    "cgnn_aggregate_tiled_bn_f32": (c_int, [TP, I32, P, I64, I32, P, P, P, P, I64, P, I32, F32, U64, P, P, P, I64, P]),
     "cgnn_gather_f32": (c_int, [P, P, I64, P, P]),
     "cgnn_gcn_dis": (c_int, [P, P, I64, P, P]),
     "cgnn_fused_grid": (c_int, []),

@@ -137,6 +137,22 @@ def aggregate_tiled_raw(structure, meta, flags: int, x, pre, post, bias, yadd=No
     return y
 
 
+def aggregate_tiled_bn_raw(structure, meta, flags: int, z, pre, post, bias, coef, relu: bool, p: float,
+                           seed: int, seed_dev, mask, xout) -> torch.Tensor:
+    """Y = post * A(pre * X) (+bias) with X = drop(act(a z + b)) formed while the tiles are staged and
+    also written to ``xout`` (keep bytes to ``mask``): cgnn_aggregate_tiled_bn_f32."""
+    lib = _lib.load()
+    n, f = z.shape
+    y = torch.empty(n, f, dtype=torch.float32, device=z.device)
+    tiles = structure.tiles_struct(meta)
+    with _lib.device_guard(z.device), _lib.timed("cgnn_aggregate_tiled_f32", f"F={f}"):
+        _lib.check(lib.cgnn_aggregate_tiled_bn_f32(
+            ctypes.byref(tiles), int(flags), _lib.ptr(z), z.stride(0), f, _lib.ptr(pre), _lib.ptr(post),
+            _lib.ptr(bias), _lib.ptr(y), y.stride(0), _lib.ptr(coef), int(relu), float(p), int(seed), seed_dev,
+            _lib.ptr(mask), _lib.ptr(xout), xout.stride(0), _lib.stream_ptr()), "cgnn_aggregate_tiled_bn_f32")
+    return y
+
+
 def aggregate_tiled_f16_raw(structure, meta, flags: int, x, pre, post, bias) -> torch.Tensor:
     """fp16-storage / fp32-accumulate tiled aggregate (cgnn_aggregate_tiled_f16): x, result half."""
     lib = _lib.load()

@@ -173,9 +173,25 @@ class SageEncode(torch.autograd.Function):
             if rng is not None and p > 0:
                 _lib.check(lib.cgnn_rng_advance(_lib.ptr(rng), L + 1, st()), "cgnn_rng_advance")
             rows = int(lib.cgnn_bn_act_slab_rows(n_nodes))
+            pending = None        # (z, coef, seed, rw, mask) of the previous layer: its BatchNorm+dropout
+                                  # is applied by the consumer below, not by a pass of its own
             for li in range(L):
                 w, b, gamma, beta = (t.contiguous() for t in params[4 * li:4 * li + 4])
                 hid = w.shape[0]
+                agg = None
+                if pending is not None:
+                    pz, pcoef, pseed, prw, pmask = pending
+                    x = torch.empty_like(pz)
+                    if s.tiled_ok(pz.shape[1]):
+                        # X' = drop(BatchNorm(Z)) formed while the aggregate stages its tiles (and
+                        # written out for the projection): no apply pass
+                        agg = ops.aggregate_tiled_bn_raw(s, sv.ell, ops.AGG_POST_DIV, pz, None, sv.norm.den, None,
+                                                         pcoef, False, p, pseed, prw, pmask, x)
+                    else:
+                        _lib.check(lib.cgnn_bn_act_fwd_apply(_lib.ptr(pz), _lib.ptr(pcoef), 0, p, pseed, prw,
+                                                             _lib.ptr(pmask), _lib.ptr(x), n_nodes, pz.shape[1], st()),
+                                   "cgnn_bn_act_fwd_apply")
+                    pending = None
                 fin = x.shape[1]
                 slab = None
                 srows = rows
@@ -190,7 +206,8 @@ class SageEncode(torch.autograd.Function):
                     sv.xa0 = xa
                     gemm_in = (xa, None, wp)
                 else:
-                    agg = _agg_fwd(s, sv.ell, sv.norm, x)
+                    if agg is None:
+                        agg = _agg_fwd(s, sv.ell, sv.norm, x)
                     gemm_in = (x, agg, w)
                 z = None
                 if training:
@@ -220,11 +237,7 @@ class SageEncode(torch.autograd.Function):
                                                         _lib.ptr(pooled), hid, st()),
                                "cgnn_bn_act_pool_fwd")
                     break
-                xn = torch.empty_like(z)
-                _lib.check(lib.cgnn_bn_act_fwd_apply(_lib.ptr(z), _lib.ptr(coef), 0, p, seed, rw,
-                                                     _lib.ptr(mask), _lib.ptr(xn), n_nodes, hid, st()),
-                           "cgnn_bn_act_fwd_apply")
-                x = xn
+                pending = (z, coef, seed, rw, mask)
         if cfg.get("record") is not None:
             cfg["record"]["layers"] = list(sv.masks)
         ctx.sv = sv

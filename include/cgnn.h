@@ -276,6 +276,15 @@ int cgnn_fused_grid(void);
 int cgnn_aggregate_tiled_f32(const cgnn_tiles* t, int32_t flags, const float* X, int64_t ldx,
                              int32_t F, const float* pre, const float* post, const float* bias,
                              const float* Yadd, int64_t ldadd, float* Y, int64_t ldy, void* stream);
+/* The same with BatchNorm(+ReLU)+dropout of the input applied while staging: X = drop(act(a Z + b)),
+ * coef = [a | b | ..] of cgnn_bn_act_finalize over the F columns; X is also written to Xout and its
+ * keep bytes to mask_out ([num_nodes][F/4], may be NULL) -- cgnn_bn_act_fwd_apply +
+ * cgnn_aggregate_tiled_f32 in one launch, bit for bit. */
+int cgnn_aggregate_tiled_bn_f32(const cgnn_tiles* t, int32_t flags, const float* Z, int64_t ldz,
+                                int32_t F, const float* pre, const float* post, const float* bias,
+                                float* Y, int64_t ldy, const float* coef, int32_t relu,
+                                float p_drop, uint64_t seed, const uint32_t* seed_dev,
+                                uint8_t* mask_out, float* Xout, int64_t ldxo, void* stream);
 
 /* fp16-storage / fp32-accumulate form of cgnn_aggregate_tiled_f32 for large dense parcellations
  * (BASELINE config 5: 1000-ROI graphs, 10 % density, hidden 256): X, Y are IEEE half [Nn, F],

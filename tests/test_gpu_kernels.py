@@ -615,3 +615,32 @@ def test_dense_per_fragment_operator_matches_dense(sizes, deg):
             yd = y.double()
             torch.testing.assert_close(slab.sum(0)[:128], yd.sum(0), rtol=1e-9, atol=1e-7)
             torch.testing.assert_close(slab.sum(0)[128:], (yd * yd).sum(0), rtol=1e-9, atol=1e-7)
+
+
+@pytest.mark.parametrize("p", [0.0, 0.3])
+def test_aggregate_tiled_with_bn_prologue_equals_two_passes(p):
+    """cgnn_aggregate_tiled_bn_f32 (BatchNorm + dropout of the input applied while the tiles are
+    staged, X' and its keep bytes written on the side) == cgnn_bn_act_fwd_apply followed by
+    cgnn_aggregate_tiled_f32, bit for bit."""
+    from connectome_gnn_amd import _lib, ops
+    ei, w, ptr, bid, nn_ = _rand_graph_batch([360, 7, 360, 84], 14, 5)
+    f = 128
+    b = _batch(ei, w, ptr, bid, nn_, f).to(DEV)
+    s = b.structure()
+    lib = _lib.load()
+    ell = s.fused_meta(384, int(lib.cgnn_fused_grid()), 0.0)
+    norm = s.sage_norm(backward_coef=False)
+    g = torch.Generator().manual_seed(2)
+    z = torch.randn(nn_, f, generator=g).to(DEV)
+    coef = torch.randn(4 * f, generator=g).to(DEV)
+    seed = 0x1234567890ABCDEF
+    x_ref = torch.empty_like(z)
+    m_ref = torch.zeros(nn_ * f // 4, dtype=torch.uint8, device=DEV)
+    _lib.check(lib.cgnn_bn_act_fwd_apply(_lib.ptr(z), _lib.ptr(coef), 0, p, seed, None, _lib.ptr(m_ref) if p else None,
+                                         _lib.ptr(x_ref), nn_, f, _lib.stream_ptr()), "apply")
+    y_ref = ops.aggregate_tiled_raw(s, ell, ops.AGG_POST_DIV, x_ref, None, norm.den, None)
+    x = torch.full_like(z, float("nan"))
+    m = torch.zeros_like(m_ref)
+    y = ops.aggregate_tiled_bn_raw(s, ell, ops.AGG_POST_DIV, z, None, norm.den, None, coef, False, p, seed, None,
+                                   m if p else None, x)
+    assert torch.equal(x, x_ref) and torch.equal(y, y_ref) and torch.equal(m, m_ref)
