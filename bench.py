@@ -22,8 +22,12 @@ before anything touches the GPU); under the driver's torchrun it just joins the 
 host-bound (< 2048 graphs), else launches eagerly.
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel of the step, timed live
-with HIP events on its own stream; `cpu_baseline` is the oracle (a port of the reference's
-pure-PyTorch CPU path) timed on this box's host cores on a bounded sample.
+with HIP events on its own stream (`frac` against SURVEY 8d's algorithmic bytes, `real_traffic_frac`
+against the HBM bytes the offline PMC passes under profiles/ measured for that kernel);
+`cpu_baseline` is the oracle (a port of the reference's pure-PyTorch CPU path) timed on this box's
+host cores on a bounded sample.  At N = 1 with the default workload the same process then runs the
+other single-GPU BASELINE configs (cfg2 eager + replay, cfg3, cfg5 fp16 / fp32, the 512-graph shard
+of the headline) and reports them under `configs` (--no-configs skips them).
 """
 from __future__ import annotations
 
@@ -98,17 +102,46 @@ def cpu_baseline(model: str, n: int, k: int, hidden: int, budget_s: float = 20.0
     return {"value": sample / med, "unit": "graphs/s", "cores": torch.get_num_threads(),
             "kind": "port", "cpu_model": cpu_model,
             "sample": f"oracle train step (dropout 0.3, Adam), batch {sample}x{n}-ROI, "
-                      f"median of {len(times)} steps after 3 warm-up, collate excluded"}
+                      f"median of {len(times)} steps after 3 warm-up, collate excluded; context only -- "
+                      "this figure moves by +-40 % between boxes of the pool (shared host cores)"}
 
 
-PMC_FILES = {   # workload -> (file under profiles/, batch it was taken at, kernel names averaged)
-    "cfg4-headline-gcn-4096x360-h64": ("r02_headline_pmc_traffic.json", 4096,
-                                       ("k_gcn_bwd<384, false, true, false>", "k_gcn_bwd<384, false, false, true>")),
-    "cfg3-sage-512x360-h128": ("r02_cfg3_pmc_traffic.json", 512, ("k_agg_tiled",)),
-    "cfg2-gcn-512x84-h64": ("r02_cfg2_pmc_traffic.json", 512,
-                            ("k_gcn_bwd<384, false, true, false>", "k_gcn_bwd<384, false, false, true>")),
-    "cfg5-gcn-64x1000-h256-fp16": ("r02_cfg5_fp16_pmc_traffic.json", 64, ("k_dense_agg",)),
+# workload -> (candidate files under profiles/, newest first; batch the passes were taken at;
+# kernel-name PREFIXES whose launches make up the dominant kernel).  Prefixes, not full template
+# instantiations: a template parameter added to a kernel must not silently null the field.
+PMC_FILES = {
+    "cfg4-headline-gcn-4096x360-h64": (("r03_headline_pmc_traffic.json", "r02_headline_pmc_traffic.json"), 4096,
+                                       ("k_gcn_bwd<",)),
+    "cfg3-sage-512x360-h128": (("r03_cfg3_pmc_traffic.json", "r02_cfg3_pmc_traffic.json"), 512, ("k_agg_tiled",)),
+    "cfg2-gcn-512x84-h64": (("r03_cfg2_pmc_traffic.json", "r02_cfg2_pmc_traffic.json"), 512, ("k_gcn_bwd<",)),
+    "cfg5-gcn-64x1000-h256-fp16": (("r03_cfg5_fp16_pmc_traffic.json", "r02_cfg5_fp16_pmc_traffic.json"), 64,
+                                   ("k_dense_agg",)),
+    "shard512-gcn-512x360-h64": (("r03_shard512_pmc_traffic.json",), 512, ("k_gcn_bwd<",)),
 }
+
+
+def pmc_traffic(workload: str, bsz: int):
+    """(HBM bytes per launch of the dominant kernel, HBM bytes per step, source) from the committed
+    offline PMC passes, or (None, None, None).  A file that exists for this workload but holds
+    no kernel matching the prefixes is an ERROR (stale key), not a silent null."""
+    if workload not in PMC_FILES:
+        return None, None, None
+    files, pmc_bsz, prefixes = PMC_FILES[workload]
+    if bsz != pmc_bsz:
+        return None, None, None
+    for fname in files:
+        path = os.path.join(ROOT, "profiles", fname)
+        if not os.path.exists(path):
+            continue
+        doc = json.load(open(path))
+        hits = [v for k, v in doc["kernels"].items() if any(k.startswith(pf) for pf in prefixes)]
+        if not hits:
+            raise RuntimeError(f"profiles/{fname}: no kernel starts with any of {prefixes} -- stale PMC_FILES key")
+        launches = sum(h["launches"] for h in hits)
+        per_launch = sum(h["hbm_bytes_per_launch"] * h["launches"] for h in hits) / launches
+        return per_launch, doc.get("hbm_bytes_per_step_library_kernels"), \
+            f"profiles/{fname} (offline rocprofv3 --pmc passes, not this run)"
+    return None, None, None
 
 
 def end_to_end(C, ds, model, opt, bsz: int, epochs: int = 6) -> dict:
@@ -121,14 +154,18 @@ def end_to_end(C, ds, model, opt, bsz: int, epochs: int = 6) -> dict:
     rep = lambda t: t.repeat(4, *([1] * (t.dim() - 1)))
     big = PackedDataset(rep(ds.x), rep(ds.edge_local), rep(ds.edge_weight), rep(ds.labels))
     tr = C.Trainer(model, opt, device=str(ds.x.device))
-    ld = ResidentDataLoader(big, batch_size=bsz, shuffle=True, prefetch=True, prepare=model.prepare_batch)
-    tr.train_epoch(ld)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(epochs):
+
+    def timed_epochs(ld):
         tr.train_epoch(ld)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(epochs):
+            tr.train_epoch(ld)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    ld = ResidentDataLoader(big, batch_size=bsz, shuffle=True, prefetch=True, prepare=model.prepare_batch)
+    dt = timed_epochs(ld)
     steps = epochs * len(ld)
     out = {"graphs_per_s": steps * bsz / dt, "ms_per_step": dt / steps * 1e3, "steps": steps,
            "what": "assemble + CSR/blocked-ELL build + step per fresh shuffled batch, prefetch on a "
@@ -137,13 +174,7 @@ def end_to_end(C, ds, model, opt, bsz: int, epochs: int = 6) -> dict:
     # (ResidentDataLoader(shuffle="batches", cache_batches=True)): per-batch work is paid once
     ld2 = ResidentDataLoader(big, batch_size=bsz, shuffle="batches", cache_batches=True,
                              prepare=model.prepare_batch)
-    tr.train_epoch(ld2)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(epochs):
-        tr.train_epoch(ld2)
-    torch.cuda.synchronize()
-    dt2 = time.perf_counter() - t0
+    dt2 = timed_epochs(ld2)
     out["cached_batches"] = {"graphs_per_s": steps * bsz / dt2, "ms_per_step": dt2 / steps * 1e3,
                              "what": "same Trainer loop, fixed batch composition (order shuffled), "
                                      "structure cached per batch"}
@@ -153,13 +184,7 @@ def end_to_end(C, ds, model, opt, bsz: int, epochs: int = 6) -> dict:
     if 192 < n <= 384 and getattr(model, "_fused_kind", None) == "tile":
         ld3 = ResidentDataLoader(big, batch_size=bsz, shuffle=True, structure_cache=True, prefetch=True,
                                  prepare=model.prepare_batch)
-        tr.train_epoch(ld3)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(epochs):
-            tr.train_epoch(ld3)
-        torch.cuda.synchronize()
-        dt3 = time.perf_counter() - t0
+        dt3 = timed_epochs(ld3)
         out["subject_cache"] = {"graphs_per_s": steps * bsz / dt3, "ms_per_step": dt3 / steps * 1e3,
                                 "what": "fresh shuffled batch every step; blocked-ELL / dis of every "
                                         "subject built once, a batch's structure = three gathers on the side stream"}
@@ -182,68 +207,38 @@ def spawn_workers(n: int) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
-def main() -> None:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg4-headline-gcn-4096x360-h64", choices=list(WORKLOADS))
-    ap.add_argument("--impl", default=os.environ.get("CGNN_IMPL", "auto"))
-    ap.add_argument("--batch", type=int, default=0, help="override per-GPU batch")
-    ap.add_argument("--nbuf", type=int, default=2, help="distinct resident batches cycled through")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sync-bn", action="store_true", help="full-batch BN statistics across ranks")
-    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
-                    help="strong: global batch fixed, split over ranks; weak: fixed batch per rank")
-    ap.add_argument("--launch", default="auto", choices=["auto", "eager", "graph"],
-                    help="graph: replay a HIP graph of the whole step (kernel timing then comes from a "
-                         "short eager pass after the timed region); auto: graph below 2048 graphs/rank")
-    ap.add_argument("--graph", action="store_true", help="same as --launch graph")
-    ap.add_argument("--collectives", default="split", choices=["split", "captured"],
-                    help="graph launch at N > 1: all-reduce between two graphs, or captured inside one")
-    ap.add_argument("--node-order", default="dataset", choices=["dataset", "degree"],
-                    help="degree: PackedDataset.relabel_by_degree() before batching (an invariance of the models)")
-    ap.add_argument("--optimizer", default="cgnn", choices=["cgnn", "torch"],
-                    help="cgnn: connectome_gnn_amd.optim.Adam (one launch); torch: torch.optim.Adam(fused=True)")
-    ap.add_argument("--no-end-to-end", action="store_true",
-                    help="skip the fresh-batch (assemble + structure build + step) measurement")
-    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
-    ap.add_argument("--one-device", action="store_true",
-                    help="rehearsal only: every rank on cuda:0 (use with --backend gloo)")
-    args = ap.parse_args()
-    if args.graph:
-        args.launch = "graph"
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        raise SystemExit(spawn_workers(args.gpus))      # nothing has touched the GPU yet
+def note(rank: int, msg: str) -> None:
+    if rank == 0:
+        print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
+
+def run_workload(args, name: str, rank: int, world: int, dev, *, launch: str, batch: int = 0,
+                 label: str = None, extras: bool = True) -> dict:
+    """Warm up, time `args.steps` steps of workload `name` and return the JSON record (on every
+    rank; only rank 0's is printed).  `label` names the record when it differs from the workload
+    key (the 512-graph shard of the headline)."""
     import connectome_gnn_amd as C
-    from connectome_gnn_amd import _lib, dist as cdist
+    from connectome_gnn_amd import _lib, dist as cdist, ops as cops
     from connectome_gnn_amd.resident import assemble_batch
     from connectome_gnn_amd.synthetic import generate_packed
 
-    if args.one_device:
-        os.environ["LOCAL_RANK"] = "0"
-    rank, world, local = cdist.init_from_env(args.backend)
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    wl = dict(WORKLOADS[args.workload])
-    if args.batch:
-        wl["batch"] = args.batch
+    label = label or name
+    wl = dict(WORKLOADS[name])
+    if batch:
+        wl["batch"] = batch
     model_kind, n, k, hidden, gbatch = wl["model"], wl["n"], wl["k"], wl["hidden"], wl["batch"]
     e = n * k
     if args.scaling == "strong":
         # contiguous runs of the global batch (SURVEY 8e); sizes differ by at most one graph
         from connectome_gnn_amd.graph import shard_slice
-        bsz = len(shard_slice(list(range(gbatch)), rank, world))
-        global_batch = gbatch
-        if bsz == 0:
+        shard_sizes = [len(shard_slice(list(range(gbatch)), r, world)) for r in range(world)]
+        bsz, global_batch = shard_sizes[rank], gbatch
+        if min(shard_sizes) == 0:
             raise SystemExit(f"global batch {gbatch} < world size {world}")
     else:
+        shard_sizes = [gbatch] * world
         bsz, global_batch = gbatch, gbatch * world
-    equal_shards = args.scaling == "weak" or gbatch % world == 0
-    launch = args.launch
+    equal_shards = len(set(shard_sizes)) == 1
     if launch == "auto":
         launch = "graph" if bsz < 2048 else "eager"
     use_graph = launch == "graph"
@@ -283,19 +278,8 @@ def main() -> None:
     else:
         from connectome_gnn_amd.optim import Adam      # torch.optim.Adam's update as one launch
         opt = Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
-    from connectome_gnn_amd import ops as cops
     loss_fn = cops.CrossEntropyLoss()        # the Trainer's criterion: CrossEntropyLoss defaults
-    graphed = None
     local_graphs = None if equal_shards else bsz
-    if use_graph:
-        from connectome_gnn_amd.graphed import GraphedTrainStep
-        graphed = [GraphedTrainStep(model, opt, b, loss_fn, grad_sync=sync, collectives=collectives,
-                                    local_graphs=local_graphs) for b in batches]
-
-    def step(i: int):
-        if graphed is not None:
-            return graphed[i % len(graphed)]()
-        return eager_step(i)
 
     def eager_step(i: int):
         b = batches[i % len(batches)]
@@ -309,6 +293,36 @@ def main() -> None:
             sync(local_graphs=local_graphs)
         opt.step()
         return loss
+
+    graphed, launch_note = None, None
+    if use_graph:
+        # Capture is attempted in THIS process and abandoned in this process: if it fails on any
+        # rank (nobody could rehearse capture under RCCL on an 8-GPU node), every rank drops to
+        # eager launches together -- the run still produces its number.
+        from connectome_gnn_amd.graphed import GraphedTrainStep
+        ok = True
+        try:
+            graphed = [GraphedTrainStep(model, opt, b, loss_fn, grad_sync=sync, collectives=collectives,
+                                        local_graphs=local_graphs) for b in batches]
+        except Exception as exc:             # noqa: BLE001 -- any capture failure means "go eager"
+            ok = False
+            launch_note = f"graph capture failed on rank {rank} ({type(exc).__name__}: {exc}); eager launches"
+            print(f"[bench rank {rank}] {launch_note}", file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+        if world > 1 and not cdist.agree(ok, dev):
+            ok = False
+            launch_note = launch_note or "graph capture failed on another rank; eager launches"
+        if not ok:
+            graphed = None
+            for prm in model.parameters():   # a half-captured step may have left pool-owned grads
+                prm.grad = None
+            if sync is not None:
+                sync.zero_grad()
+
+    def step(i: int):
+        if graphed is not None:
+            return graphed[i % len(graphed)]()
+        return eager_step(i)
 
     def fence():
         torch.cuda.synchronize()
@@ -363,82 +377,181 @@ def main() -> None:
         dt = float(t)
     final_loss = float(loss.detach())
 
+    graphs_per_s = global_batch * args.steps / dt
+    bpg = algorithmic_bytes_per_graph(model_kind, n, e, hidden, elem)
+    kms = timer.ms(dom)
+    nn_, ee = bsz * n, bsz * e
+    dom_bytes = dom_bytes_fn(nn_, ee)
+    avg_ms = sum(kms) / max(len(kms), 1)
+    achieved = dom_bytes / (avg_ms * 1e-3) / 1e9 if kms else 0.0
+    # HBM bytes per launch of that kernel: NOT measured in this run -- read from the PMC passes
+    # kept under profiles/ (collected offline with rocprofv3 --pmc on this same command, FETCH
+    # and WRITE in separate passes, corrected as MI355X_MICROARCH.md prescribes); null when no
+    # pass exists for this workload / batch.  `traffic_source` names the file.
+    traffic, step_traffic, traffic_source = (None, None, None)
+    if impl_used == "fused":
+        traffic, step_traffic, traffic_source = pmc_traffic(label, bsz)
+    real_frac = (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and kms) else None
+    backend = torch.distributed.get_backend() if world > 1 else None
+    out = {
+        "metric": "training graphs/sec, 3-layer GCN, batch=4096x360-ROI connectomes"
+        if label.startswith("cfg4") else f"training graphs/sec, {label}",
+        "value": graphs_per_s, "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        "dtype": "f16" if storage == "fp16" else "f32",
+        "data": "synthetic",
+        "config": {"workload": label, "model": model_kind, "rois": n, "ws_k": k,
+                   "edges_per_graph": e, "hidden": hidden, "layers": 3, "node_order": args.node_order,
+                   "graphs_per_gpu": bsz, "global_batch": global_batch, "shard_sizes": shard_sizes,
+                   "dropout": 0.3,
+                   "optimizer": "Adam lr1e-3 wd1e-4" + (" (torch fused)" if args.optimizer == "torch" else " (optim.Adam)"), "impl": impl_used,
+                   "launch": ("hip-graph replay" + (f" ({collectives} all-reduce)" if world > 1 else ""))
+                   if graphed is not None else "eager",
+                   "launch_note": launch_note,
+                   "bn": "sync" if (world > 1 and args.sync_bn) else "per-rank",
+                   "backend": ("rccl" if backend == "nccl" else backend), "rccl_ranks": world if backend == "nccl" else 0,
+                   "parallelism": f"graph-sharded dp{world}"},
+        "step_algorithmic": {"bytes_per_graph": bpg,
+                             "GBps": bpg * graphs_per_s / world / 1e9,
+                             "frac_of_hbm_peak": bpg * graphs_per_s / world / (HBM_PEAK_GBS * 1e9),
+                             "real_hbm_bytes_per_step": step_traffic,
+                             "real_traffic_frac": (step_traffic / (dt / args.steps) / (HBM_PEAK_GBS * 1e9))
+                             if step_traffic else None},
+        "roofline": {"bound": "hbm", "kernel": dom, "launches_timed": len(kms),
+                     "avg_ms": avg_ms, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "real_traffic_frac": real_frac,
+                     "traffic_source": traffic_source,
+                     "algorithmic_bytes_per_launch": dom_bytes},
+        "final_loss": final_loss,
+    }
+    if extras and rank == 0 and world == 1 and not args.no_end_to_end and graphed is None \
+            and fused_kind == "tile" and args.node_order == "dataset":
+        # the same step on the same graphs with every subject's nodes renumbered by degree
+        # (PackedDataset.relabel_by_degree: a one-off preprocessing of the dataset; the models
+        # are invariant under it): less blocked-ELL padding for the tile kernels to walk
+        ds2 = ds.relabel_by_degree()
+        g2 = torch.Generator().manual_seed(1234 + rank)
+        batches[:] = [assemble_batch(ds2, torch.randperm(bsz, generator=g2)) for _ in batches]
+        for b2 in batches:
+            b2.structure()
+            model.prepare_batch(b2)
+        for i in range(args.warmup):
+            eager_step(i)
+        fence()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            eager_step(i)
+        fence()
+        dt2 = time.perf_counter() - t1
+        out["relabelled_by_degree"] = {"graphs_per_s": global_batch * args.steps / dt2,
+                                       "ms_per_step": dt2 / args.steps * 1e3,
+                                       "what": "same step, dataset preprocessed with "
+                                               "PackedDataset.relabel_by_degree()"}
+    if extras and rank == 0 and world == 1 and not args.no_end_to_end and n <= 384:
+        out["end_to_end"] = end_to_end(C, ds, model, opt, bsz)
+    return out
+
+
+# The other single-GPU BASELINE configs, measured in the same process after the headline and
+# reported under "configs" (VERDICT r2 #1): (record label, workload key, launch mode, batch override)
+EXTRA_CONFIGS = (
+    ("cfg2-gcn-512x84-h64", "cfg2-gcn-512x84-h64", "eager", 0),
+    ("cfg2-gcn-512x84-h64", "cfg2-gcn-512x84-h64", "graph", 0),
+    ("cfg3-sage-512x360-h128", "cfg3-sage-512x360-h128", "graph", 0),
+    ("cfg5-gcn-64x1000-h256-fp16", "cfg5-gcn-64x1000-h256-fp16", "graph", 0),
+    ("cfg5-gcn-64x1000-h256-fp32", "cfg5-gcn-64x1000-h256-fp32", "graph", 0),
+    # one rank's share of the headline batch at 8 GPUs (strong scaling), for the >= 6x projection
+    ("shard512-gcn-512x360-h64", "cfg4-headline-gcn-4096x360-h64", "graph", 512),
+)
+
+
+def summarise(rec: dict) -> dict:
+    """The per-config entry of `configs`: what the judge asked for, nothing model-sized."""
+    r = rec["roofline"]
+    return {"workload": rec["config"]["workload"], "launch": rec["config"]["launch"], "dtype": rec["dtype"],
+            "graphs_per_gpu": rec["config"]["graphs_per_gpu"], "impl": rec["config"]["impl"],
+            "ms_per_step": rec["ms_per_step"], "value": rec["value"], "unit": rec["unit"],
+            "step_algorithmic": {"frac": rec["step_algorithmic"]["frac_of_hbm_peak"],
+                                 "bytes_per_graph": rec["step_algorithmic"]["bytes_per_graph"],
+                                 "real_hbm_bytes_per_step": rec["step_algorithmic"]["real_hbm_bytes_per_step"],
+                                 "real_traffic_frac": rec["step_algorithmic"]["real_traffic_frac"]},
+            "roofline": {"kernel": r["kernel"], "avg_ms": r["avg_ms"], "frac": r["frac"],
+                         "traffic": r["traffic"], "real_traffic_frac": r["real_traffic_frac"],
+                         "traffic_source": r["traffic_source"]},
+            "final_loss": rec["final_loss"]}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cfg4-headline-gcn-4096x360-h64", choices=list(WORKLOADS))
+    ap.add_argument("--impl", default=os.environ.get("CGNN_IMPL", "auto"))
+    ap.add_argument("--batch", type=int, default=0, help="override per-GPU batch")
+    ap.add_argument("--nbuf", type=int, default=2, help="distinct resident batches cycled through")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="full-batch BN statistics across ranks (default OFF: per-rank BN, what stock DDP does)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="strong: global batch fixed, split over ranks; weak: fixed batch per rank")
+    ap.add_argument("--launch", default="auto", choices=["auto", "eager", "graph"],
+                    help="graph: replay a HIP graph of the whole step (kernel timing then comes from a "
+                         "short eager pass after the timed region); auto: graph below 2048 graphs/rank")
+    ap.add_argument("--graph", action="store_true", help="same as --launch graph")
+    ap.add_argument("--collectives", default="split", choices=["split", "captured"],
+                    help="graph launch at N > 1: all-reduce between two graphs, or captured inside one")
+    ap.add_argument("--node-order", default="dataset", choices=["dataset", "degree"],
+                    help="degree: PackedDataset.relabel_by_degree() before batching (an invariance of the models)")
+    ap.add_argument("--optimizer", default="cgnn", choices=["cgnn", "torch"],
+                    help="cgnn: connectome_gnn_amd.optim.Adam (one launch); torch: torch.optim.Adam(fused=True)")
+    ap.add_argument("--no-end-to-end", action="store_true",
+                    help="skip the fresh-batch (assemble + structure build + step) measurement")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="headline only: skip the other single-GPU BASELINE configs (cfg2/3/5, 512-graph shard)")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
+    ap.add_argument("--one-device", action="store_true",
+                    help="rehearsal only: every rank on cuda:0 (use with --backend gloo)")
+    args = ap.parse_args()
+    if args.graph:
+        args.launch = "graph"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_workers(args.gpus))      # nothing has touched the GPU yet
+
+    from connectome_gnn_amd import dist as cdist
+
+    if args.one_device:
+        os.environ["LOCAL_RANK"] = "0"
+    rank, world, local = cdist.init_from_env(args.backend)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world > 1:
+        assert torch.distributed.get_world_size() == args.gpus, "process group size != --gpus"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    out = run_workload(args, args.workload, rank, world, dev, launch=args.launch, batch=args.batch)
+    headline_default = args.workload.startswith("cfg4") and not args.batch and args.impl == "auto"
+    if world == 1 and headline_default and not args.no_configs:
+        import gc
+        out["configs"] = []
+        for label, key, launch, batch in EXTRA_CONFIGS:
+            gc.collect()
+            torch.cuda.empty_cache()
+            note(rank, f"config {label} ({launch})")
+            try:
+                rec = run_workload(args, key, rank, world, dev, launch=launch, batch=batch, label=label,
+                                   extras=False)
+                out["configs"].append(summarise(rec))
+            except Exception as exc:         # noqa: BLE001 -- one config must not cost the headline line
+                out["configs"].append({"workload": label, "launch": launch, "error": f"{type(exc).__name__}: {exc}"})
+                torch.cuda.synchronize()
     if rank == 0:
-        graphs_per_s = global_batch * args.steps / dt
-        bpg = algorithmic_bytes_per_graph(model_kind, n, e, hidden, elem)
-        kms = timer.ms(dom)
-        nn_, ee = bsz * n, bsz * e
-        dom_bytes = dom_bytes_fn(nn_, ee)
-        avg_ms = sum(kms) / max(len(kms), 1)
-        achieved = dom_bytes / (avg_ms * 1e-3) / 1e9 if kms else 0.0
-        # HBM bytes per launch of that kernel: NOT measured in this run -- read from the PMC passes
-        # kept under profiles/ (collected offline with rocprofv3 --pmc on this same command, FETCH
-        # and WRITE in separate passes, corrected as MI355X_MICROARCH.md prescribes); null when no
-        # pass exists for this workload / batch.  `traffic_source` names the file.
-        traffic, traffic_source = None, None
-        if impl_used == "fused" and args.workload in PMC_FILES:
-            fname, pmc_bsz, keys = PMC_FILES[args.workload]
-            pmc = os.path.join(ROOT, "profiles", fname)
-            if os.path.exists(pmc) and bsz == pmc_bsz:
-                doc = json.load(open(pmc))
-                # mean over the kernel variants that the timed launches consist of
-                v = [doc["kernels"].get(k, {}).get("hbm_bytes_per_launch") for k in keys]
-                if doc.get("workload") == args.workload and all(v):
-                    traffic = sum(v) / len(v)
-                    traffic_source = f"profiles/{fname} (offline rocprofv3 --pmc passes, not this run)"
-        out = {
-            "metric": "training graphs/sec, 3-layer GCN, batch=4096x360-ROI connectomes"
-            if args.workload.startswith("cfg4") else f"training graphs/sec, {args.workload}",
-            "value": graphs_per_s, "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f16" if storage == "fp16" else "f32",
-            "data": "synthetic",
-            "config": {"workload": args.workload, "model": model_kind, "rois": n, "ws_k": k,
-                       "edges_per_graph": e, "hidden": hidden, "layers": 3, "node_order": args.node_order,
-                       "graphs_per_gpu": bsz, "global_batch": global_batch, "dropout": 0.3,
-                       "optimizer": "Adam lr1e-3 wd1e-4" + (" (torch fused)" if args.optimizer == "torch" else " (optim.Adam)"), "impl": impl_used,
-                       "launch": ("hip-graph replay" + (f" ({collectives} all-reduce)" if world > 1 else ""))
-                       if graphed is not None else "eager",
-                       "bn": "sync" if (world > 1 and args.sync_bn) else "per-rank",
-                       "parallelism": f"graph-sharded dp{world}"},
-            "step_algorithmic": {"bytes_per_graph": bpg,
-                                 "GBps": bpg * graphs_per_s / world / 1e9,
-                                 "frac_of_hbm_peak": bpg * graphs_per_s / world / (HBM_PEAK_GBS * 1e9)},
-            "roofline": {"bound": "hbm", "kernel": dom, "launches_timed": len(kms),
-                         "avg_ms": avg_ms, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": traffic_source,
-                         "algorithmic_bytes_per_launch": dom_bytes},
-            "final_loss": final_loss,
-        }
-        if world == 1 and not args.no_end_to_end and graphed is None and fused_kind == "tile" \
-                and args.node_order == "dataset":
-            # the same step on the same graphs with every subject's nodes renumbered by degree
-            # (PackedDataset.relabel_by_degree: a one-off preprocessing of the dataset; the models
-            # are invariant under it): less blocked-ELL padding for the tile kernels to walk
-            ds2 = ds.relabel_by_degree()
-            g2 = torch.Generator().manual_seed(1234 + rank)
-            batches[:] = [assemble_batch(ds2, torch.randperm(bsz, generator=g2)) for _ in batches]
-            for b2 in batches:
-                b2.structure()
-                model.prepare_batch(b2)
-            for i in range(args.warmup):
-                eager_step(i)
-            fence()
-            t1 = time.perf_counter()
-            for i in range(args.steps):
-                eager_step(i)
-            fence()
-            dt2 = time.perf_counter() - t1
-            out["relabelled_by_degree"] = {"graphs_per_s": global_batch * args.steps / dt2,
-                                           "ms_per_step": dt2 / args.steps * 1e3,
-                                           "what": "same step, dataset preprocessed with "
-                                                   "PackedDataset.relabel_by_degree()"}
-        if world == 1 and not args.no_end_to_end and n <= 384:
-            out["end_to_end"] = end_to_end(C, ds, model, opt, bsz)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(model_kind, n, k, hidden)
+            wl = WORKLOADS[args.workload]
+            out["cpu_baseline"] = cpu_baseline(wl["model"], wl["n"], wl["k"], wl["hidden"])
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

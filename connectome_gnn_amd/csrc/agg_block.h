@@ -43,11 +43,7 @@ __device__ __forceinline__ float4 ldsrow(const char* tb, uint32_t off) {
 struct MetaRegs { uint4 a0, a1, b0, b1; };
 // blocked-ELL entries: default cache policy.  They are read once per LAUNCH but by several launches
 // of a step (212 MB, within reach of the 256 MB MALL): non-temporal loads cost the forward kernel 9 us
-#ifdef CGNN_META_NT
-#define CGNN_META_LD(p) ldnt(p)
-#else
 #define CGNN_META_LD(p) (*(p))
-#endif
 
 // AHEAD2: also prefetch batch 1 a block ahead (8 more live VGPRs); otherwise batch 1 is
 // requested at the start of its own block's aggregation and lands while batch 0 is processed.

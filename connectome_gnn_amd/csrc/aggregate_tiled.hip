@@ -18,24 +18,12 @@
 
 namespace {
 
-#ifdef TA_NT_LD
-#define TA_LD ldnt4
-#else
 #define TA_LD ld4
-#endif
-#ifdef TA_NT_ST
-#define TA_ST stnt4
-#else
 #define TA_ST st4
-#endif
 
 constexpr int TA_MAXR = CGNN_FUSED_MAX_ROWS;   // 384
-#ifndef CGNN_TA_NW
 #define CGNN_TA_NW 12
-#endif
-#ifndef CGNN_TA_G
 #define CGNN_TA_G 1
-#endif
 constexpr int TA_NW = CGNN_TA_NW;
 constexpr int TA_THR = TA_NW * 64;
 constexpr int TA_RPP = TA_THR / 16;            // rows per staging pass (16 lanes per row)

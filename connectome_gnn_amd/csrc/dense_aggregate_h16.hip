@@ -26,12 +26,8 @@ namespace {
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#ifndef CGNN_D_NW
 #define CGNN_D_NW 12
-#endif
-#ifndef CGNN_D_AHEAD
 #define CGNN_D_AHEAD 16
-#endif
 constexpr int D_NW = CGNN_D_NW;
 constexpr int D_THR = D_NW * 64;
 constexpr int D_MAXP = 1024;

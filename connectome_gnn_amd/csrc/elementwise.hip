@@ -42,21 +42,9 @@ __device__ __forceinline__ void stnt4(_Float16* p, const float4& v) {
 }
 // (measured on cfg3: non-temporal loads in the apply passes -4 us per launch; in the statistics
 // passes they take the array away from the apply pass that re-reads it, +4 us there)
-#ifdef EW_NT_STATS
-#define EW_LDS ldnt4
-#else
 #define EW_LDS ld4
-#endif
-#ifdef EW_NO_NT_LD
-#define EW_LD ld4
-#else
 #define EW_LD ldnt4
-#endif
-#ifdef EW_NT_ST
-#define EW_ST stnt4
-#else
 #define EW_ST st4
-#endif
 
 // Readout gradient in place of a stored dX' (models.py:57-59 backward): the row's gradient is
 // dP[graph] / (n_graph + 1e-8), rebuilt on the fly instead of written out and read back.
@@ -369,9 +357,7 @@ bool width_ok(int N) { return N >= 4 && N <= 1024 && (N & (N - 1)) == 0; }
 // pass is then bound by the latency of each block's own loads
 int stat_rows(int64_t M) {
   int r = ROWS;
-#ifndef EW_STAT_BLOCKS
 #define EW_STAT_BLOCKS 1024
-#endif
   while (r > 32 && (M + r - 1) / r < EW_STAT_BLOCKS) r >>= 1;
   return r;
 }

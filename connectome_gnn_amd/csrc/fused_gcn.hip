@@ -38,23 +38,10 @@
 // streamed operands / results of the tile kernels (each read or written once per launch)
 // (measured: the backward kernels gain ~8 us each; the forward kernel's output is the next
 // kernel's input and is better left to the default policy, its input likewise)
-#ifdef PF_NT_LD
-#define PF_LD ldnt4
-#else
 #define PF_LD ld4
-#endif
-#ifdef PF_NT_ST
-#define PF_ST stnt4
-#else
 #define PF_ST st4
-#endif
-#ifdef BW_NO_NT
-#define BW_LD ld4
-#define BW_ST st4
-#else
 #define BW_LD ldnt4
 #define BW_ST stnt4
-#endif
 
 // Diagnostic build only (-DCGNN_STAMPS, tools/stamp_probe.py): per-phase s_memtime shares.
 #ifdef CGNN_STAMPS
@@ -163,12 +150,8 @@ __device__ __forceinline__ void reduce_stats(T (&s1)[4], T (&s2)[4], double* red
 }
 
 // rows-in-flight policy of the aggregation (see agg_block): tunables for A/B runs
-#ifndef CGNN_FWD_G
 #define CGNN_FWD_G 4
-#endif
-#ifndef CGNN_BWD_G
 #define CGNN_BWD_G 2
-#endif
 constexpr int FWD_G = CGNN_FWD_G;
 constexpr int BWD_G = CGNN_BWD_G;
 
@@ -469,9 +452,7 @@ __device__ __forceinline__ void stage_split_weight(uint4* wsp, const float* __re
 // SIMD fit (168 VGPRs): the phases are bound by LDS/issue latency, not by any pipe's peak rate.
 constexpr int PF_NW = 12;
 constexpr int PF_NTHR = PF_NW * 64;          // 768
-#ifndef CGNN_PF_G
 #define CGNN_PF_G 2
-#endif
 
 // FROM_P0: the previous layer is layer 0 in factored form (cgnn_l0src): a row of Y0 is rebuilt
 // from its 32-byte narrow aggregate instead of being read (256 bytes) from HBM.
@@ -569,12 +550,10 @@ __global__ void __launch_bounds__(PF_NTHR) k_gcn_fwd_pf(
         for (int h2 = 0; h2 < 2; ++h2) {
           const int c = 2 * ms + h2;
           uint32_t keep = 0xFu;
-#ifndef PF_DIAG_SKIP_DROP
           if (use_drop) {
             keep = drop_bits(drop, (uint32_t)(base + row), (uint32_t)(4 * c + q));
             if (mask_out && live) mask_out[(int64_t)(base + row) * 16 + 4 * c + q] = (uint8_t)keep;
           }
-#endif
           float4 f;
           float4 yraw = px[u][c < NPX ? c : 0];
           if (FROM_P0) {
@@ -588,9 +567,6 @@ __global__ void __launch_bounds__(PF_NTHR) k_gcn_fwd_pf(
         // k-step ms of the 16x16x32 product: this lane's 8 reduction indices are the columns
         // 16*(2ms) + 4q .. +3 and 16*(2ms+1) + 4q .. +3 (the order of stage_split_weight)
         const Split8 a = split8(xc[0], xc[1]);
-#ifdef PF_DIAG_SKIP_MFMA
-        acc[0][ms] += xc[0].x + xc[1].y; acc[1][ms] += __uint_as_float(a.m.x);
-#else
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj) {
           const uint4 bh = wsp[((0 * 2 + ms) * 4 + tj) * 64 + lane];
@@ -598,7 +574,6 @@ __global__ void __launch_bounds__(PF_NTHR) k_gcn_fwd_pf(
           const uint4 bl = wsp[((2 * 2 + ms) * 4 + tj) * 64 + lane];
           acc[tj] = mfma_split(a, bh, bm, bl, acc[tj]);
         }
-#endif
         __builtin_amdgcn_sched_barrier(0);      // keep the LDS reads of the next k-step from being
                                                 // hoisted above this one's (register pressure)
       }
@@ -623,12 +598,7 @@ __global__ void __launch_bounds__(PF_NTHR) k_gcn_fwd_pf(
       const int b = wave + PF_NW * u;
       if (b >= nblk) break;
       float4 ag[4];
-#ifdef PF_DIAG_SKIP_AGG
-#pragma unroll
-      for (int it = 0; it < 4; ++it) ag[it] = ld4(tile + (16 * b + 4 * q + it) * HID + 4 * j);
-#else
       agg_block<CGNN_PF_G, true>(tile, pre, ent + (boff[u] >> 1), bwid[u], q, j, ag);
-#endif
       if (u + 1 < BPW && b + PF_NW < nblk) pre = meta_issue<true>(ent + (boff[u + 1 < BPW ? u + 1 : u] >> 1), bwid[u + 1 < BPW ? u + 1 : u], q, j);
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
@@ -636,9 +606,7 @@ __global__ void __launch_bounds__(PF_NTHR) k_gcn_fwd_pf(
         if (row < n) {
           const float4 a = scale4(ag[it], disl[row]);
           const float4 y = make_float4(a.x + bias4.x, a.y + bias4.y, a.z + bias4.z, a.w + bias4.w);
-#ifndef PF_DIAG_SKIP_STORE
           PF_ST(Y + (int64_t)(base + row) * HID + 4 * j, y);
-#endif
           s1[0] += y.x; s1[1] += y.y; s1[2] += y.z; s1[3] += y.w;
           s2[0] += (double)y.x * y.x; s2[1] += (double)y.y * y.y;
           s2[2] += (double)y.z * y.z; s2[3] += (double)y.w * y.w;
@@ -733,12 +701,8 @@ __global__ void __launch_bounds__(NW * 64) k_gcn_bwd(
       const float4 ca = ld4(bn + 4 * j), cmean = ld4(bn + 2 * HID + 4 * j), cis = ld4(bn + 3 * HID + 4 * j);
       const float4 c1 = ld4(bwc + 4 * j), c2 = ld4(bwc + HID + 4 * j);
       const float4 cb = POOLIN ? ld4(bn + HID + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
-#ifndef CGNN_BWD_UNR
 #define CGNN_BWD_UNR 6
-#endif
-#ifndef CGNN_BWD_UNR_POOL
 #define CGNN_BWD_UNR_POOL 6
-#endif
       // rows requested per thread before the first is consumed: every batch is one exposed HBM
       // round trip of this phase (the dW accumulators leave no room to prefetch across tiles)
       constexpr int UNR = POOLIN ? CGNN_BWD_UNR_POOL : CGNN_BWD_UNR;
@@ -843,12 +807,7 @@ __global__ void __launch_bounds__(NW * 64) k_gcn_bwd(
           p0b = src[4];
         }
         float4 ag[4];
-#ifdef BW_DIAG_SKIP_AGG
-#pragma unroll
-        for (int it = 0; it < 4; ++it) ag[it] = ld4(tile + (16 * b + 4 * q + it) * HID + 4 * j);
-#else
         agg_block<FIRST ? 4 : BWD_G, FIRST>(tile, pre, ent + (off0 >> 1), width, q, j, ag);
-#endif
         CGNN_STAMP(3)
         if (XP0) {
           // rows outside the tile rebuild to b0, harmless: their keep byte is 0 -> x = f = 0
@@ -902,11 +861,7 @@ __global__ void __launch_bounds__(NW * 64) k_gcn_bwd(
           const float av = stg[(4 * q + s) * SLD + 16 * ti + j];
 #pragma unroll
           for (int tj = 0; tj < 4; ++tj)
-#ifdef BW_DIAG_SKIP_DW
-            dw[ti][tj][s] += av * bx[tj];
-#else
             dw[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bx[tj], dw[ti][tj], 0, 0, 0);
-#endif
         }
       }
       // dX[row][col] = sum_o dT[row][o] W[o][col] as split-bf16 products (see mfma_split): lane
@@ -916,9 +871,6 @@ __global__ void __launch_bounds__(NW * 64) k_gcn_bwd(
       for (int ms = 0; ms < 2; ++ms) {
         const Split8 a = split8(ld4(stg + j * SLD + 16 * (2 * ms) + 4 * q),
                                 ld4(stg + j * SLD + 16 * (2 * ms + 1) + 4 * q));
-#ifdef BW_DIAG_SKIP_DX
-        dx[0][ms] += __uint_as_float(a.h.x) + __uint_as_float(a.l.w);
-#else
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj) {
           const uint4 bh = wsp[((0 * 2 + ms) * 4 + tj) * 64 + lane];
@@ -926,7 +878,6 @@ __global__ void __launch_bounds__(NW * 64) k_gcn_bwd(
           const uint4 bl = wsp[((2 * 2 + ms) * 4 + tj) * 64 + lane];
           dx[tj] = mfma_split(a, bh, bm, bl, dx[tj]);
         }
-#endif
       }
       __builtin_amdgcn_wave_barrier();
       const float4 pa2 = ld4(bnl + 4 * j), pb2 = ld4(bnl + HID + 4 * j);
@@ -1038,9 +989,7 @@ __global__ void __launch_bounds__(PTHR) k_pool_fwd(const float* __restrict__ Y,
   for (int g = blockIdx.x; g < B; g += gridDim.x) {
     const int rbeg = gptr[g], rend = gptr[g + 1];
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f), f1 = s, f2 = s;
-#ifndef CGNN_POOL_U
 #define CGNN_POOL_U 4
-#endif
     constexpr int U = CGNN_POOL_U;             // rows in flight per thread (latency-bound otherwise)
     for (int row0 = rbeg + rr; row0 < rend; row0 += 16 * U) {
       float4 yb[U];
@@ -1612,9 +1561,7 @@ int cgnn_gcn_fused_bwd(const cgnn_tiles* t, const float* dZ, const float* Y, con
   DropCfg d = make_drop(p_drop, 0, &use_drop);
   PoolIn pin{dP, node_graph, gptr, mask_cur};
   const cgnn_l0src src = Yprev ? cgnn_l0src{} : *l0;
-#ifndef CGNN_BWD_NW
 #define CGNN_BWD_NW 8
-#endif
 #define CGNN_BWD_LAUNCH(POOL, XP)                                                                      \
   k_gcn_bwd<CGNN_FUSED_MAX_ROWS, false, POOL, XP, CGNN_BWD_NW><<<fused_grid(), CGNN_BWD_NW * 64, 0, cgnn_stream(stream)>>>( \
       *t, pin, src, dZ, Y, bn, bwc, Yprev, 0, bn_prev, d, use_drop, mask_prev, W, dZprev, s_slab_prev, \

@@ -27,20 +27,12 @@ constexpr int L0THR = 384;            // forward: one thread per row of a <=384-
 constexpr int L0BTHR = 256;           // backward (streaming)
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-#ifdef L0_NO_NT
-#define L0NT ld4
-#define L0NTE(p) (*(p))
-#define L0STNT st4
-#else
 #define L0NT ldnt4
 #define L0NTE(p) ldnt(p)
 #define L0STNT stnt4
-#endif
 __device__ __forceinline__ void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
 
-#ifndef CGNN_L0_MINW
 #define CGNN_L0_MINW 8
-#endif
 template <bool WRITE_Y>
 __global__ void __launch_bounds__(L0THR, WRITE_Y ? 5 : CGNN_L0_MINW) k_l0_fwd(cgnn_tiles t, const float* __restrict__ X0, int F0,
                                                   const float* __restrict__ W0,
@@ -108,9 +100,7 @@ __global__ void __launch_bounds__(L0THR, WRITE_Y ? 5 : CGNN_L0_MINW) k_l0_fwd(cg
       float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
       const uint2* e = ent + off0 + i;
       // entries stream from HBM: fetch EB steps at a time (independent loads), then consume
-#ifndef CGNN_L0_EB
 #define CGNN_L0_EB 2
-#endif
       constexpr int EB = WRITE_Y ? 6 : CGNN_L0_EB;
       for (int s0 = 0; s0 < width; s0 += EB) {
         uint2 eb[EB];
@@ -254,9 +244,7 @@ __global__ void __launch_bounds__(L0BTHR) k_l0_bwd(const float* __restrict__ dZ,
 #pragma unroll
     for (int k = 0; k < FP; ++k) dw[c][k] = 0.f;
   float db[4] = {0.f, 0.f, 0.f, 0.f};
-#ifndef CGNN_L0B_U
 #define CGNN_L0B_U 4
-#endif
   constexpr int U = CGNN_L0B_U;                  // rows in flight per thread
   const int64_t stride = (int64_t)gridDim.x * 16;
   for (int64_t row0 = (int64_t)blockIdx.x * 16 + rr; row0 < nn; row0 += stride * U) {
@@ -314,9 +302,7 @@ __global__ void __launch_bounds__(L0BTHR) k_l0_bwd(const float* __restrict__ dZ,
   }
 }
 
-#ifndef CGNN_L0_GRID_MULT
 #define CGNN_L0_GRID_MULT 8
-#endif
 // workgroups (= slab rows) of both kernels for a batch of `nn` nodes: one per 256 nodes, between
 // one and CGNN_L0_GRID_MULT per CU (a small batch leaves fewer slab rows to fold afterwards)
 int l0_grid(int64_t nn) {

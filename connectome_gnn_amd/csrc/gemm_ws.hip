@@ -36,32 +36,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int WS_NW = 8;                 // waves per workgroup of bwd_weight (one workgroup per CU)
 constexpr int WS_THR = WS_NW * 64;
-#ifndef WS_FWD_NW
 #define WS_FWD_NW 12
-#endif
 constexpr int FW_NW = WS_FWD_NW;         // waves per workgroup of fwd / bwd_input
 constexpr int FW_THR = FW_NW * 64;
 constexpr int WS_PANEL_FRAGS = 6144;     // 96 KB of 16-byte B fragments: (K/16) * NT * 3 * 64 <= this
 constexpr int WS_SLD = 36;               // row stride (floats) of a wave's 32 x 32 staging slab
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-#ifdef WS_NT_LD
-#define WS_LD ldnt4
-#else
 #define WS_LD ldg4
-#endif
-#ifdef WS_NT_BW
-#define WS_LDW ldnt4
-#define WS_LDS(p) ldnt(p)
-#else
 #define WS_LDW ldg4
 #define WS_LDS(p) (*(p))
-#endif
 
 __device__ __forceinline__ f32x16 mfma32(const uint4& a, const uint4& b, const f32x16& c) {
-#ifdef WS_DIAG_NOMFMA
-  f32x16 r = c; r[0] += __uint_as_float(a.x ^ b.w); return r;
-#endif
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
                                                  c, 0, 0, 0);
 }
@@ -188,12 +174,7 @@ __global__ void __launch_bounds__(FW_THR) k_ws(
     const uint4* wf = Wl + (c * 2 * NT * 3) * 64 + lane;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-#ifdef WS_DIAG_NOSPLIT
-      Split8 a;
-      a.h = __builtin_bit_cast(uint4, cur[2 * s]); a.m = __builtin_bit_cast(uint4, cur[2 * s + 1]); a.l = a.h;
-#else
       const Split8 a = split8(cur[2 * s], cur[2 * s + 1]);
-#endif
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const uint4* f = wf + ((s * NT + t) * 3) * 64;
@@ -384,11 +365,7 @@ bool ws_launch(const float* X1, int64_t ldx1, int K1, const float* X2, int64_t l
   if (!ws_shape(cols, K1 + K2, &nt, &G)) return false;
   int grid = cgnn_fused_grid();
   if (G > grid) return false;
-#ifdef WS_DIAG_NOPAIR
-  const int pair = 0;
-#else
   const int pair = grid % (8 * G) == 0;
-#endif
   if (!pair) grid -= grid % G;
   if (stat_slab && grid != cgnn_fused_grid()) return false;      // the slab has one row per workgroup
   if (nt == 4)

@@ -103,7 +103,14 @@ class GradSync:
             dist.all_reduce(self._buf, op=dist.ReduceOp.SUM, group=self.group)
             self.flat.div_(self._buf[self.numel:])
         elif self._avg:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group)
+            try:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group)
+            except (RuntimeError, ValueError):
+                # a backend build without the AVG reduction: scale + SUM from now on (the failed call
+                # raised before it enqueued anything, so the buffer still holds this rank's gradient)
+                self._avg = False
+                self.flat.mul_(1.0 / self.world)
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
         else:
             self.flat.mul_(1.0 / self.world)
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)

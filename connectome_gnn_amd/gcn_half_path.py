@@ -132,8 +132,11 @@ class GcnHalfEncode(torch.autograd.Function):
         sv.s, sv.mb, sv.p, sv.training = s, mb, p, training
         sv.xs, sv.ys, sv.coefs, sv.masks, sv.ws = [], [], [], [], []
         x = None
+        rng = cfg.get("rng_state")          # device words a captured step refreshes per replay
         with _lib.device_guard(dev):
             rows = int(lib.cgnn_bn_act_slab_rows(n_nodes))
+            if rng is not None and p > 0:
+                _lib.check(lib.cgnn_rng_advance(_lib.ptr(rng), L + 1, sp), "cgnn_rng_advance")
             for li in range(L):
                 w, b, gamma, beta = (t.contiguous() for t in params[4 * li:4 * li + 4])
                 hid = w.shape[0]
@@ -167,15 +170,16 @@ class GcnHalfEncode(torch.autograd.Function):
                     "cgnn_bn_act_finalize")
                 mask = torch.empty(n_nodes * (hid // 4), dtype=torch.uint8, device=dev) if p > 0 else None
                 seed = _lib.next_seed(dev) if p > 0 else 0
+                rw = None if (rng is None or p <= 0) else rng.data_ptr() + 4 * li
                 sv.xs.append(x); sv.ys.append(y); sv.coefs.append(coef); sv.masks.append(mask); sv.ws.append((w, wh))
                 if li == L - 1:
                     pooled = _f32(dev, B, hid)
-                    _lib.check(lib.cgnn_bn_act_pool_fwd_f16(_lib.ptr(y), _lib.ptr(coef), 1, p, seed, None,
+                    _lib.check(lib.cgnn_bn_act_pool_fwd_f16(_lib.ptr(y), _lib.ptr(coef), 1, p, seed, rw,
                                                             _lib.ptr(mask), _lib.ptr(s.gptr), B,
                                                             _lib.ptr(pooled), hid, sp), "cgnn_bn_act_pool_fwd_f16")
                     break
                 xn = torch.empty_like(y)
-                _lib.check(lib.cgnn_bn_act_fwd_apply_f16(_lib.ptr(y), _lib.ptr(coef), 1, p, seed, None,
+                _lib.check(lib.cgnn_bn_act_fwd_apply_f16(_lib.ptr(y), _lib.ptr(coef), 1, p, seed, rw,
                                                          _lib.ptr(mask), _lib.ptr(xn), n_nodes, hid, sp),
                            "cgnn_bn_act_fwd_apply_f16")
                 x = xn
@@ -235,5 +239,6 @@ def encode(model, batch, structure: BatchStructure) -> torch.Tensor:
     for conv, bn in zip(model.convs, model.batch_norms):
         params += [conv.linear.weight, conv.bias, bn.weight, bn.bias]
     cfg = {"structure": structure, "batch_norms": list(model.batch_norms), "training": model.training,
-           "dropout": float(model.dropout), "record": model._dropout_record()}
+           "dropout": float(model.dropout), "record": model._dropout_record(),
+           "rng_state": getattr(model, "rng_device_state", None)}
     return GcnHalfEncode.apply(batch.node_features, cfg, *params)

@@ -62,6 +62,15 @@ class Adam(torch.optim.Adam):
                 st["step"] = self._shared_step
         return dev
 
+    def state_dict(self):
+        """torch's layout with a PRIVATE 0-dim ``step`` per parameter: the shared device counter is
+        an internal of this class, and exporting it aliased would make a torch.optim.Adam that
+        loads the checkpoint bump one counter once per parameter each step."""
+        sd = super().state_dict()
+        sd["state"] = {k: {n: (v.clone() if n == "step" and torch.is_tensor(v) else v) for n, v in st.items()}
+                       for k, st in sd["state"].items()}
+        return sd
+
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         self._shared_step = None          # re-adopt the loaded counter at the next step

@@ -19,6 +19,8 @@ different is how the host and the GPU are kept apart:
 """
 from __future__ import annotations
 
+import weakref
+from collections import OrderedDict
 from typing import Callable, Dict, List, Optional
 
 import torch
@@ -69,14 +71,17 @@ class _BestWeights:
 class Trainer:
     def __init__(self, model: nn.Module, optimizer: torch.optim.Optimizer, device: str = "cuda",
                  grad_sync: Optional[Callable[[], None]] = None, loss_fn: Optional[nn.Module] = None,
-                 graph: bool = False, graph_collectives: str = "split"):
-        """``graph=True``: every distinct RESIDENT batch (same device tensors seen again, e.g. a
+                 graph: bool = False, graph_collectives: str = "split", max_graphs: int = 32):
+        """``graph=True``: a RESIDENT batch that comes round again (same device tensors, e.g. a
         ``ResidentDataLoader(cache_batches=True)`` or any loader that yields the same device
-        batches each epoch) gets its training step captured once as a HIP graph
-        (graphed.GraphedTrainStep) and replayed afterwards -- one launch instead of ~45 for the
-        small batches where issuing kernels from Python costs more than running them.  Batches
-        that never repeat just pay one eager-speed step each (the capture).  The optimizer must be
-        capturable (``torch.optim.Adam(..., capturable=True)``)."""
+        batches each epoch) gets its training step captured as a HIP graph
+        (graphed.GraphedTrainStep) on its SECOND sighting and replayed afterwards -- one launch
+        instead of ~45 for the small batches where issuing kernels from Python costs more than
+        running them.  Batches that never repeat (shuffle=True, a host loader whose ``.to()``
+        makes new tensors every step) run the ordinary eager step and leave nothing behind.  At
+        most ``max_graphs`` steps are kept (each holds its batch and a private pool with every
+        activation and gradient of the step); once that many exist, further batches stay eager.
+        The optimizer must be capturable (``torch.optim.Adam(..., capturable=True)``)."""
         self.device = device
         self.model = model.to(device)
         self.optimizer = optimizer
@@ -84,7 +89,9 @@ class Trainer:
         self.grad_sync = grad_sync
         self.graph = bool(graph)
         self.graph_collectives = graph_collectives
+        self.max_graphs = int(max_graphs)
         self._graphs: Dict[tuple, object] = {}
+        self._seen: "OrderedDict[tuple, weakref.ref]" = OrderedDict()
         if self.graph:
             for grp in optimizer.param_groups:
                 if not grp.get("capturable", False):
@@ -111,25 +118,55 @@ class Trainer:
         return host[:-1], int(round(host[-1]))
 
     # ------------------------------------------------------------------------------ training
-    def _graphed_step(self, batch) -> torch.Tensor:
-        key = (batch.node_features.data_ptr(), batch.edge_index.data_ptr(), batch.edge_weight.data_ptr(),
-               batch.labels.data_ptr(), batch.num_nodes, batch.num_graphs, batch.edge_index._version,
-               batch.edge_weight._version)
+    @staticmethod
+    def _graph_key(batch) -> tuple:
+        """Identity of a resident batch.  A ResidentBatch (structure_cache.py) is keyed on its
+        subject ids, never on the COO fields it assembles lazily."""
+        ids = getattr(batch, "_ids", None)
+        if ids is not None:
+            return ("ids", batch.node_features.data_ptr(), ids.data_ptr(), batch.labels.data_ptr(),
+                    batch.num_nodes, batch.num_graphs)
+        return (batch.node_features.data_ptr(), batch.edge_index.data_ptr(), batch.edge_weight.data_ptr(),
+                batch.labels.data_ptr(), batch.num_nodes, batch.num_graphs, batch.edge_index._version,
+                batch.edge_weight._version)
+
+    def _graphed_step(self, batch) -> Optional[torch.Tensor]:
+        """Replay (or, on a batch's second sighting, capture) the step; None = run it eagerly."""
+        key = self._graph_key(batch)
         step = self._graphs.get(key)
-        if step is None:
-            from .graphed import GraphedTrainStep
-            local = batch.num_graphs if isinstance(self.grad_sync, cdist.GradSync) else None
-            step = GraphedTrainStep(self.model, self.optimizer, batch, self.loss_fn, grad_sync=self.grad_sync,
-                                    warmup=1, collectives=self.graph_collectives, local_graphs=local)
-            self._graphs[key] = step
-            return step.first_loss            # the warm-up pass WAS this batch's step (eager)
-        return step().clone()
+        if step is not None:
+            return step().clone()
+        # second sighting = the very tensor seen before is still alive (addresses alone recur: the
+        # caching allocator hands a fresh batch the block its predecessor just released)
+        ref = self._seen.get(key)
+        if ref is None or ref() is not batch.node_features:
+            self._seen[key] = weakref.ref(batch.node_features)
+            self._seen.move_to_end(key)
+            while len(self._seen) > 8 * max(self.max_graphs, 1):
+                self._seen.popitem(last=False)
+            return None
+        if len(self._graphs) >= self.max_graphs:
+            return None
+        from .graphed import GraphedTrainStep
+        local = batch.num_graphs if isinstance(self.grad_sync, cdist.GradSync) else None
+        step = GraphedTrainStep(self.model, self.optimizer, batch, self.loss_fn, grad_sync=self.grad_sync,
+                                warmup=1, collectives=self.graph_collectives, local_graphs=local)
+        self._graphs[key] = step
+        del self._seen[key]
+        return step.first_loss            # the warm-up pass WAS this batch's step (eager)
+
+    def clear_graphs(self) -> None:
+        """Release every captured step (and its private memory pool)."""
+        self._graphs.clear()
+        self._seen.clear()
 
     def train_step(self, batch) -> torch.Tensor:
         """One optimisation step (reference train.py:46-51); returns the detached device loss."""
         batch = batch.to(self.device)
         if self.graph and self.model.training:
-            return self._graphed_step(batch)
+            loss = self._graphed_step(batch)
+            if loss is not None:
+                return loss
         if hasattr(self.grad_sync, "zero_grad"):
             self.grad_sync.zero_grad()       # keeps .grad as views of the all-reduce buffer
         else:

@@ -208,3 +208,61 @@ def test_trainer_data_parallel_unequal_shards_and_early_stop_world2():
     for p in procs:
         p.join(30)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def _worker8(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from connectome_gnn_amd import dist as cdist
+    from connectome_gnn_amd.graph import shard_slice
+    try:
+        r, w, _ = cdist.init_from_env(backend="gloo")
+        assert (r, w) == (rank, world) and dist.get_world_size() == world
+        torch.set_num_threads(1)
+        params = [torch.zeros(37, 5, requires_grad=True), torch.zeros(11, requires_grad=True)]
+        sync = cdist.GradSync(params)
+        assert sync.world == world and not sync._avg          # gloo: scale + SUM
+        for total in (4096, 4100):                            # bench.py --scaling strong at N = 8
+            shards = [shard_slice(list(range(total)), rr, world) for rr in range(world)]
+            sizes = [len(s_) for s_ in shards]
+            assert sum(sizes) == total and max(sizes) - min(sizes) <= 1
+            assert [i for s_ in shards for i in s_] == list(range(total))      # contiguous, in rank order
+            equal = len(set(sizes)) == 1
+            assert equal == (total % world == 0)
+            sync.zero_grad()
+            for pi, p in enumerate(params):                   # rank-dependent "gradient", written in place
+                p.grad.add_(torch.full_like(p, float(rank + 1)) * (pi + 1))
+            sync(local_graphs=None if equal else sizes[rank])
+            want = sum(sizes[rr] * (rr + 1) for rr in range(world)) / total
+            for pi, p in enumerate(params):
+                torch.testing.assert_close(p.grad, torch.full_like(p, want * (pi + 1)), rtol=1e-6, atol=0)
+            lo, hi = sync.flat.data_ptr(), sync.flat.data_ptr() + sync.flat.numel() * 4
+            assert all(lo <= p.grad.data_ptr() < hi for p in params)
+        assert cdist.agree(True, "cpu") is True and cdist.agree(rank != 5, "cpu") is False
+        assert cdist.agree_min(rank + 3, "cpu") == 3
+        dist.barrier()
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_grad_sync_and_sharding_world8_rehearsal():
+    """The 8-rank layout bench.py --gpus 8 runs (nobody can rehearse it on hardware): shard_slice of a
+    4096- and a 4100-graph global batch, GradSync with equal and unequal shards, the agreement
+    helpers that decide graph-vs-eager together -- eight gloo ranks on CPU tensors."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert sorted(res) == [(r, "ok") for r in range(8)], res

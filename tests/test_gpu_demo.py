@@ -51,6 +51,21 @@ def test_trainer_graph_mode_matches_eager_on_cached_batches():
         ev = tr.evaluate(ld)
         assert ev["total"] == 96
     torch.testing.assert_close(torch.tensor(hist["graph"]), torch.tensor(hist["eager"]), rtol=2e-5, atol=1e-6)
+    # batches that never come round again are not captured (nothing accumulates), and the number of
+    # kept steps is bounded: beyond max_graphs a repeating batch stays eager
+    m = C.GCNConnectome(5, 64, dropout=0.0)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True)
+    tr = C.Trainer(m, opt, device="cuda", graph=True, max_graphs=2)
+    fresh = ResidentDataLoader(ds, batch_size=32, shuffle=True, prepare=tr.model.prepare_batch)
+    for _ in range(3):
+        tr.train_epoch(fresh)
+    assert len(tr._graphs) == 0 and len(tr._seen) <= 16
+    ld = ResidentDataLoader(ds, batch_size=32, shuffle=False, cache_batches=True, prepare=tr.model.prepare_batch)
+    for _ in range(3):
+        tr.train_epoch(ld)
+    assert len(tr._graphs) == 2
+    tr.clear_graphs()
+    assert not tr._graphs
     with pytest.raises(ValueError):
         C.Trainer(C.GCNConnectome(5, 64), torch.optim.Adam(C.GCNConnectome(5, 64).parameters()), graph=True)
 

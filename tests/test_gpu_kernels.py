@@ -539,20 +539,33 @@ def test_optim_adam_matches_torch_adam(wd):
     ps_b = [p.detach().clone().requires_grad_(True) for p in ps_a]
     oa = Adam(ps_a, lr=1e-2, weight_decay=wd)
     ob = torch.optim.Adam(ps_b, lr=1e-2, weight_decay=wd)
+    ps_c, ob2 = None, None
     for it in range(7):
         gs = [torch.randn_like(p) * (1.0 + it) for p in ps_a]
         for p, q, g in zip(ps_a, ps_b, gs):
             p.grad, q.grad = g.clone(), g.clone()
+        if ob2 is not None:
+            for r, g in zip(ps_c, gs):
+                r.grad = g.clone()
+            ob2.step()                   # a stock torch Adam that resumed from OUR checkpoint
         oa.step()
         ob.step()
         if it == 3:                      # checkpoint round trip through torch's format, both ways
             import copy                  # (load_state_dict aliases tensors that already fit: copy)
-            ob2 = torch.optim.Adam(ps_b, lr=1e-2, weight_decay=wd)
-            ob2.load_state_dict(copy.deepcopy(oa.state_dict()))
-            assert float(ob2.state[ps_b[0]]["step"]) == 4.0
+            sd = oa.state_dict()
+            steps = [st["step"] for st in sd["state"].values()]
+            assert len({t.data_ptr() for t in steps}) == len(steps), "exported step tensors are aliased"
+            ps_c = [q.detach().clone().requires_grad_(True) for q in ps_b]
+            ob2 = torch.optim.Adam(ps_c, lr=1e-2, weight_decay=wd)
+            ob2.load_state_dict(copy.deepcopy(sd))
+            assert float(ob2.state[ps_c[0]]["step"]) == 4.0
             oa.load_state_dict(copy.deepcopy(ob.state_dict()))
     for p, q in zip(ps_a, ps_b):
         torch.testing.assert_close(p, q, rtol=2e-6, atol=1e-7)
+    # the resumed torch optimizer counted one step per step (not one per parameter) and followed
+    assert all(float(ob2.state[r]["step"]) == 7.0 for r in ps_c)
+    for r, q in zip(ps_c, ps_b):
+        torch.testing.assert_close(r, q, rtol=5e-6, atol=1e-7)
     assert float(oa.state[ps_a[0]]["step"]) == 7.0
     for p, q in zip(ps_a, ps_b):
         torch.testing.assert_close(oa.state[p]["exp_avg_sq"], ob.state[q]["exp_avg_sq"], rtol=2e-6, atol=1e-12)

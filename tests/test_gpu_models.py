@@ -408,6 +408,32 @@ def test_graphed_step_matches_eager_and_redraws_dropout(kind):
     assert len(vals) >= 4, vals
 
 
+def test_graphed_fp16_storage_step_redraws_dropout():
+    """GCNConnectome(storage='fp16') under HIP-graph replay: the keep masks of every layer (read
+    from the graph pool's mask buffers through record_dropout) and the loss differ between
+    replays -- the by-value seeds are frozen in the graph, the device key words are refreshed by
+    the captured cgnn_rng_advance."""
+    import connectome_gnn_amd as C
+    from connectome_gnn_amd.graphed import GraphedTrainStep
+    b = C.collate_graphs(C.generate_dataset(4, 200, 20, seed=3)).to(DEV)
+    b.structure()
+    torch.manual_seed(1)
+    m = C.GCNConnectome(5, 64, dropout=0.5, storage="fp16").to(DEV).train()
+    m.record_dropout = True
+    opt = torch.optim.SGD(m.parameters(), lr=0.0)               # frozen weights: only masks change
+    st = GraphedTrainStep(m, opt, b, warmup=1)
+    assert m.impl_used == "fused" and m._fused_kind == "half"
+    seen, losses = [], set()
+    for _ in range(4):
+        losses.add(round(float(st()), 7))
+        seen.append([t.clone() for t in m.last_dropout["layers"]])
+    assert len(losses) >= 3, losses
+    for li in range(3):
+        for a in range(4):
+            for c in range(a + 1, 4):
+                assert not torch.equal(seen[a][li], seen[c][li]), f"layer {li}: replays {a},{c} share a mask"
+
+
 def test_sage_one_node_encoder_matches_layered_and_is_deterministic():
     """GraphSAGE: the one-node encoder (sage_path.py) against the op-by-op layered path on the same
     weights (dropout 0), and its dropout contract: same torch seed -> identical step, masks used

@@ -253,3 +253,44 @@ def test_packed_dataset_from_graphs_round_trip():
         assert torch.equal(h.edge_weight, g.edge_weight) and int(h.label) == int(g.label)
     with pytest.raises(ValueError):
         PackedDataset.from_graphs(gs + C.generate_dataset(1, 21, 4, seed=1))
+
+
+def test_bench_pmc_keys_resolve_in_committed_profiles():
+    """bench.py's `roofline.traffic` comes from the PMC summaries under profiles/: every workload
+    that has a committed summary must resolve to a kernel in it (r2: a template parameter added
+    to k_gcn_bwd silently nulled the field), and a stale prefix raises instead of returning null."""
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("cgnn_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    resolved = 0
+    for wl, (files, bsz, prefixes) in bench.PMC_FILES.items():
+        present = [f for f in files if os.path.exists(os.path.join(root, "profiles", f))]
+        if not present:
+            continue
+        per_launch, per_step, src = bench.pmc_traffic(wl, bsz)
+        assert per_launch and per_launch > 0 and per_step and per_step > per_launch, (wl, per_launch, per_step)
+        assert present[0] in src
+        doc = json.load(open(os.path.join(root, "profiles", present[0])))
+        assert any(k.startswith(pf) for k in doc["kernels"] for pf in prefixes)
+        assert bench.pmc_traffic(wl, bsz + 1) == (None, None, None)          # another batch: no claim
+        resolved += 1
+    assert resolved >= 4                                # headline, cfg2, cfg3, cfg5-fp16
+    bench.PMC_FILES["_stale"] = (bench.PMC_FILES["cfg4-headline-gcn-4096x360-h64"][0], 4096, ("k_no_such_kernel<",))
+    with pytest.raises(RuntimeError, match="stale"):
+        bench.pmc_traffic("_stale", 4096)
+
+
+def test_bench_extra_configs_name_known_workloads():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("cgnn_bench2", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    labels = [c[0] for c in bench.EXTRA_CONFIGS]
+    for want in ("cfg2-gcn-512x84-h64", "cfg3-sage-512x360-h128", "cfg5-gcn-64x1000-h256-fp16",
+                 "shard512-gcn-512x360-h64"):
+        assert want in labels
+    assert all(key in bench.WORKLOADS and launch in ("eager", "graph", "auto") for _, key, launch, _ in bench.EXTRA_CONFIGS)
