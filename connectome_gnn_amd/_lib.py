@@ -90,6 +90,11 @@ PROTOTYPES = {
     "cgnn_linear_bwd_weight_workspace_bytes": (I64, [I64, I32, I32]),
     "cgnn_linear_bwd_weight_f32": (c_int, [P, I64, P, I64, P, I32, I32, I64, I32, I32, P, P]),
     "cgnn_linear_bwd_weight2_f32": (c_int, [P, I64, P, I64, I32, P, I64, I32, P, I32, I64, I32, P, P]),
+    "cgnn_linear_fwd_f16": (c_int, [P, I64, I32, P, I32, I32, P, P, I64, I64, I32, P]),
+    "cgnn_linear_bwd_input_f16": (c_int, [P, I64, P, I32, P, I64, I64, I32, I32, P]),
+    "cgnn_linear_bwd_weight_f16_workspace_bytes": (I64, [I64, I32, I32]),
+    "cgnn_linear_bwd_weight_f16": (c_int, [P, I64, P, I64, P, I32, I32, I64, I32, I32, P, P]),
+    "cgnn_pad_cast_f16": (c_int, [P, I64, I32, P, I32, I64, P]),
     "cgnn_colsum_workspace_bytes": (I64, [I64, I32]),
     "cgnn_colsum_f32": (c_int, [P, I64, P, I64, I32, P, P]),
     "cgnn_pool_mean_fwd_f32": (c_int, [P, I64, P, P, I32, I32, P]),

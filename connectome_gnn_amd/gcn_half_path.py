@@ -13,16 +13,17 @@ per edge, so the operator is applied DENSE, per graph, on the fp16 matrix cores:
                     MFMA-fragment-major                         cgnn_dense_adj_f16 (static, cached)
   layer 0           P0 = Mf X0 on a 64-column half panel (narrow: a quarter of a 256-wide pass),
                     Y0 = P0 W0^T + b0
-  layer l > 0       T = X W^T                       half GEMM, fp32 accumulate (library GEMM)
+  layer l > 0       T = X W^T                       cgnn_linear_fwd_f16 (weight-stationary, fp32 accumulate)
                     Y = Mf T + b                    cgnn_dense_aggregate_f16 (v_mfma_f32_32x32x16_f16)
   every layer       X' = dropout(relu(BatchNorm(Y)))            cgnn_bn_act_*_f16 (two passes)
   readout           fused into the last BatchNorm pass          cgnn_bn_act_pool_fwd_f16
   backward          dY = BatchNorm'(...) (two passes, db = column sums), dT = Mb dY,
-                    dW = dT^T X, dX = dT W  (half GEMMs);  layer 0: dW0 = dY0^T P0, no aggregation
+                    dW = dT^T X (cgnn_linear_bwd_weight_f16: LDS transposing reads, fp32 partials
+                    per run of rows), dX = dT W (cgnn_linear_bwd_input_f16);
+                    layer 0: dW0 = dY0^T P0, no aggregation
 
-The projections are plain [Nn,256] x [256,256] GEMMs and go to the GEMM library through torch
-(hipBLASLt, fp16 in / fp32 accumulate); the hand-written kernels are the aggregation and the
-fused elementwise passes, which carry the bytes.
+Every product is a hand-written kernel of csrc/gemm_h16.hip (v_mfma_f32_32x32x16_f16, weights
+converted fp32 -> half inside the kernels): nothing on this path goes to a GEMM library.
 """
 from __future__ import annotations
 
@@ -88,23 +89,6 @@ def dense_operators(s: BatchStructure):
 P0_COLS = 64             # layer 0's input features ride in one 64-column half panel
 
 
-def _weight_grad(dt: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-    """dW = dT^T X  ([Nn, N]^T [Nn, K] -> fp32 [N, K]) as a split-K batched half GEMM: chunks of ~2048
-    rows each produce a half [N, K] partial (fp32 accumulate inside), the partials are summed in
-    fp32.  The single tall GEMM runs at a tenth of this in the library (no split-K heuristics for
-    a 64000-deep reduction) and rounds the whole sum to half once."""
-    n = dt.shape[0]
-    chunks = max(1, n // 2048)
-    rows = (n // chunks) * chunks
-    per = rows // chunks
-    part = torch.bmm(dt[:rows].view(chunks, per, dt.shape[1]).transpose(1, 2),
-                     x[:rows].view(chunks, per, x.shape[1]))
-    dw = torch.sum(part, 0, dtype=torch.float32)       # fp32 accumulation, no separate cast pass
-    if rows < n:
-        dw += torch.matmul(dt[rows:].t(), x[rows:]).float()
-    return dw
-
-
 class _Saved:
     __slots__ = ("s", "mb", "xs", "ys", "coefs", "masks", "ws", "p0", "p", "training")
 
@@ -143,16 +127,11 @@ class GcnHalfEncode(torch.autograd.Function):
                 if li == 0:
                     # A_hat (X0 W0^T) == (A_hat X0) W0^T: aggregate the few input columns (one
                     # 64-column half panel through the dense operator), then project
-                    f0 = x0.shape[1]
-                    x0h = torch.zeros(n_nodes, P0_COLS, dtype=torch.float16, device=dev)
-                    x0h[:, :f0] = x0
-                    sv.p0 = _agg(s, mf, x0h)        # [Nn, 64] half, cols >= F0 zero
-                    wh = w.half()
-                    y = torch.addmm(b.half(), sv.p0[:, :f0], wh.t())
+                    sv.p0 = _agg(s, mf, ops.pad_cast_f16(x0, P0_COLS))    # [Nn, 64] half, cols >= F0 zero
+                    y = ops.linear_fwd_f16_raw(sv.p0, w, b)               # K = 64 panel, W0 [H, F0]
                 slab, srows = None, rows
                 if li > 0:
-                    wh = w.half()
-                    t = torch.matmul(x, wh.t())                            # half GEMM, fp32 accumulate
+                    t = ops.linear_fwd_f16_raw(x, w)                       # half in / out, fp32 accumulate
                     if training:                                           # statistics in the epilogue
                         srows = int(lib.cgnn_fused_grid())
                         slab = torch.empty(srows, 2 * hid, dtype=torch.float64, device=dev)
@@ -171,7 +150,7 @@ class GcnHalfEncode(torch.autograd.Function):
                 mask = torch.empty(n_nodes * (hid // 4), dtype=torch.uint8, device=dev) if p > 0 else None
                 seed = _lib.next_seed(dev) if p > 0 else 0
                 rw = None if (rng is None or p <= 0) else rng.data_ptr() + 4 * li
-                sv.xs.append(x); sv.ys.append(y); sv.coefs.append(coef); sv.masks.append(mask); sv.ws.append((w, wh))
+                sv.xs.append(x); sv.ys.append(y); sv.coefs.append(coef); sv.masks.append(mask); sv.ws.append(w)
                 if li == L - 1:
                     pooled = _f32(dev, B, hid)
                     _lib.check(lib.cgnn_bn_act_pool_fwd_f16(_lib.ptr(y), _lib.ptr(coef), 1, p, seed, rw,
@@ -202,7 +181,7 @@ class GcnHalfEncode(torch.autograd.Function):
             rows = int(lib.cgnn_bn_act_slab_rows(n_nodes))
             dx = None                           # last layer: gradient rebuilt from dP inside the kernels
             for li in range(L - 1, -1, -1):
-                x, y, coef, mask, (w, wh) = sv.xs[li], sv.ys[li], sv.coefs[li], sv.masks[li], sv.ws[li]
+                x, y, coef, mask, w = sv.xs[li], sv.ys[li], sv.coefs[li], sv.masks[li], sv.ws[li]
                 hid = w.shape[0]
                 pool = (_lib.ptr(dP), _lib.ptr(s.node_graph), _lib.ptr(s.gptr)) if li == L - 1 else (None, None, None)
                 slab = torch.empty(rows, 2 * hid, dtype=torch.float64, device=dev)
@@ -224,12 +203,12 @@ class GcnHalfEncode(torch.autograd.Function):
                            "cgnn_slab_reduce_f64")
                 if li == 0:
                     # Y0 = (A_hat X0) W0^T + b0: dW0 = dY0^T P0, no aggregation in the backward
-                    dw = _weight_grad(dy, sv.p0)[:, :w.shape[1]].contiguous()
+                    dw = ops.linear_bwd_weight_f16_raw(dy, sv.p0, w.shape[1])
                     grads[0:4] = [dw, db, dgamma, dbeta]
                     break
                 dt = _agg(s, sv.mb, dy)             # dT = A_hat^T dY
-                grads[4 * li:4 * li + 4] = [_weight_grad(dt, x), db, dgamma, dbeta]
-                dx = torch.matmul(dt, wh)                                  # dX = dT W
+                grads[4 * li:4 * li + 4] = [ops.linear_bwd_weight_f16_raw(dt, x), db, dgamma, dbeta]
+                dx = ops.linear_bwd_input_f16_raw(dt, w)                   # dX = dT W
         ctx.sv = None
         return (None, None, *grads)
 

@@ -270,6 +270,76 @@ def dense_aggregate_c16_raw(structure, pack: DensePack, x, bias=None, stat_slab=
     return y
 
 
+# ---- fp16-storage projections (gemm_h16.hip): activations half, weights / weight gradients fp32
+def _need_half(t: torch.Tensor, what: str) -> None:
+    _require_device(t, what)
+    if t.dtype != torch.float16 or t.stride(-1) != 1:
+        raise TypeError(f"{what} must be a float16 matrix with contiguous rows")
+
+
+def linear_fwd_f16_raw(x, w, bias=None) -> torch.Tensor:
+    """Y = X W^T + bias: X half [M, K], W fp32 [N, Kw] with Kw <= K (columns k >= Kw of X are
+    ignored: layer 0's few input features ride in a 64-column panel); Y half [M, N]."""
+    lib = _lib.load()
+    _need_half(x, "x")
+    m, k = x.shape
+    n, kw = w.shape
+    y = torch.empty(m, n, dtype=torch.float16, device=x.device)
+    with _lib.device_guard(x.device), _lib.timed("cgnn_linear_fwd_f16", f"K={k},N={n}"):
+        _lib.check(lib.cgnn_linear_fwd_f16(_lib.ptr(x), x.stride(0), k, _lib.ptr(w), w.stride(0), kw,
+                                           _lib.ptr(bias), _lib.ptr(y), y.stride(0), m, n, _lib.stream_ptr()),
+                   "cgnn_linear_fwd_f16")
+    return y
+
+
+def linear_bwd_input_f16_raw(dy, w) -> torch.Tensor:
+    """dX = dY W: dY half [M, N], W fp32 [N, K]; dX half [M, K]."""
+    lib = _lib.load()
+    _need_half(dy, "dy")
+    m, n = dy.shape
+    k = w.shape[1]
+    dx = torch.empty(m, k, dtype=torch.float16, device=dy.device)
+    with _lib.device_guard(dy.device), _lib.timed("cgnn_linear_bwd_input_f16", f"K={k},N={n}"):
+        _lib.check(lib.cgnn_linear_bwd_input_f16(_lib.ptr(dy), dy.stride(0), _lib.ptr(w), w.stride(0), _lib.ptr(dx),
+                                                 dx.stride(0), m, n, k, _lib.stream_ptr()),
+                   "cgnn_linear_bwd_input_f16")
+    return dx
+
+
+def linear_bwd_weight_f16_raw(dy, x, kw: Optional[int] = None) -> torch.Tensor:
+    """dW[N, kw] (fp32) = dY^T X[:, :kw]: dY half [M, N], X half [M, K]."""
+    lib = _lib.load()
+    _need_half(dy, "dy")
+    _need_half(x, "x")
+    m, n = dy.shape
+    k = x.shape[1]
+    kw = k if kw is None else int(kw)
+    nbytes = int(lib.cgnn_linear_bwd_weight_f16_workspace_bytes(m, n, k))
+    if nbytes < 0:
+        raise _lib.CgnnError(f"cgnn_linear_bwd_weight_f16: shape N={n}, K={k} not covered")
+    slab = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=dy.device)
+    dw = torch.empty(n, kw, dtype=torch.float32, device=dy.device)
+    with _lib.device_guard(dy.device), _lib.timed("cgnn_linear_bwd_weight_f16", f"K={k},N={n}"):
+        _lib.check(lib.cgnn_linear_bwd_weight_f16(_lib.ptr(dy), dy.stride(0), _lib.ptr(x), x.stride(0), _lib.ptr(dw),
+                                                  kw, kw, m, n, k, _lib.ptr(slab), _lib.stream_ptr()),
+                   "cgnn_linear_bwd_weight_f16")
+    return dw
+
+
+def pad_cast_f16(x, width: int) -> torch.Tensor:
+    """[x | zeros] as a half [M, width] panel (x fp32 [M, F], F <= width)."""
+    lib = _lib.load()
+    _require_device(x, "x")
+    if x.dtype != torch.float32 or x.stride(1) != 1:
+        raise TypeError("x must be a float32 matrix with contiguous rows")
+    m, f = x.shape
+    y = torch.empty(m, width, dtype=torch.float16, device=x.device)
+    with _lib.device_guard(x.device):
+        _lib.check(lib.cgnn_pad_cast_f16(_lib.ptr(x), x.stride(0), f, _lib.ptr(y), width, m, _lib.stream_ptr()),
+                   "cgnn_pad_cast_f16")
+    return y
+
+
 class _AggregateTiled(torch.autograd.Function):
     """Y = post * A(pre * X) + bias on the blocked-ELL tiles; backward = the transposed ELL with
     pre and post swapped."""

@@ -156,6 +156,31 @@ int cgnn_linear_bwd_weight2_f32(const float* dY, int64_t lddy, const float* X1, 
                                 int32_t K1, const float* X2, int64_t ldx2, int32_t K2, float* dW,
                                 int32_t ldw, int64_t M, int32_t N, void* slab, void* stream);
 
+/* fp16-STORAGE forms of the projection for large dense parcellations (BASELINE config 5; the
+ * reference, models.py:111 and its autograd backward, has no fp16 path -- results are the fp32
+ * oracle's to fp16 resolution).  Activations X / Y / dY / dX are IEEE half, the weight and its
+ * gradient stay fp32 (converted to half once per workgroup while it is laid out as MFMA operands
+ * in LDS), accumulation is fp32 on v_mfma_f32_32x32x16_f16.
+ *   fwd       : Y[M,N] = X[M,K] W^T + bias   W fp32 [N, Kw] row-major with row stride ldw; columns
+ *               k >= Kw of X meet zeros (layer 0's 5 input features ride in a 64-column panel)
+ *   bwd_input : dX[M,K] = dY[M,N] W           W fp32 [N, K], row stride ldw
+ *   bwd_weight: dW[n*ldw + k] = sum_m dY[m,n] X[m,k] for k < Kw   (fp32 partials per run of rows in
+ *               `slab`, cgnn_linear_bwd_weight_f16_workspace_bytes(M,N,K) bytes, folded in fixed
+ *               order with fp64 accumulation)
+ * Shapes: N, K in {64,128,256} for fwd / bwd_input (K any multiple of 32 <= 256 on the reduction
+ * side), N and K in {64,128,256} for bwd_weight; rows 16-byte aligned (ld % 8 == 0).
+ * Anything else returns CGNN_EUNSUPPORTED and launches nothing. */
+int cgnn_linear_fwd_f16(const void* X, int64_t ldx, int32_t K, const float* W, int32_t ldw, int32_t Kw,
+                        const float* bias, void* Y, int64_t ldy, int64_t M, int32_t N, void* stream);
+int cgnn_linear_bwd_input_f16(const void* dY, int64_t lddy, const float* W, int32_t ldw, void* dX,
+                              int64_t lddx, int64_t M, int32_t N, int32_t K, void* stream);
+int64_t cgnn_linear_bwd_weight_f16_workspace_bytes(int64_t M, int32_t N, int32_t K);
+int cgnn_linear_bwd_weight_f16(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW,
+                               int32_t ldw, int32_t Kw, int64_t M, int32_t N, int32_t K, void* slab,
+                               void* stream);
+/* Y[M, Fp] (half) = [X[M, F] (fp32) | zeros]: the input features of a batch as a half panel. */
+int cgnn_pad_cast_f16(const float* X, int64_t ldx, int32_t F, void* Y, int32_t Fp, int64_t M, void* stream);
+
 /* Column sums (bias gradients, models.py:81,114): out[j] = sum_r A[r, j]; fp64 combine.
  * slab: cgnn_colsum_workspace_bytes(M, N) bytes. */
 int64_t cgnn_colsum_workspace_bytes(int64_t M, int32_t N);
