@@ -127,7 +127,7 @@ PROTOTYPES = {
     "cgnn_rng_advance": (c_int, [P, I32, P]),
     "cgnn_gcn_fused_fwd": (c_int, [TP, P, LP, P, F32, U64, P, P, P, P, P, P, P]),
     "cgnn_bn_reduce": (c_int, [P, I32, I32, P, P]),
-    "cgnn_bn_finalize": (c_int, [P, F64, P, P, P, P, P, F32, F32, I32, P, P]),
+    "cgnn_bn_finalize": (c_int, [P, F64, P, P, P, P, P, F32, F32, I32, P, P, P]),
     "cgnn_gcn_fused_pool_fwd": (c_int, [P, P, F32, U64, P, P, P, I32, P, P, P, P]),
     "cgnn_gcn_fused_pool_bwd_sums": (c_int, [P, P, P, P, I32, P, P]),
     "cgnn_gcn_fused_pool_bwd": (c_int, [P, P, P, F32, P, P, I32, P, P, P]),
@@ -135,15 +135,16 @@ PROTOTYPES = {
     "cgnn_gcn_fused_bwd": (c_int, [TP, P, P, P, P, P, LP, P, F32, P, P, P, P, P, P, P, P, P, P, P]),
     "cgnn_gcn_fused_bwd_first": (c_int, [TP, P, P, P, P, P, I32, P, P, F32, P, P, P, P, P]),
     "cgnn_bn_stats_finalize": (c_int, [P, I32, F64, P, P, P, P, F32, F32, P, P, P]),
-    "cgnn_bn_stats_finalize_rng": (c_int, [P, I32, F64, P, P, P, P, F32, F32, P, P, P, I32, P]),
+    "cgnn_bn_stats_finalize_rng": (c_int, [P, I32, F64, P, P, P, P, F32, F32, P, P, P, I32, P, P]),
     "cgnn_gcn_fused_pool_bwd_finalize": (c_int, [P, P, P, P, I32, F64, I32, P, P, P, P]),
     "cgnn_bn_bwd_stats_finalize": (c_int, [P, I32, F64, I32, P, P, P, P]),
     "cgnn_dw_db_reduce": (c_int, [P, P, I32, I32, I32, P, I32, P, P]),
     "cgnn_dw_db_reduce_multi": (c_int, [ctypes.POINTER(CgnnDwJobs), P]),
     "cgnn_adam_step": (c_int, [ctypes.POINTER(CgnnAdamJobs), P, P, I32, F64, F64, F64, F64, F64, P]),
     "cgnn_l0_grid": (c_int, [c_int64]),
-    "cgnn_gcn_l0_fwd": (c_int, [TP, P, I32, P, P, P, P, P, P]),
-    "cgnn_gcn_l0_bwd": (c_int, [P, P, LP, P, P, P, I64, P, P, P]),
+    "cgnn_gcn_l0_center": (c_int, [TP, P, I32, P, P]),
+    "cgnn_gcn_l0_fwd": (c_int, [TP, P, I32, P, P, P, P, P, P, P, P, P]),
+    "cgnn_gcn_l0_bwd": (c_int, [P, P, LP, P, P, P, I64, P, P, P, P]),
     "cgnn_slab_reduce_f32": (c_int, [P, I32, I32, I32, I32, P, I32, P]),
     "cgnn_slab_reduce_f64": (c_int, [P, I32, I32, P, P]),
 }

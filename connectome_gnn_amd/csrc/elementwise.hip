@@ -75,6 +75,7 @@ __global__ void __launch_bounds__(THR) k_colstats(
   const int c = threadIdx.x % nch, rr = threadIdx.x / nch, rpp = THR / nch;
   const int64_t rbeg = (int64_t)blockIdx.x * rows_per_block, rend = min(M, rbeg + rows_per_block);
   float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  double q2[4] = {0.0, 0.0, 0.0, 0.0};    // forward: sum y^2 in fp64 (it cancels against mean^2 downstream)
   float4 ca = s1, cb = s1, cm = s1, ci = s1;
   if (BWD) {
     ca = ld4(coef + 4 * c); cb = ld4(coef + N + 4 * c);
@@ -85,8 +86,8 @@ __global__ void __launch_bounds__(THR) k_colstats(
       const float4 a = (BWD && pg.dP) ? pool_grad(pg, r, N, c) : EW_LDS(A + r * N + 4 * c);
       if (!BWD) {
         s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
-        s2.x = fmaf(a.x, a.x, s2.x); s2.y = fmaf(a.y, a.y, s2.y);
-        s2.z = fmaf(a.z, a.z, s2.z); s2.w = fmaf(a.w, a.w, s2.w);
+        q2[0] += (double)a.x * a.x; q2[1] += (double)a.y * a.y;
+        q2[2] += (double)a.z * a.z; q2[3] += (double)a.w * a.w;
       } else {
         const float4 y = EW_LDS(Y + r * N + 4 * c);
         const uint32_t kb = use_drop ? mask[r * nch + c] : 0xFu;
@@ -106,7 +107,11 @@ __global__ void __launch_bounds__(THR) k_colstats(
   if (rr < rpp) {
     double* p = red + (int64_t)rr * 2 * N;
     p[4 * c + 0] = s1.x; p[4 * c + 1] = s1.y; p[4 * c + 2] = s1.z; p[4 * c + 3] = s1.w;
-    p[N + 4 * c + 0] = s2.x; p[N + 4 * c + 1] = s2.y; p[N + 4 * c + 2] = s2.z; p[N + 4 * c + 3] = s2.w;
+    if (BWD) {
+      p[N + 4 * c + 0] = s2.x; p[N + 4 * c + 1] = s2.y; p[N + 4 * c + 2] = s2.z; p[N + 4 * c + 3] = s2.w;
+    } else {
+      p[N + 4 * c + 0] = q2[0]; p[N + 4 * c + 1] = q2[1]; p[N + 4 * c + 2] = q2[2]; p[N + 4 * c + 3] = q2[3];
+    }
   }
   __syncthreads();
   for (int e = threadIdx.x; e < 2 * N; e += THR) {

@@ -1179,10 +1179,14 @@ __global__ void k_bn_finalize(const double* __restrict__ sums, double count,
                               const double* __restrict__ count_dev,
                               const float* __restrict__ gamma, const float* __restrict__ beta,
                               float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
-                              float eps, int training, float* __restrict__ bn_out) {
+                              float eps, int training, float* __restrict__ bn_out,
+                              const float* __restrict__ mean_offset) {
   const int c = threadIdx.x;
   if (c >= HID) return;
   if (count_dev) count = count_dev[0];
+  // mean_offset (nullable): the statistics are those of y - mean_offset[c] (the factored layer 0 is
+  // handed on without its constant term); the module's running mean is that of y
+  const double off = mean_offset ? (double)mean_offset[c] : 0.0;
   float mean, var;
   if (training) {
     const double m = sums[c] / count;
@@ -1191,10 +1195,10 @@ __global__ void k_bn_finalize(const double* __restrict__ sums, double count,
     mean = (float)m;
     var = (float)v;
     const double unbiased = count > 1.0 ? v * count / (count - 1.0) : v;
-    rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean;
+    rmean[c] = (1.0f - momentum) * rmean[c] + momentum * (float)(m + off);
     rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (float)unbiased;
   } else {
-    mean = rmean[c];
+    mean = (float)((double)rmean[c] - off);
     var = rvar[c];
   }
   const float invstd = 1.0f / sqrtf(var + eps);
@@ -1234,7 +1238,7 @@ __global__ void __launch_bounds__(256) k_bn_fwd_stats(
     const double* __restrict__ slab, int rows, double count, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
     float momentum, float eps, long long* __restrict__ tracked, float* __restrict__ bn_out,
-    uint32_t* __restrict__ rng_state, int rng_n) {
+    uint32_t* __restrict__ rng_state, int rng_n, const float* __restrict__ mean_offset) {
   __shared__ double sh[4];
   const int c = blockIdx.x;
   // graph replay: refresh the device dropout words here (cgnn_rng_advance's arithmetic) -- this
@@ -1253,7 +1257,9 @@ __global__ void __launch_bounds__(256) k_bn_fwd_stats(
     if (v < 0.0) v = 0.0;
     const float mean = (float)m, var = (float)v;
     const double unbiased = count > 1.0 ? v * count / (count - 1.0) : v;
-    rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean;
+    // (mean_offset: the statistics are those of y - offset, the running mean is that of y)
+    const float mean_y = mean_offset ? (float)(m + (double)mean_offset[c]) : mean;
+    rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean_y;
     rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (float)unbiased;
     const float invstd = 1.0f / sqrtf(var + eps);
     const float a = gamma[c] * invstd;
@@ -1487,11 +1493,11 @@ int cgnn_bn_reduce(const double* slab, int32_t rows, int32_t width, double* sums
 
 int cgnn_bn_finalize(const double* sums, double count, const double* count_dev, const float* gamma,
                      const float* beta, float* running_mean, float* running_var, float momentum,
-                     float eps, int32_t training, float* bn_out, void* stream) {
+                     float eps, int32_t training, float* bn_out, const float* mean_offset, void* stream) {
   if (!gamma || !beta || !running_mean || !running_var || !bn_out) return CGNN_EINVAL;
   if (training && (!sums || (!count_dev && count <= 0.0))) return CGNN_EINVAL;
   k_bn_finalize<<<1, 64, 0, cgnn_stream(stream)>>>(sums, count, count_dev, gamma, beta, running_mean,
-                                                   running_var, momentum, eps, training, bn_out);
+                                                   running_var, momentum, eps, training, bn_out, mean_offset);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }
@@ -1604,7 +1610,7 @@ int cgnn_bn_stats_finalize(const double* slab, int32_t rows, double count, const
     return CGNN_EINVAL;
   k_bn_fwd_stats<<<HID, 256, 0, cgnn_stream(stream)>>>(
       slab, rows, count, gamma, beta, running_mean, running_var, momentum, eps,
-      reinterpret_cast<long long*>(num_batches_tracked), bn_out, nullptr, 0);
+      reinterpret_cast<long long*>(num_batches_tracked), bn_out, nullptr, 0, nullptr);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }
@@ -1612,13 +1618,13 @@ int cgnn_bn_stats_finalize(const double* slab, int32_t rows, double count, const
 int cgnn_bn_stats_finalize_rng(const double* slab, int32_t rows, double count, const float* gamma,
                                const float* beta, float* running_mean, float* running_var,
                                float momentum, float eps, int64_t* num_batches_tracked, float* bn_out,
-                               uint32_t* rng_state, int32_t rng_n, void* stream) {
+                               uint32_t* rng_state, int32_t rng_n, const float* mean_offset, void* stream) {
   if (!slab || rows <= 0 || count <= 0.0 || !gamma || !beta || !running_mean || !running_var || !bn_out)
     return CGNN_EINVAL;
   if (rng_n < 0 || rng_n > 64 || (rng_n > 0 && !rng_state)) return CGNN_EINVAL;
   k_bn_fwd_stats<<<HID, 256, 0, cgnn_stream(stream)>>>(
       slab, rows, count, gamma, beta, running_mean, running_var, momentum, eps,
-      reinterpret_cast<long long*>(num_batches_tracked), bn_out, rng_state, rng_n);
+      reinterpret_cast<long long*>(num_batches_tracked), bn_out, rng_state, rng_n, mean_offset);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }

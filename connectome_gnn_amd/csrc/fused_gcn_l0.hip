@@ -38,7 +38,10 @@ __global__ void __launch_bounds__(L0THR, WRITE_Y ? 5 : CGNN_L0_MINW) k_l0_fwd(cg
                                                   const float* __restrict__ W0,
                                                   const float* __restrict__ bias,
                                                   float* __restrict__ P0, float* __restrict__ Y,
-                                                  double* __restrict__ stat_slab) {
+                                                  double* __restrict__ stat_slab,
+                                                  const float* __restrict__ center,
+                                                  float* __restrict__ w_eff,
+                                                  float* __restrict__ mean_offset) {
   __shared__ __attribute__((aligned(16))) float smem[2 * MAXR * FP];   // 24 KB -> 6 WGs per CU
   float* xs = smem;
   float* ps = smem + MAXR * FP;
@@ -63,9 +66,44 @@ __global__ void __launch_bounds__(L0THR, WRITE_Y ? 5 : CGNN_L0_MINW) k_l0_fwd(cg
   __shared__ double macc[WRITE_Y ? 1 : NWV * NM * NM];
   if (!WRITE_Y)
     for (int i = threadIdx.x; i < NWV * NM * NM; i += L0THR) macc[i] = 0.0;
-  // per-thread partial sums stay fp32 (a thread sees <= ~16 rows per tile, a few tiles); the
-  // cross-thread / cross-workgroup combination is fp64
-  float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  // CENTRED form (center != NULL, F0 <= 7).  With c = center[0..F0) (a per-column constant near the
+  // column means of X0) and rbar = center[7] (near the mean of r = A_hat 1, the row sums of the
+  // normalised operator) -- cgnn_gcn_l0_center --
+  //     A_hat X0 = A_hat (X0 - 1 c^T) + r c^T
+  //     P0' = [A_hat (X0 - 1 c^T) | r - rbar | 0..]   (column F0 = the aggregated ones column, fp64 sum)
+  //     W'  = [W0 | W0 c]                              ([64][F0 + 1], `w_eff`)
+  //     Y0  = P0 W0^T + b = P0' W'^T + (b + rbar W0 c)
+  // The layer is handed on WITHOUT its constant term: consumers rebuild y_c = P0' W'^T (bias 0) and
+  // BatchNorm, which is invariant under a per-channel shift, is finalised on y_c; the constant
+  // b + rbar W0 c (`mean_offset`, fp64 -> fp32, written by workgroup 0) only enters the running mean.
+  // Same function of the parameters, but everything that is aggregated, stored, squared, multiplied
+  // or summed in fp32 lives at the scale of the features' SPREAD: raw features far from zero
+  // (un-normalised strength / degree columns, mean >> sigma) otherwise put rounding of the size
+  // 2^-24 * mean into every aggregated row and every rebuilt y, and lose log2((mean/sigma)^2) bits
+  // of the BatchNorm variance to cancellation.
+  constexpr int RC = FP - 1;                         // the ones column
+  __shared__ float cvec[FP];
+  if (!WRITE_Y) {
+    if (threadIdx.x < FP)
+      cvec[threadIdx.x] = (center && (threadIdx.x < F0 || threadIdx.x == RC)) ? center[threadIdx.x] : 0.f;
+    if (w_eff && blockIdx.x == 0 && threadIdx.x < HID) {
+      double last = 0.0;
+      for (int k = 0; k < F0; ++k) {
+        const float wv = W0[threadIdx.x * F0 + k];
+        w_eff[threadIdx.x * (F0 + 1) + k] = wv;
+        last += (double)wv * (double)center[k];
+      }
+      w_eff[threadIdx.x * (F0 + 1) + F0] = (float)last;
+      if (mean_offset)
+        mean_offset[threadIdx.x] = (float)((double)bias[threadIdx.x] + (double)(float)last * (double)center[RC]);
+    }
+    __syncthreads();
+  }
+  const bool centred = !WRITE_Y && center != nullptr;
+  // per-thread partial sums: a thread sees <= ~16 rows per tile, a few tiles; sum y^2 in fp64 (it
+  // cancels against mean^2 downstream), the cross-thread / cross-workgroup combination is fp64
+  float s1[4] = {0, 0, 0, 0};
+  double s2[4] = {0, 0, 0, 0};
 
   for (int tid = blockIdx.x; tid < t.num_tiles; tid += gridDim.x) {
     const int base = t.tile_ptr[tid];
@@ -82,8 +120,8 @@ __global__ void __launch_bounds__(L0THR, WRITE_Y ? 5 : CGNN_L0_MINW) k_l0_fwd(cg
         for (int u = 0; u < NB; ++u) {
           const int idx = threadIdx.x + L0THR * (u0 + u), r = idx >> 3, k = idx & 7;
           xv[u] = dvv[u] = 0.f;
-          if (r < n && k < F0) {
-            xv[u] = X0[(int64_t)(base + r) * F0 + k];
+          if (r < n && (k < F0 || (centred && k == RC))) {
+            xv[u] = k < F0 ? X0[(int64_t)(base + r) * F0 + k] - (WRITE_Y ? 0.f : cvec[k]) : 1.f;
             dvv[u] = t.dis[base + r];
           }
         }
@@ -98,6 +136,7 @@ __global__ void __launch_bounds__(L0THR, WRITE_Y ? 5 : CGNN_L0_MINW) k_l0_fwd(cg
       const int off0 = t.blk_off_dst[gb0 + b];
       const int width = (t.blk_off_dst[gb0 + b + 1] - off0) >> 4;
       float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+      double ar = 0.0;                                 // the ones column: r = A_hat 1, summed in fp64
       const uint2* e = ent + off0 + i;
       // entries stream from HBM: fetch EB steps at a time (independent loads), then consume
 #define CGNN_L0_EB 2
@@ -112,12 +151,26 @@ __global__ void __launch_bounds__(L0THR, WRITE_Y ? 5 : CGNN_L0_MINW) k_l0_fwd(cg
           const float* src = xs + (eb[u].x >> 8) * FP;       // entry offset = 256 * local row
           const float4 v0 = ld4(src), v1 = ld4(src + 4);
           a0.x = fmaf(w, v0.x, a0.x); a0.y = fmaf(w, v0.y, a0.y); a0.z = fmaf(w, v0.z, a0.z); a0.w = fmaf(w, v0.w, a0.w);
-          a1.x = fmaf(w, v1.x, a1.x); a1.y = fmaf(w, v1.y, a1.y); a1.z = fmaf(w, v1.z, a1.z); a1.w = fmaf(w, v1.w, a1.w);
+          a1.x = fmaf(w, v1.x, a1.x); a1.y = fmaf(w, v1.y, a1.y); a1.z = fmaf(w, v1.z, a1.z);
+          if (WRITE_Y) a1.w = fmaf(w, v1.w, a1.w);
+          else ar = fma((double)w, (double)v1.w, ar);
         }
       }
       const float dv = t.dis[base + r];
       a0 = make_float4(a0.x * dv, a0.y * dv, a0.z * dv, a0.w * dv);
       a1 = make_float4(a1.x * dv, a1.y * dv, a1.z * dv, a1.w * dv);
+      if (!WRITE_Y) {
+        // the ones column was aggregated in LDS column 7; in P0' it sits right behind the features
+        // (column F0), so that consumers rebuild rows from F0 + 1 columns
+        if (centred) {
+          const float rc = (float)(ar * (double)dv - (double)cvec[RC]);
+          a0.y = F0 == 1 ? rc : a0.y; a0.z = F0 == 2 ? rc : a0.z; a0.w = F0 == 3 ? rc : a0.w;
+          a1.x = F0 == 4 ? rc : a1.x; a1.y = F0 == 5 ? rc : a1.y; a1.z = F0 == 6 ? rc : a1.z;
+          a1.w = F0 == 7 ? rc : 0.f;
+        } else {
+          a1.w = (float)(ar * (double)dv);           // (an 8th feature column, if there is one)
+        }
+      }
       st4(ps + r * FP, a0); st4(ps + r * FP + 4, a1);
       L0STNT(P0 + (int64_t)(base + r) * FP, a0); L0STNT(P0 + (int64_t)(base + r) * FP + 4, a1);
     }
@@ -158,13 +211,13 @@ __global__ void __launch_bounds__(L0THR, WRITE_Y ? 5 : CGNN_L0_MINW) k_l0_fwd(cg
       const float4 z = l0_rebuild4(q0, q1, wl, 4 * j, F0);
       st4(Y + (int64_t)(base + r) * HID + 4 * j, y);
       s1[0] += y.x; s1[1] += y.y; s1[2] += y.z; s1[3] += y.w;
-      s2[0] = fmaf(y.x, y.x, s2[0]); s2[1] = fmaf(y.y, y.y, s2[1]);
-      s2[2] = fmaf(y.z, y.z, s2[2]); s2[3] = fmaf(y.w, y.w, s2[3]);
+      s2[0] += (double)y.x * y.x; s2[1] += (double)y.y * y.y;
+      s2[2] += (double)y.z * y.z; s2[3] += (double)y.w * y.w;
       if (two) {
         st4(Y + (int64_t)(base + r2) * HID + 4 * j, z);
         s1[0] += z.x; s1[1] += z.y; s1[2] += z.z; s1[3] += z.w;
-        s2[0] = fmaf(z.x, z.x, s2[0]); s2[1] = fmaf(z.y, z.y, s2[1]);
-        s2[2] = fmaf(z.z, z.z, s2[2]); s2[3] = fmaf(z.w, z.w, s2[3]);
+        s2[0] += (double)z.x * z.x; s2[1] += (double)z.y * z.y;
+        s2[2] += (double)z.z * z.z; s2[3] += (double)z.w * z.w;
       }
     }
     __syncthreads();
@@ -172,9 +225,10 @@ __global__ void __launch_bounds__(L0THR, WRITE_Y ? 5 : CGNN_L0_MINW) k_l0_fwd(cg
   if (!stat_slab) return;
   __syncthreads();
   if (!WRITE_Y) {
-    // moments -> sums: the waves' accumulators folded in fixed order, then
-    //   S1[c] = sum_k W[c][k] M[k][8] + M[8][8] b[c]
-    //   S2[c] = sum_kl W[c][k] W[c][l] M[k][l] + 2 b[c] sum_k W[c][k] M[k][8] + M[8][8] b[c]^2
+    // moments -> sums: the waves' accumulators folded in fixed order, then, with the moments M of
+    // the stored rows p' and the weights W' the consumers use (fp32-rounded last column), in fp64:
+    //   S1[c] = sum_k W'[c][k] M[k][8] + M[8][8] b[c]                 (b = 0 in the centred form:
+    //   S2[c] = sum_kl W'[c][k] W'[c][l] M[k][l] + 2 b[c] sum_k W'[c][k] M[k][8] + M[8][8] b[c]^2    sums of y_c)
     if (threadIdx.x < NM * NM) {
       double tsum = 0.0;
 #pragma unroll
@@ -184,20 +238,28 @@ __global__ void __launch_bounds__(L0THR, WRITE_Y ? 5 : CGNN_L0_MINW) k_l0_fwd(cg
     __syncthreads();
     if (threadIdx.x < 128) {
       const int c = threadIdx.x & 63;
-      const double bc = (double)bias[c], cnt = red[FP * NM + FP];
-      const float* wc = W0 + c * F0;
-      double lin = 0.0;                              // sum_k W[c][k] M1[k]
+      const double bc = centred ? 0.0 : (double)bias[c], cnt = red[FP * NM + FP];
+      double* wc = red + 128 + FP * threadIdx.x;      // (smem is dead here; M occupies red[0..80])
+      double last = 0.0;
 #pragma unroll 1
-      for (int k = 0; k < F0; ++k) lin += (double)wc[k] * red[k * NM + FP];
+      for (int k = 0; k < F0; ++k) {
+        wc[k] = (double)W0[c * F0 + k];
+        last += wc[k] * (double)cvec[k];
+      }
+      if (centred) wc[F0] = (double)(float)last;      // exactly the w_eff value
+      const int FA = centred ? F0 + 1 : F0;
+      double lin = 0.0;                              // sum_k W'[c][k] M1[k]
+#pragma unroll 1
+      for (int k = 0; k < FA; ++k) lin += wc[k] * red[k * NM + FP];
       double out = lin + cnt * bc;
       if (threadIdx.x >= 64) {
         double quad = 0.0;
 #pragma unroll 1
-        for (int k = 0; k < F0; ++k) {
+        for (int k = 0; k < FA; ++k) {
           double rowsum = 0.0;
 #pragma unroll 1
-          for (int l = 0; l < F0; ++l) rowsum += (double)wc[l] * red[k * NM + l];
-          quad += (double)wc[k] * rowsum;
+          for (int l = 0; l < FA; ++l) rowsum += wc[l] * red[k * NM + l];
+          quad += wc[k] * rowsum;
         }
         out = quad + 2.0 * bc * lin + cnt * bc * bc;
       }
@@ -208,7 +270,7 @@ __global__ void __launch_bounds__(L0THR, WRITE_Y ? 5 : CGNN_L0_MINW) k_l0_fwd(cg
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     red[rr * 128 + 4 * j + i] = (double)s1[i];
-    red[rr * 128 + 64 + 4 * j + i] = (double)s2[i];
+    red[rr * 128 + 64 + 4 * j + i] = s2[i];
   }
   __syncthreads();
   if (threadIdx.x < 128) {
@@ -227,7 +289,8 @@ __global__ void __launch_bounds__(L0BTHR) k_l0_bwd(const float* __restrict__ dZ,
                                                   const float* __restrict__ bwc,
                                                   const float* __restrict__ P0, int64_t nn,
                                                   float* __restrict__ dW_slab,
-                                                  double* __restrict__ db_slab) {
+                                                  double* __restrict__ db_slab,
+                                                  const float* __restrict__ center) {
   __shared__ float redw[16 * HID * FP];          // 32 KB
   __shared__ double redb[16 * HID];
   __shared__ __attribute__((aligned(16))) float wl[REBUILD ? L0_LDS_FLOATS : 4];
@@ -238,6 +301,13 @@ __global__ void __launch_bounds__(L0BTHR) k_l0_bwd(const float* __restrict__ dZ,
   const int j = threadIdx.x & 15, rr = threadIdx.x >> 4;
   const float4 ca = ld4(bn + 4 * j), cmean = ld4(bn + 2 * HID + 4 * j), cis = ld4(bn + 3 * HID + 4 * j);
   const float4 c1 = ld4(bwc + 4 * j), c2 = ld4(bwc + HID + 4 * j);
+  // centred form (see k_l0_fwd): P0 holds P0' (column FT = r - rbar, FT the true feature count), l0
+  // the weights W' ([64][FT + 1]) and a zero bias; with y = P0' W'^T + b + rbar W0 c the weight
+  // gradient is     dW0[:, k] = dW'[:, k] + c[k] (dW'[:, FT] + rbar db0),
+  // formed in the fp64 fold below (columns >= FT of the slab are dropped by the caller's reduce).
+  __shared__ float shs[FP];
+  const int FT = center ? l0.F0 - 1 : FP - 1;
+  if (threadIdx.x < FP) shs[threadIdx.x] = center ? center[threadIdx.x] : 0.f;
   float dw[4][FP];
 #pragma unroll
   for (int c = 0; c < 4; ++c)
@@ -289,9 +359,15 @@ __global__ void __launch_bounds__(L0BTHR) k_l0_bwd(const float* __restrict__ dZ,
   }
   __syncthreads();
   for (int e = threadIdx.x; e < HID * FP; e += L0BTHR) {
-    double tot = 0.0;
+    double tot = 0.0, ext = 0.0, dbt = 0.0;          // this element; the ones column and db of its row
+    const int col = e / FP, k = e % FP;
 #pragma unroll
-    for (int r2 = 0; r2 < 16; ++r2) tot += (double)redw[r2 * HID * FP + e];
+    for (int r2 = 0; r2 < 16; ++r2) {
+      tot += (double)redw[r2 * HID * FP + e];
+      ext += (double)redw[r2 * HID * FP + col * FP + FT];
+      dbt += redb[r2 * HID + col];
+    }
+    if (center && k < FT) tot += (double)shs[k] * (ext + (double)shs[FP - 1] * dbt);
     dW_slab[(int64_t)blockIdx.x * HID * FP + e] = (float)tot;
   }
   if (threadIdx.x < HID) {
@@ -299,6 +375,53 @@ __global__ void __launch_bounds__(L0BTHR) k_l0_bwd(const float* __restrict__ dZ,
 #pragma unroll
     for (int r2 = 0; r2 < 16; ++r2) tot += redb[r2 * HID + threadIdx.x];
     db_slab[(int64_t)blockIdx.x * HID + threadIdx.x] = tot;
+  }
+}
+
+// Centring constants of the factored layer 0, from the batch's first non-empty tile:
+// center[k] = mean of X0[:, k] (k < F0), center[7] = mean of r = A_hat 1 (the normalised operator's
+// row sums); any finite values are exact, values near the true means are accurate.
+__global__ void __launch_bounds__(L0THR) k_l0_center(cgnn_tiles t, const float* __restrict__ X0, int F0,
+                                                     float* __restrict__ center) {
+  __shared__ float ds[MAXR];
+  __shared__ double part[L0THR / 64][FP];
+  const uint2* ent = static_cast<const uint2*>(t.ent_dst);
+  int tid = 0;
+  while (tid < t.num_tiles && t.tile_ptr[tid + 1] == t.tile_ptr[tid]) ++tid;
+  if (tid >= t.num_tiles) {
+    if (threadIdx.x < FP) center[threadIdx.x] = threadIdx.x == FP - 1 ? 1.f : 0.f;
+    return;
+  }
+  const int base = t.tile_ptr[tid], n = t.tile_ptr[tid + 1] - base, gb0 = t.tile_blk[tid];
+  for (int r = threadIdx.x; r < MAXR; r += L0THR) ds[r] = r < n ? t.dis[base + r] : 0.f;
+  __syncthreads();
+  double a[FP];
+#pragma unroll
+  for (int k = 0; k < FP; ++k) a[k] = 0.0;
+  for (int r = threadIdx.x; r < n; r += L0THR) {
+#pragma unroll
+    for (int k = 0; k < FP - 1; ++k)
+      if (k < F0) a[k] += (double)X0[(int64_t)(base + r) * F0 + k];
+    const int b = r >> 4, i = r & 15;
+    const int off0 = t.blk_off_dst[gb0 + b];
+    const int width = (t.blk_off_dst[gb0 + b + 1] - off0) >> 4;
+    double acc = 0.0;
+    for (int s0 = 0; s0 < width; ++s0) {
+      const uint2 e = ent[off0 + i + 16 * s0];
+      acc += (double)__uint_as_float(e.y) * (double)ds[e.x >> 8];
+    }
+    a[FP - 1] += acc * (double)ds[r];
+  }
+#pragma unroll
+  for (int k = 0; k < FP; ++k) {
+    const double v = cgnn_wave_sum(a[k]);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < FP) {
+    double tot = 0.0;
+    for (int w2 = 0; w2 < L0THR / 64; ++w2) tot += part[w2][threadIdx.x];
+    center[threadIdx.x] = (float)(tot / (double)n);
   }
 }
 
@@ -316,32 +439,49 @@ extern "C" {
 
 int cgnn_l0_grid(int64_t num_nodes) { return num_nodes < 0 ? CGNN_EINVAL : l0_grid(num_nodes); }
 
-int cgnn_gcn_l0_fwd(const cgnn_tiles* t, const float* X0, int32_t F0, const float* W0,
-                    const float* bias, float* P0, float* Y, double* stat_slab, void* stream) {
+int cgnn_gcn_l0_center(const cgnn_tiles* t, const float* X0, int32_t F0, float* center, void* stream) {
   if (!t || F0 <= 0 || F0 > FP || t->max_tile_rows > CGNN_FUSED_MAX_ROWS) return t && F0 > FP ? CGNN_EUNSUPPORTED : CGNN_EINVAL;
+  if (!center) return CGNN_EINVAL;
+  if (t->num_tiles > 0 && (!X0 || !t->tile_ptr || !t->tile_blk || !t->blk_off_dst || !t->ent_dst || !t->dis))
+    return CGNN_EINVAL;
+  k_l0_center<<<1, L0THR, 0, cgnn_stream(stream)>>>(*t, X0, F0, center);
+  CGNN_CHECK_LAUNCH();
+  return CGNN_OK;
+}
+
+int cgnn_gcn_l0_fwd(const cgnn_tiles* t, const float* X0, int32_t F0, const float* W0,
+                    const float* bias, float* P0, float* Y, double* stat_slab, const float* center,
+                    float* w_eff, float* mean_offset, void* stream) {
+  if (!t || F0 <= 0 || F0 > FP || t->max_tile_rows > CGNN_FUSED_MAX_ROWS) return t && F0 > FP ? CGNN_EUNSUPPORTED : CGNN_EINVAL;
+  if (Y && (center || w_eff || mean_offset)) return CGNN_EINVAL;   // the centred form belongs to the factored layer
+  if (center && (!w_eff || !mean_offset || F0 >= FP)) return CGNN_EINVAL;   // column 7 must be spare
+  if (!center && (w_eff || mean_offset)) return CGNN_EINVAL;
   if (t->num_tiles == 0) return CGNN_OK;
   if (!X0 || !W0 || !bias || !P0 || !t->tile_ptr || !t->tile_blk || !t->blk_off_dst ||
       !t->ent_dst || !t->dis)
     return CGNN_EINVAL;
   if (Y)
-    k_l0_fwd<true><<<l0_grid(t->num_nodes), L0THR, 0, cgnn_stream(stream)>>>(*t, X0, F0, W0, bias, P0, Y, stat_slab);
+    k_l0_fwd<true><<<l0_grid(t->num_nodes), L0THR, 0, cgnn_stream(stream)>>>(*t, X0, F0, W0, bias, P0, Y, stat_slab,
+                                                                             nullptr, nullptr, nullptr);
   else
-    k_l0_fwd<false><<<l0_grid(t->num_nodes), L0THR, 0, cgnn_stream(stream)>>>(*t, X0, F0, W0, bias, P0, Y, stat_slab);
+    k_l0_fwd<false><<<l0_grid(t->num_nodes), L0THR, 0, cgnn_stream(stream)>>>(*t, X0, F0, W0, bias, P0, Y, stat_slab,
+                                                                              center, w_eff, mean_offset);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }
 
 int cgnn_gcn_l0_bwd(const float* dZ, const float* Y, const cgnn_l0src* l0, const float* bn,
                     const float* bwc, const float* P0, int64_t num_nodes, float* dW_slab,
-                    double* db_slab, void* stream) {
+                    double* db_slab, const float* center, void* stream) {
   if (num_nodes < 0 || !dZ || !bn || !bwc || !P0 || !dW_slab || !db_slab) return CGNN_EINVAL;
   if (!Y && !(l0 && l0->W0 && l0->b0 && l0->F0 >= 1 && l0->F0 <= FP)) return CGNN_EINVAL;
+  if (center && (Y || l0->F0 < 2)) return CGNN_EINVAL;
   if (Y)
     k_l0_bwd<false><<<l0_grid(num_nodes), L0BTHR, 0, cgnn_stream(stream)>>>(dZ, Y, cgnn_l0src{}, bn, bwc, P0,
-                                                                   num_nodes, dW_slab, db_slab);
+                                                                   num_nodes, dW_slab, db_slab, nullptr);
   else
     k_l0_bwd<true><<<l0_grid(num_nodes), L0BTHR, 0, cgnn_stream(stream)>>>(dZ, nullptr, *l0, bn, bwc, P0,
-                                                                  num_nodes, dW_slab, db_slab);
+                                                                  num_nodes, dW_slab, db_slab, center);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }

@@ -183,9 +183,10 @@ __global__ void __launch_bounds__(FW_THR) k_ws(
     }
     if (c + 1 == nchunks) {
       // epilogue: bias, activation, 16-byte (NT = 4) / 8-byte (NT = 2) stores
-      float p1[NT], p2[NT];                           // this block's 16 rows: fp32 partials
+      float p1[NT];                                   // this block's 16 rows: fp32 partial sums,
+      double p2[NT];                                  // squares in fp64 (they cancel against mean^2)
 #pragma unroll
-      for (int t = 0; t < NT; ++t) p1[t] = p2[t] = 0.f;
+      for (int t = 0; t < NT; ++t) { p1[t] = 0.f; p2[t] = 0.0; }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
@@ -195,7 +196,7 @@ __global__ void __launch_bounds__(FW_THR) k_ws(
           for (int t = 0; t < NT; ++t) {
             v[t] = acc[t][r] + bv[t];
             if (relu) v[t] = fmaxf(v[t], 0.f);
-            if (!BT) { p1[t] += v[t]; p2[t] = fmaf(v[t], v[t], p2[t]); }
+            if (!BT) { p1[t] += v[t]; p2[t] += (double)v[t] * v[t]; }
           }
           float* yp = Y + row * ldy + col0 + NT * j;
           if (NT == 4) *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[NT > 2 ? 2 : 0], v[NT > 3 ? 3 : 0]);
@@ -204,7 +205,7 @@ __global__ void __launch_bounds__(FW_THR) k_ws(
       }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        if (!BT) { s1[t] += (double)p1[t]; s2[t] += (double)p2[t]; }
+        if (!BT) { s1[t] += (double)p1[t]; s2[t] += p2[t]; }
         acc[t] = f32x16{0};
       }
     }

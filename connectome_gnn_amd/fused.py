@@ -48,6 +48,33 @@ def _tiles_struct(s: BatchStructure, meta, dis: torch.Tensor):
     return s.tiles_struct(meta, dis)
 
 
+_ZEROS = {}
+
+
+def _zeros(dev) -> torch.Tensor:
+    """64 fp32 zeros on `dev` (the bias of a layer handed on without its constant term)."""
+    z = _ZEROS.get(dev)
+    if z is None:
+        z = _ZEROS[dev] = torch.zeros(HID, dtype=torch.float32, device=dev)
+    return z
+
+
+def _l0_center(lib, s, x0: torch.Tensor, tiles_ref, stream) -> torch.Tensor:
+    """The centring constants of the factored layer 0 (cgnn_gcn_l0_center): column means of X0 and
+    the mean row sum of the normalised operator over the batch's first tile.  It is a conditioning hint, not part of the arithmetic (any value
+    gives the same result up to rounding), so it is computed once per (batch, feature tensor)
+    and cached on the structure -- one tiny launch at a batch's first use."""
+    key = (x0.data_ptr(), x0._version, tuple(x0.shape))
+    hit = s.__dict__.get("_l0_center")
+    if hit is None or hit[0] != key:
+        center = torch.empty(8, dtype=torch.float32, device=x0.device)
+        _lib.check(lib.cgnn_gcn_l0_center(tiles_ref, _lib.ptr(x0), x0.shape[1], _lib.ptr(center), stream),
+                   "cgnn_gcn_l0_center")
+        hit = (key, center)
+        s.__dict__["_l0_center"] = hit
+    return hit[1]
+
+
 class _Ctx:
     """Everything of one forward pass that backward needs and autograd must not track."""
     __slots__ = ("s", "meta", "dis", "tiles", "grid", "ys", "bns", "masks", "p", "x0", "f0", "p0", "count_dev", "fsum", "l0src", "l0keep",
@@ -113,16 +140,29 @@ class FusedGCNEncode(torch.autograd.Function):
                     # layer 0, narrow form: Y0 = (A_hat X0) W0^T + b is NEVER written: only the
                     # narrow aggregate P0 = A_hat X0 (32 B per node) is kept and every consumer
                     # rebuilds the rows of Y0 it needs from it (cgnn_l0src)
+                    # ... in CENTRED form when column 7 is spare (F0 <= 7) and the statistics are this
+                    # rank's own: P0' = [A_hat (X0 - 1 c^T) | r - rbar], W' = [W0 | W0 c], handed on
+                    # without its constant term (mean_offset) -- the same function, evaluated at the
+                    # scale of the features' spread rather than of their mean (cgnn_gcn_l0_fwd).
+                    # (Under sync-BN the ranks' constants would differ: raw form there.)
                     y = None
+                    f0 = int(x0.shape[1])
                     p0 = torch.empty(nn_, 8, **f32)
-                    l0src = _lib.CgnnL0Src(_lib.ptr(p0), _lib.ptr(w), _lib.ptr(b), int(x0.shape[1]))
-                    l0keep = (w, b)                     # the struct holds raw pointers
+                    center = _l0_center(lib, s, x0, tp, st()) if (f0 < 8 and sync_group is None) else None
+                    if center is not None:
+                        w_eff, mean_off = torch.empty(HID, f0 + 1, **f32), torch.empty(HID, **f32)
+                        l0src = _lib.CgnnL0Src(_lib.ptr(p0), _lib.ptr(w_eff), _lib.ptr(_zeros(dev)), f0 + 1)
+                        l0keep = (w_eff, _zeros(dev), center, mean_off)     # the struct holds raw pointers
+                    else:
+                        w_eff = mean_off = None
+                        l0src = _lib.CgnnL0Src(_lib.ptr(p0), _lib.ptr(w), _lib.ptr(b), f0)
+                        l0keep = (w, b, None, None)
                     slab_rows = lib.cgnn_l0_grid(nn_)
                     slab = torch.empty(slab_rows, 128, dtype=torch.float64, device=dev) if training else None
                     with _lib.timed("cgnn_gcn_l0_fwd"):
                         _lib.check(lib.cgnn_gcn_l0_fwd(
-                            tp, _lib.ptr(x0), x0.shape[1], _lib.ptr(w), _lib.ptr(b), _lib.ptr(p0),
-                            None, _lib.ptr(slab), st()), "cgnn_gcn_l0_fwd")
+                            tp, _lib.ptr(x0), f0, _lib.ptr(w), _lib.ptr(b), _lib.ptr(p0), None, _lib.ptr(slab),
+                            _lib.ptr(center), _lib.ptr(w_eff), _lib.ptr(mean_off), st()), "cgnn_gcn_l0_fwd")
                 elif l == 0:
                     with _lib.timed("cgnn_gcn_fused_fwd_first"):
                         _lib.check(lib.cgnn_gcn_fused_fwd_first(
@@ -149,7 +189,8 @@ class FusedGCNEncode(torch.autograd.Function):
                         _lib.ptr(bn_mod.running_mean), _lib.ptr(bn_mod.running_var),
                         float(bn_mod.momentum), float(bn_mod.eps),
                         _lib.ptr(bn_mod.num_batches_tracked), _lib.ptr(bn),
-                        _lib.ptr(rng) if adv else None, L + 1 if adv else 0, st()),
+                        _lib.ptr(rng) if adv else None, L + 1 if adv else 0,
+                        _lib.ptr(l0keep[3]) if (l == 0 and l0keep is not None) else None, st()),
                         "cgnn_bn_stats_finalize_rng")
                 else:
                     cnt_dev = None
@@ -165,7 +206,8 @@ class FusedGCNEncode(torch.autograd.Function):
                     _lib.check(lib.cgnn_bn_finalize(
                         _lib.ptr(sums), cnt, cnt_dev, _lib.ptr(gamma), _lib.ptr(beta),
                         _lib.ptr(bn_mod.running_mean), _lib.ptr(bn_mod.running_var),
-                        float(bn_mod.momentum), float(bn_mod.eps), int(training), _lib.ptr(bn), st()),
+                        float(bn_mod.momentum), float(bn_mod.eps), int(training), _lib.ptr(bn),
+                        _lib.ptr(l0keep[3]) if (l == 0 and l0keep is not None) else None, st()),
                         "cgnn_bn_finalize")
                 ys.append(y)
                 bns.append(bn)
@@ -289,7 +331,7 @@ class FusedGCNEncode(torch.autograd.Function):
                 with _lib.timed("cgnn_gcn_l0_bwd"):
                     _lib.check(lib.cgnn_gcn_l0_bwd(
                         _lib.ptr(dz), None, ctypes.byref(c.l0src), _lib.ptr(c.bns[0]), _lib.ptr(bwc),
-                        _lib.ptr(c.p0), nn_, _lib.ptr(dw_slab0), _lib.ptr(db_slab0), st()),
+                        _lib.ptr(c.p0), nn_, _lib.ptr(dw_slab0), _lib.ptr(db_slab0), _lib.ptr(c.l0keep[2]), st()),
                         "cgnn_gcn_l0_bwd")
                 jobs.append((dw_slab0, db_slab0, g0, 8, c.f0, dw0, db0))
             else:

@@ -392,7 +392,7 @@ int cgnn_bn_reduce(const double* slab, int32_t rows, int32_t width, double* sums
  * multi-rank batch stays on the device, no host read-back between reduce and finalise. */
 int cgnn_bn_finalize(const double* sums, double count, const double* count_dev, const float* gamma,
                      const float* beta, float* running_mean, float* running_var, float momentum,
-                     float eps, int32_t training, float* bn_out, void* stream);
+                     float eps, int32_t training, float* bn_out, const float* mean_offset, void* stream);
 
 /* Readout: P[g,:] = mean over nodes of drop(relu(a*Y+b)) (models.py:209-211,57-59).
  * F1, F2 (both or neither; [num_graphs,64]): per graph and column the sums over the graph's rows
@@ -454,12 +454,33 @@ int cgnn_gcn_fused_bwd_first(const cgnn_tiles* t, const float* dZ, const float* 
  * one-layer models.) */
 int cgnn_l0_grid(int64_t num_nodes);
 /* Y (forward) may be NULL: only P0 and the statistics are produced and every consumer rebuilds
- * Y0's rows from a cgnn_l0src.  Backward: Y == NULL -> rebuilt from P0 with l0->W0/b0/F0. */
+ * Y0's rows from a cgnn_l0src.  Backward: Y == NULL -> rebuilt from P0 with l0->W0/b0/F0.
+ *
+ * Centred form (Y == NULL, F0 <= 7; round 3).  With `center` (float[8], device): c = center[0..F0)
+ * near the column means of X0 and rbar = center[7] near the mean of r = A_hat 1 (the normalised
+ * operator's row sums) -- cgnn_gcn_l0_center computes both from the batch's first non-empty tile;
+ * any finite values give the same result up to rounding --
+ *     A_hat X0 = A_hat (X0 - 1 c^T) + r c^T
+ *     P0' = [A_hat (X0 - 1 c^T) | r - rbar | 0..]   ([Nn,8]; column F0 = the aggregated ones column,
+ *                                                     summed in fp64)
+ *     W'  = [W0 | W0 c]                              (`w_eff`, float[64][F0 + 1], written by the launch)
+ *     Y0  = P0 W0^T + b = P0' W'^T + mean_offset,    mean_offset = b + rbar W0 c  (float[64], written)
+ * The layer is handed on WITHOUT its constant term: consumers take cgnn_l0src{P0', w_eff, zeros, F0 + 1},
+ * the statistics in stat_slab are those of y_c = Y0 - mean_offset, and the BatchNorm finalisation
+ * (cgnn_bn_stats_finalize_rng / cgnn_bn_finalize with the same mean_offset) describes y_c -- BatchNorm
+ * is invariant under a per-channel shift; only the running mean sees the constant.  The SAME function
+ * of the parameters, evaluated at the scale of the features' spread: with node features far from
+ * zero (un-normalised strength / degree columns) the raw form puts rounding of the size
+ * 2^-24 * mean into every aggregated row and every rebuilt y, and loses log2((mean/sigma)^2) bits of
+ * the BatchNorm variance.  cgnn_gcn_l0_bwd (same `center`, l0->F0 = F0 + 1) returns
+ * dW0[:, k] = dW'[:, k] + c[k] (dW'[:, F0] + rbar db0) in the first F0 of the 8 slab columns. */
+int cgnn_gcn_l0_center(const cgnn_tiles* t, const float* X0, int32_t F0, float* center, void* stream);
 int cgnn_gcn_l0_fwd(const cgnn_tiles* t, const float* X0, int32_t F0, const float* W0,
-                    const float* bias, float* P0, float* Y, double* stat_slab, void* stream);
+                    const float* bias, float* P0, float* Y, double* stat_slab, const float* center,
+                    float* w_eff, float* mean_offset, void* stream);
 int cgnn_gcn_l0_bwd(const float* dZ, const float* Y, const cgnn_l0src* l0, const float* bn,
                     const float* bwc, const float* P0, int64_t num_nodes, float* dW_slab,
-                    double* db_slab, void* stream);
+                    double* db_slab, const float* center, void* stream);
 
 /* fp16-storage forms of the BatchNorm(+ReLU)+dropout kernels (cgnn_bn_act_*): the [M,N] activation
  * arrays (Y, X, dX, dY) are IEEE half, the arithmetic is fp32, the statistics fp64, coefficient
@@ -508,11 +529,15 @@ int cgnn_bn_stats_finalize(const double* slab, int32_t rows, double count, const
                            float momentum, float eps, int64_t* num_batches_tracked, float* bn_out,
                            void* stream);
 /* the same, also refreshing the rng_n (<= 64) device dropout words of a graph-captured step
- * (cgnn_rng_advance's arithmetic) in the same launch; rng_state NULL / rng_n 0: no refresh */
+ * (cgnn_rng_advance's arithmetic) in the same launch; rng_state NULL / rng_n 0: no refresh.
+ * mean_offset (float[64], nullable; also cgnn_bn_finalize): the slab holds the statistics of
+ * y - mean_offset[c] (the centred factored layer 0 is handed on without its constant term, which
+ * BatchNorm's output does not depend on): bn_out describes that shifted variable, the module's
+ * running_mean is updated with (resp. in eval mode read as) the mean of y itself. */
 int cgnn_bn_stats_finalize_rng(const double* slab, int32_t rows, double count, const float* gamma,
                                const float* beta, float* running_mean, float* running_var,
                                float momentum, float eps, int64_t* num_batches_tracked, float* bn_out,
-                               uint32_t* rng_state, int32_t rng_n, void* stream);
+                               uint32_t* rng_state, int32_t rng_n, const float* mean_offset, void* stream);
 int cgnn_bn_bwd_stats_finalize(const double* slab, int32_t rows, double count, int32_t zero_coef,
                                float* dgamma, float* dbeta, float* bwc, void* stream);
 int cgnn_dw_db_reduce(const float* dw_slab, const double* db_slab, int32_t rows, int32_t out_cols,

@@ -760,35 +760,67 @@ def test_cfg5_fp16_storage_gcn_vs_fp32_oracle(dropout):
         C.GraphSAGEConnectome(5, 64, storage="fp16")
 
 
-@pytest.mark.parametrize("offset,scale", [(0.0, 1.0), (3.0, 1.0), (-2.0, 0.25)])
+@pytest.mark.parametrize("offset,scale", [(0.0, 1.0), (3.0, 1.0), (-2.0, 0.25), (10.0, 1.0), (100.0, 1.0),
+                                          (300.0, 1.0), (1000.0, 10.0), (-50.0, 0.1)])
 def test_fused_gcn_layer0_moment_statistics_with_offset_features(offset, scale):
-    """Layer 0's BatchNorm sums come from the second moments of P0 = A_hat X0 (fused_gcn_l0.hip):
-    sum y^2 is a quadratic form of moments that cancel when the features sit far from zero.
-    Node features with a mean of several standard deviations must still give the oracle's
-    logits, loss, gradients and running statistics at the usual tolerances."""
+    """Layer 0's BatchNorm sums come from the second moments of P0 = A_hat X0 (fused_gcn_l0.hip),
+    CENTRED on a per-workgroup shift (round 3): node features whose mean is many standard
+    deviations (un-normalised strength / degree columns, mean / sigma up to 500 here) must still give
+    the oracle's logits, loss, gradients and running statistics.  Up to a few sigma that is the usual
+    fp32 tolerance.  Beyond, the fp32 reference ITSELF drifts from the exact answer (its X0 W0^T
+    carries 2^-24 * mean of rounding against a spread of sigma): there logits / loss / running
+    statistics must be within the usual tolerance of the fp32 oracle OR at least as close to the
+    float64 oracle as the fp32 oracle is; gradients go through the suite's rules (tests/parity.py), and
+    where the mean is >= 100 sigma the weight gradients must be markedly closer to float64 than the
+    fp32 reference's."""
     import connectome_gnn_amd as C
     graphs = C.generate_dataset(12, 360, 14, seed=5)
     b = C.collate_graphs(graphs)
     b.node_features = b.node_features * scale + offset
+    far = abs(offset) > 5.0 * scale
     torch.manual_seed(11)
     m = _model("gcn", 5, 64, dropout=0.0)
     sd0 = {k: v.clone() for k, v in m.state_dict().items()}
     lo, loss_o, g32, stats_o = P.oracle_run("gcn", sd0, b)
-    _, _, g64, _ = P.oracle_run("gcn", sd0, b, dtype=torch.float64)
+    lo64, loss64, g64, stats64 = P.oracle_run("gcn", sd0, b, dtype=torch.float64)
     m = m.to(DEV).train()
     bd = b.to(DEV)
     lg = m(bd)
     assert m.impl_used == "fused"
     loss_g = torch.nn.functional.cross_entropy(lg, bd.labels)
     loss_g.backward()
-    torch.testing.assert_close(lg.cpu(), lo, **TOL)
-    torch.testing.assert_close(loss_g.cpu(), loss_o, **TOL)
+
+    def close(got, want32, want64, what, tol=TOL):
+        got = got.detach().cpu()
+        try:
+            torch.testing.assert_close(got, want32, **tol)
+            return
+        except AssertionError:
+            if not far:
+                raise
+        e_gpu = float((got.double() - want64).abs().max())
+        e_cpu = float((want32.double() - want64).abs().max())
+        assert e_gpu <= e_cpu + 1e-12, f"{what}: HIP {e_gpu:.3e} from float64, the fp32 oracle {e_cpu:.3e}"
+
+    close(lg, lo, lo64, "logits")
+    close(loss_g, loss_o, loss64, "loss")
     floor = P.NoiseFloor("gcn", sd0, b)
+    worst = 0.0
     for k_, p in m.named_parameters():
         P.assert_grad(k_, p.grad, g32[k_], g64[k_], f"offset{offset}", floor)
+        if k_.endswith("linear.weight"):
+            e_gpu = float((p.grad.detach().cpu().double() - g64[k_]).abs().max())
+            e_cpu = float((g32[k_].double() - g64[k_]).abs().max())
+            worst = max(worst, e_gpu / max(e_cpu, 1e-30))
+    if offset >= 100.0:
+        # far from zero the centred layer 0 is not merely "as good as fp32": the weight gradients
+        # must be several times CLOSER to float64 than the fp32 reference's own (measured 0.01-0.3).
+        # ((-50, 0.1) is left to the rules above: there every fp32 evaluation -- the reference, the
+        # layered and the fused HIP path -- shares one deviation from float64, tools/offset_probe.py.)
+        assert worst <= 0.5, f"weight gradients are only {worst:.2f}x the fp32 oracle's distance from float64"
     sd = m.state_dict()
     for k_, v in stats_o.items():
-        torch.testing.assert_close(sd[k_].cpu(), v, rtol=2e-5, atol=1e-6, msg=lambda s: f"{k_}: {s}")
+        close(sd[k_], v, stats64[k_], k_, dict(rtol=2e-5, atol=1e-6))
 
 
 def test_backward_unit_equals_backward():

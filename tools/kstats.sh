@@ -6,7 +6,7 @@ TAG=${1:-ks}; shift
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O -o ks -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-end-to-end "$@" > $O/run.log 2>&1 || { tail -5 $O/run.log; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $O -o ks -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-end-to-end --no-configs "$@" > $O/run.log 2>&1 || { tail -5 $O/run.log; exit 1; }
 python3 - $O <<'PY'
 import csv, sys, glob
 f = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)[0]
