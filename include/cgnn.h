@@ -365,6 +365,7 @@ int cgnn_dense_aggregate_c16(const void* dfrag, const int32_t* dstep, const uint
                              int64_t ldx, int32_t F, const float* bias, void* Y, int64_t ldy,
                              double* stat_slab, void* stream);
 
+
 /* Layer 0 forward.  X0 [Nn,F0] (F0 <= 16), W0 [64,F0], bias [64] -> Y [Nn,64];
  * stat_slab [grid][128] fp64 (sum(y) | sum(y^2)) or NULL (eval). */
 int cgnn_gcn_fused_fwd_first(const cgnn_tiles* t, const float* X0, int32_t F0, const float* W0,

@@ -18,8 +18,6 @@ norm = s.gcn_norm()
 x16 = torch.randn(s.num_nodes, 256, device="cuda").half()
 mden = ops.dense_adj_f16(s, norm.coef_dst, norm.selfc)
 pk = ops.dense_pack_f16(s, norm.coef_dst, norm.selfc)
-print(f"  dense M {mden.numel() * 2 / 1e6:.1f} MB; per-fragment form {pk.nbytes() / 1e6:.1f} MB "
-      f"({pk.num_dense} dense + {pk.num_sparse} sparse fragments of {mden.numel() // 512})")
 junk = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
 for name, fn in (("dense_agg ", lambda: ops.dense_aggregate_f16_raw(s, mden, x16)),
                  ("packed_agg", lambda: ops.dense_aggregate_c16_raw(s, pk, x16))):
