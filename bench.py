@@ -155,12 +155,13 @@ def end_to_end(C, ds, model, opt, bsz: int, epochs: int = 6) -> dict:
     big = PackedDataset(rep(ds.x), rep(ds.edge_local), rep(ds.edge_weight), rep(ds.labels))
     tr = C.Trainer(model, opt, device=str(ds.x.device))
 
-    def timed_epochs(ld):
-        tr.train_epoch(ld)
+    def timed_epochs(ld, trainer=None, n_epochs=epochs):
+        trainer = trainer or tr
+        trainer.train_epoch(ld)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(epochs):
-            tr.train_epoch(ld)
+        for _ in range(n_epochs):
+            trainer.train_epoch(ld)
         torch.cuda.synchronize()
         return time.perf_counter() - t0
 
@@ -188,6 +189,23 @@ def end_to_end(C, ds, model, opt, bsz: int, epochs: int = 6) -> dict:
         out["subject_cache"] = {"graphs_per_s": steps * bsz / dt3, "ms_per_step": dt3 / steps * 1e3,
                                 "what": "fresh shuffled batch every step; blocked-ELL / dis of every "
                                         "subject built once, a batch's structure = three gathers on the side stream"}
+        # ... and with Trainer(graph=True): one captured step per batch size, the batch assembled INSIDE
+        # the graph from its subject ids (graphed.GraphedResidentStep) -- per-epoch reshuffling at replay
+        # speed; also at one rank's 512-graph share of the batch (8-GPU strong scaling with a real loader)
+        if getattr(opt, "defaults", {}).get("capturable", False):
+            trg = C.Trainer(model, opt, device=str(ds.x.device), graph=True)
+            for tag, b2 in (("subject_cache_graph", bsz), ("subject_cache_graph_512", 512)):
+                if b2 > bsz:
+                    continue
+                ld4 = ResidentDataLoader(big, batch_size=b2, shuffle=True, structure_cache=True, prefetch=True,
+                                         prepare=model.prepare_batch)
+                ne = epochs if b2 == bsz else 2
+                dt4 = timed_epochs(ld4, trg, ne)
+                st4 = ne * len(ld4)
+                out[tag] = {"graphs_per_s": st4 * b2 / dt4, "ms_per_step": dt4 / st4 * 1e3, "batch": b2,
+                            "what": "fresh shuffled batch every step through Trainer(graph=True): HIP-graph "
+                                    "replay with the batch assembled inside the graph from its subject ids"}
+            trg.clear_graphs()
     return out
 
 
@@ -376,6 +394,8 @@ def run_workload(args, name: str, rank: int, world: int, dev, *, launch: str, ba
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
     final_loss = float(loss.detach())
+    loss = None     # drop the last eager autograd graph: its AccumulateGrad nodes are tied to this stream,
+                    # and a later capture of the same parameters on another stream must not meet them
 
     graphs_per_s = global_batch * args.steps / dt
     bpg = algorithmic_bytes_per_graph(model_kind, n, e, hidden, elem)

@@ -15,7 +15,10 @@ What makes the step capturable:
     (``model.rng_device_state``);
   * BatchNorm's ``num_batches_tracked`` is bumped on the device by the finalise kernel.
 The batch must be resident with its structure (CSR / blocked-ELL) already built: structure
-building reads sizes back to the host and stays outside the graph, like collate.
+building reads sizes back to the host and stays outside the graph, like collate.  Autograd graphs
+of EARLIER eager steps on the same parameters must be gone by then (do not keep their ``loss``
+tensors alive): their AccumulateGrad nodes are tied to the stream they ran on, and meeting them
+from the capturing stream ends the capture with a fault inside the HIP runtime.
 
 Data parallel (``grad_sync`` = dist.GradSync): gradients are views of one flat buffer that lives
 outside the graph's pool, so the step is cut at its single exchange point into
@@ -45,13 +48,19 @@ class GraphedTrainStep:
 
     def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer, batch,
                  loss_fn: Optional[Callable] = None, grad_sync: Optional[Callable[[], None]] = None,
-                 warmup: int = 3, collectives: str = "split", local_graphs: Optional[int] = None):
+                 warmup: int = 3, collectives: str = "split", local_graphs: Optional[int] = None,
+                 make_batch: Optional[Callable[[], object]] = None):
         """local_graphs: with dist.GradSync and shards that may be unequal, this rank's graph count
-        (the update is then the exact global-batch gradient, see dist.GradSync)."""
+        (the update is then the exact global-batch gradient, see dist.GradSync).
+
+        make_batch: assemble the batch INSIDE the captured step from fixed-address inputs (``batch``
+        is then only the first batch, used for the device and the warm-up): every replay re-runs the
+        assembly, so one graph serves any batch of that shape -- see GraphedResidentStep."""
         if collectives not in ("split", "captured"):
             raise ValueError("collectives must be 'split' or 'captured'")
         dev = batch.node_features.device
         self.model, self.optimizer, self.batch = model, optimizer, batch
+        self.make_batch = make_batch
         self.loss_fn = loss_fn or torch.nn.CrossEntropyLoss()
         self.grad_sync = grad_sync
         self._weighted = hasattr(grad_sync, "numel")       # dist.GradSync: exact with unequal shards
@@ -108,7 +117,8 @@ class GraphedTrainStep:
 
     def _fwd_bwd(self) -> torch.Tensor:
         self._zero()
-        loss = self.loss_fn(self.model(self.batch), self.batch.labels)
+        batch = self.batch if self.make_batch is None else self.make_batch()
+        loss = self.loss_fn(self.model(batch), batch.labels)
         ops.backward_unit(loss)
         return loss.detach()
 
@@ -126,3 +136,28 @@ class GraphedTrainStep:
             self._exchange()
             self.graph_tail.replay()
         return self.loss
+
+
+class GraphedResidentStep(GraphedTrainStep):
+    """One captured step for EVERY batch of a given size drawn from a device-resident dataset with a
+    per-subject structure cache (structure_cache.py: one graph per tile, the per-tile GCN path).
+
+    The batch is assembled inside the graph -- five gathers by the subject ids in a fixed device
+    buffer (node features, labels, the two block-offset rows, `dis`) -- so a replay is: copy this
+    batch's ids into the buffer, launch.  ``Trainer(graph=True)`` uses it for ResidentBatch inputs:
+    a loader that re-shuffles every epoch (the reference's semantics, graph.py:190-197) then runs at
+    replay speed instead of issuing ~45 launches per step from Python."""
+
+    def __init__(self, model, optimizer, first_batch, loss_fn=None, **kw):
+        from .structure_cache import ResidentBatch
+        cache = first_batch._cache
+        self.ids_buf = first_batch._ids.clone()
+        cache.static(int(self.ids_buf.numel()))            # batch-size constants exist before capture
+        super().__init__(model, optimizer, first_batch, loss_fn,
+                         make_batch=lambda: ResidentBatch(cache, self.ids_buf), **kw)
+
+    def __call__(self, batch=None) -> torch.Tensor:
+        if batch is not None:
+            self.ids_buf.copy_(batch._ids)
+        return super().__call__()
+

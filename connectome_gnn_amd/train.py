@@ -77,8 +77,11 @@ class Trainer:
         batches each epoch) gets its training step captured as a HIP graph
         (graphed.GraphedTrainStep) on its SECOND sighting and replayed afterwards -- one launch
         instead of ~45 for the small batches where issuing kernels from Python costs more than
-        running them.  Batches that never repeat (shuffle=True, a host loader whose ``.to()``
-        makes new tensors every step) run the ordinary eager step and leave nothing behind.  At
+        running them.  Batches of a ``ResidentDataLoader(structure_cache=True)`` are replayed from
+        their FIRST sighting whatever their composition (one graph per batch size, the batch
+        assembled inside it: graphed.GraphedResidentStep), so per-epoch reshuffling keeps replay
+        speed.  Other batches that never repeat (a host loader whose ``.to()`` makes new tensors
+        every step) run the ordinary eager step and leave nothing behind.  At
         most ``max_graphs`` steps are kept (each holds its batch and a private pool with every
         activation and gradient of the step); once that many exist, further batches stay eager.
         The optimizer must be capturable (``torch.optim.Adam(..., capturable=True)``)."""
@@ -132,6 +135,23 @@ class Trainer:
 
     def _graphed_step(self, batch) -> Optional[torch.Tensor]:
         """Replay (or, on a batch's second sighting, capture) the step; None = run it eagerly."""
+        ids = getattr(batch, "_ids", None)
+        if ids is not None and getattr(batch, "_cache", None) is not None:
+            # a batch of a resident dataset with a per-subject structure cache: ONE captured step per
+            # batch size serves every composition (the batch is assembled inside the graph from the
+            # ids) -- fresh shuffles every epoch replay too
+            rkey = ("resident", id(batch._cache), batch.num_graphs)
+            step = self._graphs.get(rkey)
+            if step is not None:
+                return step(batch).clone()
+            if len(self._graphs) < self.max_graphs:
+                from .graphed import GraphedResidentStep
+                local = batch.num_graphs if isinstance(self.grad_sync, cdist.GradSync) else None
+                step = GraphedResidentStep(self.model, self.optimizer, batch, self.loss_fn, grad_sync=self.grad_sync,
+                                           warmup=1, collectives=self.graph_collectives, local_graphs=local)
+                self._graphs[rkey] = step
+                return step.first_loss        # the warm-up pass WAS this batch's step (eager)
+            return None
         key = self._graph_key(batch)
         step = self._graphs.get(key)
         if step is not None:

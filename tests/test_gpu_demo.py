@@ -117,3 +117,40 @@ def test_subject_structure_cache_equals_per_batch_build():
         C.GraphSAGEConnectome(5, 64).to("cuda")(batches[1])
     with pytest.raises(ValueError):
         ResidentDataLoader(generate_packed(4, 84, 8, seed=1).to("cuda"), batch_size=2, structure_cache=True)
+
+
+def test_trainer_graph_mode_replays_fresh_shuffled_resident_batches():
+    """Trainer(graph=True) over a ResidentDataLoader(shuffle=True, structure_cache=True): every epoch
+    re-draws the batch compositions (the reference's loader semantics, graph.py:190-197), yet all
+    batches of one size share ONE captured step -- the batch is assembled inside the graph from its
+    subject ids (graphed.GraphedResidentStep) -- and the trajectory equals the eager Trainer's."""
+    import connectome_gnn_amd as C
+    from connectome_gnn_amd.graphed import GraphedResidentStep
+    from connectome_gnn_amd.resident import ResidentDataLoader
+    from connectome_gnn_amd.synthetic import generate_packed
+    ds = generate_packed(40, 360, 14, seed=4).to("cuda")
+    hist, finals = {}, {}
+    for mode in ("eager", "graph"):
+        torch.manual_seed(0)
+        m = C.GCNConnectome(5, 64, dropout=0.0)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-4, capturable=True)   # the same update both ways
+        tr = C.Trainer(m, opt, device="cuda", graph=(mode == "graph"))
+        ld = ResidentDataLoader(ds, batch_size=16, shuffle=True, structure_cache=True, prefetch=True,
+                                prepare=tr.model.prepare_batch)
+        hist[mode] = [tr.train_epoch(ld) for _ in range(4)]          # batches of 16, 16, 8 subjects
+        finals[mode] = {k: v.detach().clone() for k, v in tr.model.state_dict().items()}
+        if mode == "graph":
+            assert len(tr._graphs) == 2                               # one per batch SIZE, not per batch
+            assert all(isinstance(s, GraphedResidentStep) for s in tr._graphs.values())
+    torch.testing.assert_close(torch.tensor(hist["graph"]), torch.tensor(hist["eager"]), rtol=2e-5, atol=1e-6)
+    for k, v in finals["eager"].items():
+        if v.is_floating_point() and not (k.startswith("convs.") and k.endswith(".bias")):
+            torch.testing.assert_close(finals["graph"][k], v, rtol=1e-4, atol=1e-5, msg=lambda s: f"{k}: {s}")
+    # with dropout the replays draw fresh masks: two epochs over the same subjects differ
+    torch.manual_seed(1)
+    m = C.GCNConnectome(5, 64, dropout=0.5)
+    opt = torch.optim.Adam(m.parameters(), lr=0.0, capturable=True)      # frozen weights: only masks change
+    tr = C.Trainer(m, opt, device="cuda", graph=True)
+    ld = ResidentDataLoader(ds, batch_size=40, shuffle=False, structure_cache=True, prepare=tr.model.prepare_batch)
+    vals = {round(tr.train_epoch(ld), 7) for _ in range(4)}
+    assert len(vals) >= 3, vals
