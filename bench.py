@@ -117,6 +117,7 @@ PMC_FILES = {
     "cfg5-gcn-64x1000-h256-fp16": (("r03_cfg5_fp16_pmc_traffic.json", "r02_cfg5_fp16_pmc_traffic.json"), 64,
                                    ("k_dense_agg",)),
     "shard512-gcn-512x360-h64": (("r03_shard512_pmc_traffic.json",), 512, ("k_gcn_bwd<",)),
+    "cfg5-gcn-64x1000-h256-fp32": (("r03_cfg5_fp32_pmc_traffic.json",), 64, ("k_agg_wave_row",)),
 }
 
 
@@ -408,9 +409,7 @@ def run_workload(args, name: str, rank: int, world: int, dev, *, launch: str, ba
     # kept under profiles/ (collected offline with rocprofv3 --pmc on this same command, FETCH
     # and WRITE in separate passes, corrected as MI355X_MICROARCH.md prescribes); null when no
     # pass exists for this workload / batch.  `traffic_source` names the file.
-    traffic, step_traffic, traffic_source = (None, None, None)
-    if impl_used == "fused":
-        traffic, step_traffic, traffic_source = pmc_traffic(label, bsz)
+    traffic, step_traffic, traffic_source = pmc_traffic(label, bsz)
     real_frac = (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and kms) else None
     backend = torch.distributed.get_backend() if world > 1 else None
     out = {

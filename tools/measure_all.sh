@@ -20,7 +20,7 @@ for wl in cfg3-sage-512x360-h128 cfg2-gcn-512x84-h64 cfg5-gcn-64x1000-h256-fp16 
   echo "kernel trace $wl ok"
 done
 python3 $R/tools/scatter_bench.py > $O/scatter_bench.log 2>&1 && cp $R/gpurun_out/scatter_bench.json $O/ &&
-for spec in "$H -" "cfg3-sage-512x360-h128 -" "cfg2-gcn-512x84-h64 -" "cfg5-gcn-64x1000-h256-fp16 -" "shard512-gcn-512x360-h64 512"; do
+for spec in "$H -" "cfg3-sage-512x360-h128 -" "cfg2-gcn-512x84-h64 -" "cfg5-gcn-64x1000-h256-fp16 -" "cfg5-gcn-64x1000-h256-fp32 -" "shard512-gcn-512x360-h64 512"; do
   set -- $spec
   wl=$1; extra=""; bwl=$wl
   if [ "$2" != "-" ]; then extra="--batch $2"; bwl=$H; fi
