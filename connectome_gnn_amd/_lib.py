@@ -63,6 +63,15 @@ class CgnnAdamJobs(ctypes.Structure):
                 ("exp_avg_sq", c_void_p * ADAM_MAX_JOBS)]
 
 
+GATHER_MAX_JOBS = 8
+
+
+class CgnnGatherJobs(ctypes.Structure):
+    """Mirror of `struct cgnn_gather_jobs` (include/cgnn.h): row gathers sharing one id list."""
+    _fields_ = [("n", c_int32), ("src", c_void_p * GATHER_MAX_JOBS), ("dst", c_void_p * GATHER_MAX_JOBS),
+                ("row_bytes", c_int64 * GATHER_MAX_JOBS)]
+
+
 # name -> (restype, argtypes).  Order and meaning follow include/cgnn.h exactly.
 PROTOTYPES = {
     "cgnn_abi_version": (c_int, []),
@@ -121,6 +130,7 @@ PROTOTYPES = {
     "cgnn_aggregate_tiled_f32": (c_int, [TP, I32, P, I64, I32, P, P, P, P, I64, P, I64, P]),
     "cgnn_aggregate_tiled_bn_f32": (c_int, [TP, I32, P, I64, I32, P, P, P, P, I64, P, I32, F32, U64, P, P, P, I64, P]),
     "cgnn_gather_f32": (c_int, [P, P, I64, P, P]),
+    "cgnn_gather_rows": (c_int, [ctypes.POINTER(CgnnGatherJobs), P, I32, P]),
     "cgnn_gcn_dis": (c_int, [P, P, I64, P, P]),
     "cgnn_fused_grid": (c_int, []),
     "cgnn_gcn_fused_fwd_first": (c_int, [TP, P, I32, P, P, P, P, P]),

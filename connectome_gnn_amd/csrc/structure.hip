@@ -433,6 +433,29 @@ int scan_i32(int32_t* counts, int64_t n, int32_t* tile_sums, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? CGNN_OK : CGNN_ELAUNCH;
 }
 
+// Several row gathers by ONE id list in one launch (resident datasets: node features, labels, block
+// offsets and `dis` of a batch's subjects): dst_j[i] = src_j[ids[i]], rows of row_bytes_j bytes.
+// blockIdx.y = job, blockIdx.x strides over the ids; 16-byte words when a job's rows allow it.
+__global__ void __launch_bounds__(256) k_gather_rows(cgnn_gather_jobs jobs, const int64_t* __restrict__ ids, int nids) {
+  const int jb = blockIdx.y;
+  const int64_t rb = jobs.row_bytes[jb];
+  const char* src = static_cast<const char*>(jobs.src[jb]);
+  char* dst = static_cast<char*>(jobs.dst[jb]);
+  const bool wide = (rb & 15) == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+  for (int i = blockIdx.x; i < nids; i += gridDim.x) {
+    const int64_t id = ids[i];
+    const char* s = src + id * rb;
+    char* d = dst + (int64_t)i * rb;
+    if (wide) {
+      for (int64_t o = 16 * (int64_t)threadIdx.x; o < rb; o += 16 * 256)
+        *reinterpret_cast<uint4*>(d + o) = *reinterpret_cast<const uint4*>(s + o);
+    } else {
+      for (int64_t o = 4 * (int64_t)threadIdx.x; o < rb; o += 4 * 256)
+        *reinterpret_cast<uint32_t*>(d + o) = *reinterpret_cast<const uint32_t*>(s + o);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -591,6 +614,20 @@ int cgnn_bell_fill(const int32_t* tile_ptr, const int32_t* tile_blk, int32_t num
   k_bell_fill<<<num_tiles, 256, 0, cgnn_stream(stream)>>>(tile_ptr, tile_blk, num_tiles, rowptr, col,
                                                          eid, edge_weight, self_weight, blk_off,
                                                          static_cast<uint2*>(entries));
+  CGNN_CHECK_LAUNCH();
+  return CGNN_OK;
+}
+
+int cgnn_gather_rows(const cgnn_gather_jobs* jobs, const int64_t* ids, int32_t num_ids, void* stream) {
+  if (!jobs || jobs->n < 0 || jobs->n > CGNN_GATHER_MAX_JOBS || num_ids < 0) return CGNN_EINVAL;
+  if (jobs->n == 0 || num_ids == 0) return CGNN_OK;
+  if (!ids) return CGNN_EINVAL;
+  for (int j = 0; j < jobs->n; ++j)
+    if (!jobs->src[j] || !jobs->dst[j] || jobs->row_bytes[j] <= 0 || (jobs->row_bytes[j] & 3) ||
+        ((reinterpret_cast<uintptr_t>(jobs->src[j]) | reinterpret_cast<uintptr_t>(jobs->dst[j])) & 3))
+      return CGNN_EINVAL;
+  const int gx = num_ids < 2048 ? num_ids : 2048;
+  k_gather_rows<<<dim3(gx, jobs->n), 256, 0, cgnn_stream(stream)>>>(*jobs, ids, num_ids);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }

@@ -158,6 +158,7 @@ class GraphedResidentStep(GraphedTrainStep):
 
     def __call__(self, batch=None) -> torch.Tensor:
         if batch is not None:
-            self.ids_buf.copy_(batch._ids)
+            # the ids as the loader handed them over (host): one small copy, no gather is launched
+            self.ids_buf.copy_(getattr(batch, "_ids_src", batch._ids), non_blocking=True)
         return super().__call__()
 

@@ -76,6 +76,9 @@ class ResidentDataLoader:
         return -(-self.dataset.num_subjects // self.batch_size)
 
     def _chunks(self):
+        """Subject ids of this rank's batches.  The permutation is drawn on the host (the global CPU
+        generator, as the reference's loader does) and uploaded ONCE per epoch; a batch's ids are a
+        slice of that device array, so handing a batch over costs no host-to-device copy."""
         n = self.dataset.num_subjects
         if self.shuffle == "batches":
             if self._fixed_order is None:
@@ -83,14 +86,17 @@ class ResidentDataLoader:
             order = self._fixed_order
         else:
             order = torch.randperm(n) if self.shuffle else torch.arange(n)
+        dev = self.dataset.x.device
+        if dev.type == "cuda":
+            order = order.to(dev)
         for lo in range(0, n, self.batch_size):
-            chunk = order[lo:lo + self.batch_size]
+            hi = min(n, lo + self.batch_size)
             if self.world_size > 1:
-                if chunk.numel() < self.world_size:
+                if hi - lo < self.world_size:
                     continue          # a tail smaller than the world: dropped on every rank
-                chunk = torch.tensor(shard_slice(chunk.tolist(), self.rank, self.world_size),
-                                     dtype=torch.long)
-            yield chunk
+                run = shard_slice(range(lo, hi), self.rank, self.world_size)   # a contiguous run
+                lo, hi = run.start, run.stop
+            yield order[lo:hi]
 
     def __iter__(self):
         if self.structure_cache is not None and not self.cache_batches:

@@ -4,10 +4,10 @@ Re-shuffling a resident dataset every epoch (the reference's loader semantics, g
 makes every batch new, and building a batch's structure -- on-device collate of the int64 COO
 (454 MB at 4096 x 360 ROI), the two CSR orderings (342 MB), the two blocked-ELL arrays (424 MB)
 -- costs 1.5 ms against a 2.1 ms step.  None of it depends on the batch: a subject's graph is
-fixed, and when a tile holds exactly one graph (more than 192 nodes per graph, e.g. 360 ROI) the
-tile's blocked-ELL entries, its block offsets and its `dis` vector ARE the subject's.  So they
-are built once per subject (with the ordinary HIP builders, over the dataset in chunks) and a
-batch's structure becomes three small gathers:
+fixed, and when a tile holds exactly one graph the tile's blocked-ELL entries, its block offsets
+and its `dis` vector ARE the subject's.  So they are built once per subject (with the ordinary HIP
+builders, over the dataset in chunks, tiles cut at every graph) and a batch's structure becomes
+three small gathers:
 
     blk_off_{dst,src}[tile] = cache.blk_off[subject]      (absolute offsets into the cache arrays)
     dis[tile rows]          = cache.dis[subject]
@@ -18,7 +18,14 @@ offsets, so tile_blk gets a stride of (blocks + 1) and every subject's offset ro
 offset: no kernel change.  The public COO fields of the batch (`edge_index`, `edge_weight`,
 `batch`) are assembled lazily, only if something reads them.
 
-Scope: the per-tile fused GCN path (hidden 64) on regular datasets with one graph per tile; anything
+Graphs of up to 192 nodes (84-ROI atlases) would share a tile in the per-batch build (two to four
+graphs per 384-row tile, whose 16-row blocks straddle graphs and therefore belong to no subject);
+under the cache every graph gets a tile of its own.  The tile kernels then walk more, smaller tiles
+(512 x 84 rows instead of 256 x 168 for BASELINE config 2) -- a few per cent of GPU time against
+issuing ~45 launches per step from Python, which is what a freshly shuffled batch costs otherwise
+(`Trainer(graph=True)` replays ONE captured step per batch size over such a loader).
+
+Scope: the per-tile fused GCN path (hidden 64) on regular datasets (<= 384 nodes per graph); anything
 else keeps the ordinary per-batch build.
 """
 from __future__ import annotations
@@ -42,8 +49,8 @@ class SubjectStructureCache:
         from .resident import assemble_batch
         lib = _lib.load()
         n = int(ds.x.shape[1])
-        if not (MAX_ROWS // 2 < n <= MAX_ROWS):
-            raise ValueError(f"structure cache needs one graph per tile: {MAX_ROWS // 2} < nodes <= {MAX_ROWS}, got {n}")
+        if not (0 < n <= MAX_ROWS):
+            raise ValueError(f"structure cache: a graph must fit one LDS tile (<= {MAX_ROWS} nodes), got {n}")
         dev = ds.x.device
         self.dataset, self.n = ds, n
         self.nb = (n + 15) // 16                                     # 16-row blocks per graph
@@ -59,7 +66,7 @@ class SubjectStructureCache:
             s = b.structure()
             if not s.block_diagonal:
                 raise ValueError("structure cache: a subject has edges outside its graph")
-            m = s.fused_meta(MAX_ROWS, grid)
+            m = s.fused_meta(n, grid)                   # row cap = one graph: a tile per subject
             if int(m.tile_ptr.numel()) - 1 != ids.numel():
                 raise ValueError("structure cache: tiles are not one graph each")
             dis.append(s.gcn_dis(m).view(ids.numel(), n))
@@ -93,20 +100,48 @@ class SubjectStructureCache:
 
 
 class CachedStructure:
-    """What the fused per-tile GCN encoder asks of a batch structure, assembled from the cache."""
+    """What the fused per-tile GCN encoder asks of a batch structure, assembled from the cache.  The
+    three gathers run on first use: a batch that `Trainer(graph=True)` only takes the subject ids
+    from (the captured step assembles its own) costs no launch at all."""
 
-    def __init__(self, cache: SubjectStructureCache, ids: torch.Tensor):
-        b = int(ids.numel())
-        self.cache = cache
+    def __init__(self, cache: SubjectStructureCache, ids, b: int, assembled=None):
+        """ids: the subject ids on the cache's device, or a callable that returns them.
+        assembled: callable returning (blk_off_dst, blk_off_src, dis) of the batch when its owner
+        gathers them together with the node features (ResidentBatch: one launch for all five)."""
+        self.cache, self._ids_src, self._assembled = cache, ids, assembled
         self.num_graphs, self.num_nodes = b, b * cache.n
         self.max_nodes_per_graph = cache.n
         self.block_diagonal = True
         tile_ptr, tile_blk, node_graph = cache.static(b)
         self.gptr, self.node_graph = tile_ptr, node_graph
-        self._meta = FusedMeta(tile_ptr, tile_blk, cache.n, b * (cache.nb + 1),
-                               cache.blk_off_dst.index_select(0, ids).view(-1), cache.ent_dst,
-                               cache.blk_off_src.index_select(0, ids).view(-1), cache.ent_src, None)
-        self._dis = cache.dis.index_select(0, ids).view(-1)
+        self._meta_ = self._dis_ = None
+
+    @property
+    def _ids(self) -> torch.Tensor:
+        return self._ids_src() if callable(self._ids_src) else self._ids_src
+
+    @property
+    def _meta(self) -> FusedMeta:
+        if self._meta_ is None:
+            cache, b = self.cache, self.num_graphs
+            tile_ptr, tile_blk, _ = cache.static(b)
+            if self._assembled is not None:
+                od, os_, self._dis_ = self._assembled()
+            else:
+                od = cache.blk_off_dst.index_select(0, self._ids).view(-1)
+                os_ = cache.blk_off_src.index_select(0, self._ids).view(-1)
+            self._meta_ = FusedMeta(tile_ptr, tile_blk, cache.n, b * (cache.nb + 1), od, cache.ent_dst,
+                                    os_, cache.ent_src, None)
+        return self._meta_
+
+    @property
+    def _dis(self) -> torch.Tensor:
+        if self._dis_ is None:
+            if self._assembled is not None:
+                self._dis_ = self._assembled()[2]
+            else:
+                self._dis_ = self.cache.dis.index_select(0, self._ids).view(-1)
+        return self._dis_
 
     # -- the interface fused.py / models.py use
     def fused_meta(self, max_rows: int, num_workgroups: int, self_weight: float = 1.0) -> FusedMeta:
@@ -138,21 +173,56 @@ class CachedStructure:
 
 
 class ResidentBatch(ConnectomeBatch):
-    """A ConnectomeBatch of a resident dataset whose structure comes from the subject cache and
-    whose COO fields are assembled on first access (bit-identical to ``assemble_batch``)."""
+    """A ConnectomeBatch of a resident dataset whose structure comes from the subject cache.  Every
+    field is assembled on first access -- node features, labels and the structure by gathers, the COO
+    fields bit-identical to ``assemble_batch`` -- so handing the batch to a captured step that reads
+    only its subject ids launches nothing."""
 
     def __init__(self, cache: SubjectStructureCache, ids: torch.Tensor):
-        ds = cache.dataset
-        dev = ds.x.device
-        self._cache, self._ids = cache, ids.to(dev)
-        b, n = int(ids.numel()), cache.n
-        self.node_features = ds.x.index_select(0, self._ids).reshape(b * n, -1)
-        self.labels = ds.labels.index_select(0, self._ids)
-        self.ptr = torch.arange(b + 1, device=dev, dtype=torch.long) * n
+        self._cache, self._ids_src = cache, ids      # as handed in (host ids of a loader: no copy yet)
+        self._b = int(ids.numel())
+        self._lazy = {}
         self._coo = None
-        self._structure = CachedStructure(cache, self._ids)
+        self._structure = CachedStructure(cache, lambda: self._ids, self._b, assembled=lambda: self._assemble()[2:])
         self._structure_key = None
         self._eptr = None
+
+    def _get(self, name, make):
+        if name not in self._lazy:
+            self._lazy[name] = make()
+        return self._lazy[name]
+
+    def _assemble(self):
+        """Node features, labels, both block-offset rows and `dis` of the batch's subjects in ONE
+        launch (cgnn_gather_rows) -- on first access of any of them."""
+        if "asm" not in self._lazy:
+            cache, ds, b = self._cache, self._cache.dataset, self._b
+            dev = ds.x.device
+            x = torch.empty(b * cache.n, ds.x.shape[2], dtype=ds.x.dtype, device=dev)
+            y = torch.empty(b, dtype=ds.labels.dtype, device=dev)
+            od = torch.empty(b * (cache.nb + 1), dtype=torch.int32, device=dev)
+            os_ = torch.empty(b * (cache.nb + 1), dtype=torch.int32, device=dev)
+            dis = torch.empty(b * cache.n, dtype=torch.float32, device=dev)
+            jobs = _lib.CgnnGatherJobs()
+            pairs = ((ds.x, x), (ds.labels, y), (cache.blk_off_dst, od), (cache.blk_off_src, os_), (cache.dis, dis))
+            jobs.n = len(pairs)
+            for i, (src, dst) in enumerate(pairs):
+                assert src.is_contiguous()
+                jobs.src[i], jobs.dst[i] = src.data_ptr(), dst.data_ptr()
+                jobs.row_bytes[i] = src[0].numel() * src.element_size()
+            with _lib.device_guard(dev):
+                _lib.check(_lib.load().cgnn_gather_rows(jobs, _lib.ptr(self._ids), b, _lib.stream_ptr(dev)),
+                           "cgnn_gather_rows")
+            self._lazy["asm"] = (x, y, od, os_, dis)
+        return self._lazy["asm"]
+
+    _ids = property(lambda self: self._get("ids", lambda: self._ids_src.to(device=self._cache.dataset.x.device, dtype=torch.long).contiguous()))
+    node_features = property(lambda self: self._assemble()[0])
+    labels = property(lambda self: self._assemble()[1])
+    ptr = property(lambda self: self._get(
+        "ptr", lambda: torch.arange(self._b + 1, device=self._cache.dataset.x.device, dtype=torch.long) * self._cache.n))
+    num_graphs = property(lambda self: self._b)
+    num_nodes = property(lambda self: self._b * self._cache.n)
 
     def _materialise(self):
         if self._coo is None:
@@ -172,7 +242,7 @@ class ResidentBatch(ConnectomeBatch):
         raise RuntimeError("a ResidentBatch's structure belongs to the subject cache")
 
     def to(self, device) -> "ConnectomeBatch":
-        if torch.device(device).type == self.node_features.device.type:
+        if torch.device(device).type == self._cache.dataset.x.device.type:
             return self
         ei, ew, bt = self._materialise()
         return ConnectomeBatch(self.node_features.to(device), ei.to(device), ew.to(device), bt.to(device),

@@ -41,6 +41,15 @@ class _DeviceTally:
         self.total = value if self.total is None else self.total + value
         self.graphs += graphs
 
+    def add_scaled(self, value: torch.Tensor, graphs: int) -> None:
+        """total += value * graphs, one launch, `value` only read (it may be a captured step's static
+        loss tensor that the next replay overwrites -- stream order keeps this read ahead of it)."""
+        if self.total is None:
+            self.total = value * float(graphs)
+        else:
+            self.total.add_(value, alpha=float(graphs))
+        self.graphs += graphs
+
     def read(self) -> float:
         """The one device-to-host copy of an epoch."""
         return float(self.total) if self.total is not None else 0.0
@@ -125,25 +134,24 @@ class Trainer:
     def _graph_key(batch) -> tuple:
         """Identity of a resident batch.  A ResidentBatch (structure_cache.py) is keyed on its
         subject ids, never on the COO fields it assembles lazily."""
-        ids = getattr(batch, "_ids", None)
-        if ids is not None:
+        if getattr(batch, "_ids_src", None) is not None:
+            ids = batch._ids
             return ("ids", batch.node_features.data_ptr(), ids.data_ptr(), batch.labels.data_ptr(),
                     batch.num_nodes, batch.num_graphs)
         return (batch.node_features.data_ptr(), batch.edge_index.data_ptr(), batch.edge_weight.data_ptr(),
                 batch.labels.data_ptr(), batch.num_nodes, batch.num_graphs, batch.edge_index._version,
                 batch.edge_weight._version)
 
-    def _graphed_step(self, batch) -> Optional[torch.Tensor]:
+    def _graphed_step(self, batch, borrow: bool = False) -> Optional[torch.Tensor]:
         """Replay (or, on a batch's second sighting, capture) the step; None = run it eagerly."""
-        ids = getattr(batch, "_ids", None)
-        if ids is not None and getattr(batch, "_cache", None) is not None:
+        if getattr(batch, "_ids_src", None) is not None and getattr(batch, "_cache", None) is not None:
             # a batch of a resident dataset with a per-subject structure cache: ONE captured step per
             # batch size serves every composition (the batch is assembled inside the graph from the
             # ids) -- fresh shuffles every epoch replay too
             rkey = ("resident", id(batch._cache), batch.num_graphs)
             step = self._graphs.get(rkey)
             if step is not None:
-                return step(batch).clone()
+                return step(batch) if borrow else step(batch).clone()
             if len(self._graphs) < self.max_graphs:
                 from .graphed import GraphedResidentStep
                 local = batch.num_graphs if isinstance(self.grad_sync, cdist.GradSync) else None
@@ -155,7 +163,7 @@ class Trainer:
         key = self._graph_key(batch)
         step = self._graphs.get(key)
         if step is not None:
-            return step().clone()
+            return step() if borrow else step().clone()
         # second sighting = the very tensor seen before is still alive (addresses alone recur: the
         # caching allocator hands a fresh batch the block its predecessor just released)
         ref = self._seen.get(key)
@@ -180,11 +188,13 @@ class Trainer:
         self._graphs.clear()
         self._seen.clear()
 
-    def train_step(self, batch) -> torch.Tensor:
-        """One optimisation step (reference train.py:46-51); returns the detached device loss."""
+    def train_step(self, batch, _borrow: bool = False) -> torch.Tensor:
+        """One optimisation step (reference train.py:46-51); returns the detached device loss.
+        (_borrow: the caller consumes the loss before the next step -- a replayed step then hands
+        out its static loss tensor instead of a copy.)"""
         batch = batch.to(self.device)
         if self.graph and self.model.training:
-            loss = self._graphed_step(batch)
+            loss = self._graphed_step(batch, _borrow)
             if loss is not None:
                 return loss
         if hasattr(self.grad_sync, "zero_grad"):
@@ -206,7 +216,7 @@ class Trainer:
         tally = _DeviceTally()
         for batch in loader:
             graphs = batch.num_graphs
-            tally.add(self.train_step(batch) * graphs, graphs)
+            tally.add_scaled(self.train_step(batch, _borrow=True), graphs)
         (loss_sum,), seen = self._global_tallies(loader, tally)
         return loss_sum / max(seen, 1)
 

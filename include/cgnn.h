@@ -253,6 +253,20 @@ int cgnn_bell_fill(const int32_t* tile_ptr, const int32_t* tile_blk, int32_t num
 /* out[i] = src[idx[i]] (edge weights permuted to CSR slot order, once per batch). */
 int cgnn_gather_f32(const float* src, const int32_t* idx, int64_t n, float* out, void* stream);
 
+/* Several row gathers by one id list in ONE launch: dst[j][i] = src[j][ids[i]] for rows of
+ * row_bytes[j] bytes (a multiple of 4; pointers 4-byte aligned).  The on-device form of the
+ * reference's collate for device-resident regular datasets (graph.py:143-167 stacks node features and
+ * labels per graph) extended to the per-subject structure arrays: node features, labels, blocked-ELL
+ * block offsets and `dis` of a batch leave in one kernel. */
+#define CGNN_GATHER_MAX_JOBS 8
+typedef struct cgnn_gather_jobs {
+  int32_t n;
+  const void* src[CGNN_GATHER_MAX_JOBS];
+  void* dst[CGNN_GATHER_MAX_JOBS];
+  int64_t row_bytes[CGNN_GATHER_MAX_JOBS];
+} cgnn_gather_jobs;
+int cgnn_gather_rows(const cgnn_gather_jobs* jobs, const int64_t* ids, int32_t num_ids, void* stream);
+
 /* GCN degree normalisation, models.py:97-105, every step: dis[i] = (sum of row i of w_src
  * (COO order) + 1 + 1e-8)^-1/2 with w_src the edge weights in src-CSR slot order. */
 int cgnn_gcn_dis(const float* w_src, const int32_t* rowptr_src, int64_t num_nodes, float* dis,

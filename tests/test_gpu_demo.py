@@ -115,8 +115,47 @@ def test_subject_structure_cache_equals_per_batch_build():
     # other models are refused loudly, not served a wrong structure
     with pytest.raises((AttributeError, ValueError, RuntimeError)):
         C.GraphSAGEConnectome(5, 64).to("cuda")(batches[1])
-    with pytest.raises(ValueError):
-        ResidentDataLoader(generate_packed(4, 84, 8, seed=1).to("cuda"), batch_size=2, structure_cache=True)
+    with pytest.raises(ValueError):       # a graph must fit one LDS tile
+        ResidentDataLoader(generate_packed(2, 400, 8, seed=1).to("cuda"), batch_size=2, structure_cache=True)
+
+
+@pytest.mark.parametrize("n,k", [(84, 8), (48, 6), (192, 10)])
+def test_subject_structure_cache_small_graphs_get_a_tile_each(n, k):
+    """Graphs of <= 192 nodes share tiles in the per-batch build (their 16-row blocks straddle graphs);
+    under the subject cache each gets its own tile.  Same mathematics, another grouping of the
+    BatchNorm / weight-gradient partial sums: equal to the per-batch build at rounding level."""
+    import connectome_gnn_amd as C
+    from connectome_gnn_amd.resident import ResidentDataLoader, assemble_batch
+    from connectome_gnn_amd.synthetic import generate_packed
+    ds = generate_packed(40, n, k, seed=5).to("cuda")
+    torch.manual_seed(3)
+    batches = list(ResidentDataLoader(ds, batch_size=16, shuffle=True, structure_cache=True))
+    assert [b.num_graphs for b in batches] == [16, 16, 8]
+    st = batches[0].structure()
+    assert int(st.fused_meta(384, 256).tile_ptr.numel()) - 1 == 16          # one tile per graph
+    outs = []
+    for use_cache in (True, False):
+        torch.manual_seed(0)
+        m = C.GCNConnectome(5, 64, dropout=0.0).to("cuda").train()
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+        res = []
+        for rb in batches:
+            b = rb if use_cache else assemble_batch(ds, rb._ids)
+            opt.zero_grad()
+            lg = m(b)
+            assert m.impl_used == "fused"
+            torch.nn.functional.cross_entropy(lg, b.labels).backward()
+            res.append((lg.detach().clone(), [p.grad.detach().clone() for p in m.parameters()]))
+            opt.step()
+        outs.append(res)
+    names = [k_ for k_, _ in C.GCNConnectome(5, 64).named_parameters()]
+    for (la, ga), (lb, gb) in zip(*outs):
+        torch.testing.assert_close(la, lb, rtol=1e-5, atol=2e-6)
+        for nm, a, c in zip(names, ga, gb):
+            if nm.startswith("convs.") and nm.endswith(".bias"):
+                continue                      # exactly-zero true gradient: rounding noise either way
+            scale = float(c.abs().max())
+            assert float((a - c).abs().max()) <= 2e-5 * scale + 2e-6, nm
 
 
 def test_trainer_graph_mode_replays_fresh_shuffled_resident_batches():
@@ -128,7 +167,15 @@ def test_trainer_graph_mode_replays_fresh_shuffled_resident_batches():
     from connectome_gnn_amd.graphed import GraphedResidentStep
     from connectome_gnn_amd.resident import ResidentDataLoader
     from connectome_gnn_amd.synthetic import generate_packed
-    ds = generate_packed(40, 360, 14, seed=4).to("cuda")
+    _trainer_replay_equals_eager(generate_packed(40, 360, 14, seed=4).to("cuda"))
+    # 84-ROI graphs (BASELINE config 2): one tile per graph under the cache, same replay
+    _trainer_replay_equals_eager(generate_packed(40, 84, 8, seed=4).to("cuda"), masks=False)
+
+
+def _trainer_replay_equals_eager(ds, masks=True):
+    import connectome_gnn_amd as C
+    from connectome_gnn_amd.graphed import GraphedResidentStep
+    from connectome_gnn_amd.resident import ResidentDataLoader
     hist, finals = {}, {}
     for mode in ("eager", "graph"):
         torch.manual_seed(0)
@@ -146,6 +193,8 @@ def test_trainer_graph_mode_replays_fresh_shuffled_resident_batches():
     for k, v in finals["eager"].items():
         if v.is_floating_point() and not (k.startswith("convs.") and k.endswith(".bias")):
             torch.testing.assert_close(finals["graph"][k], v, rtol=1e-4, atol=1e-5, msg=lambda s: f"{k}: {s}")
+    if not masks:
+        return
     # with dropout the replays draw fresh masks: two epochs over the same subjects differ
     torch.manual_seed(1)
     m = C.GCNConnectome(5, 64, dropout=0.5)
