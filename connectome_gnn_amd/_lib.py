@@ -72,6 +72,37 @@ class CgnnGatherJobs(ctypes.Structure):
                 ("row_bytes", c_int64 * GATHER_MAX_JOBS)]
 
 
+REDUCE_MAX_JOBS = 8
+
+
+class CgnnReduceJobs(ctypes.Structure):
+    """Mirror of `struct cgnn_reduce_jobs` (include/cgnn.h): f64 slab -> f32 vector reductions, one launch."""
+    _fields_ = [("n", c_int32), ("slab", c_void_p * REDUCE_MAX_JOBS), ("rows", c_int32 * REDUCE_MAX_JOBS),
+                ("width", c_int32 * REDUCE_MAX_JOBS), ("out", c_void_p * REDUCE_MAX_JOBS)]
+
+
+class DeferredReduce:
+    """Collects (f64 slab [rows][width] -> f32 out [width]) reductions and issues them as one launch
+    (cgnn_slab_reduce_f64_multi) -- e.g. the bias gradients of all layers at the end of a backward pass."""
+
+    def __init__(self):
+        self.items = []
+
+    def add(self, slab, rows: int, width: int, out) -> None:
+        self.items.append((slab, int(rows), int(width), out))
+
+    def flush(self, stream_ptr) -> None:
+        lib = load()
+        for lo in range(0, len(self.items), REDUCE_MAX_JOBS):
+            chunk = self.items[lo:lo + REDUCE_MAX_JOBS]
+            jobs = CgnnReduceJobs()
+            jobs.n = len(chunk)
+            for i, (slab, rows, width, out) in enumerate(chunk):
+                jobs.slab[i], jobs.rows[i], jobs.width[i], jobs.out[i] = slab.data_ptr(), rows, width, out.data_ptr()
+            check(lib.cgnn_slab_reduce_f64_multi(jobs, stream_ptr), "cgnn_slab_reduce_f64_multi")
+        self.items = []
+
+
 # name -> (restype, argtypes).  Order and meaning follow include/cgnn.h exactly.
 PROTOTYPES = {
     "cgnn_abi_version": (c_int, []),
@@ -101,6 +132,7 @@ PROTOTYPES = {
     "cgnn_linear_bwd_weight2_f32": (c_int, [P, I64, P, I64, I32, P, I64, I32, P, I32, I64, I32, P, P]),
     "cgnn_linear_fwd_f16": (c_int, [P, I64, I32, P, I32, I32, P, P, I64, I64, I32, P]),
     "cgnn_linear_bwd_input_f16": (c_int, [P, I64, P, I32, P, I64, I64, I32, I32, P]),
+    "cgnn_linear_fwd_stats_f16": (c_int, [P, I64, I32, P, I32, I32, P, P, I64, I64, I32, P, P]),
     "cgnn_linear_bwd_weight_f16_workspace_bytes": (I64, [I64, I32, I32]),
     "cgnn_linear_bwd_weight_f16": (c_int, [P, I64, P, I64, P, I32, I32, I64, I32, I32, P, P]),
     "cgnn_pad_cast_f16": (c_int, [P, I64, I32, P, I32, I64, P]),
@@ -114,14 +146,15 @@ PROTOTYPES = {
     "cgnn_bn_act_fwd_stats": (c_int, [P, I64, I32, P, P]),
     "cgnn_bn_act_finalize": (c_int, [P, I32, I32, F64, P, I32, P, P, P, P, F32, F32, P, P, P]),
     "cgnn_bn_act_fwd_apply": (c_int, [P, P, I32, F32, U64, P, P, P, I64, I32, P]),
-    "cgnn_bn_act_pool_fwd": (c_int, [P, P, I32, F32, U64, P, P, P, I32, P, I32, P]),
+    "cgnn_bn_act_pool_fwd": (c_int, [P, P, I32, F32, U64, P, P, P, I32, P, I32, P, P]),
+    "cgnn_bn_act_pool_bwd_finalize": (c_int, [P, P, P, I32, I32, F64, I32, P, P, P, P]),
     "cgnn_bn_act_bwd_stats": (c_int, [P, P, P, P, I32, F32, I64, I32, P, P, P, P, P]),
     "cgnn_bn_act_bwd_finalize": (c_int, [P, I32, I32, F64, P, I32, P, P, P, P]),
     "cgnn_bn_act_apply_blocks": (I64, [I64, I32]),
     "cgnn_bn_act_bwd_apply": (c_int, [P, P, P, P, P, I32, F32, I32, P, P, I64, I32, P, P, P, P]),
     "cgnn_bn_act_fwd_stats_f16": (c_int, [P, I64, I32, P, P]),
     "cgnn_bn_act_fwd_apply_f16": (c_int, [P, P, I32, F32, U64, P, P, P, I64, I32, P]),
-    "cgnn_bn_act_pool_fwd_f16": (c_int, [P, P, I32, F32, U64, P, P, P, I32, P, I32, P]),
+    "cgnn_bn_act_pool_fwd_f16": (c_int, [P, P, I32, F32, U64, P, P, P, I32, P, I32, P, P]),
     "cgnn_bn_act_bwd_stats_f16": (c_int, [P, P, P, P, I32, F32, I64, I32, P, P, P, P, P]),
     "cgnn_bn_act_bwd_apply_f16": (c_int, [P, P, P, P, P, I32, F32, I32, P, P, I64, I32, P, P, P, P]),
     # fused per-tile GCN path
@@ -129,6 +162,7 @@ PROTOTYPES = {
     "cgnn_bell_fill": (c_int, [P, P, I32, P, P, P, P, F32, P, P, P]),
     "cgnn_aggregate_tiled_f32": (c_int, [TP, I32, P, I64, I32, P, P, P, P, I64, P, I64, P]),
     "cgnn_aggregate_tiled_bn_f32": (c_int, [TP, I32, P, I64, I32, P, P, P, P, I64, P, I32, F32, U64, P, P, P, I64, P]),
+    "cgnn_slab_reduce_f64_multi": (c_int, [ctypes.POINTER(CgnnReduceJobs), P]),
     "cgnn_gather_f32": (c_int, [P, P, I64, P, P]),
     "cgnn_gather_rows": (c_int, [ctypes.POINTER(CgnnGatherJobs), P, I32, P]),
     "cgnn_gcn_dis": (c_int, [P, P, I64, P, P]),

@@ -234,6 +234,46 @@ __global__ void __launch_bounds__(FIN_C * FIN_G) k_bn_bwd_finalize_n(const doubl
   }
 }
 
+// BatchNorm-backward sums of a pooled last layer from the forward pass's factor sums (see
+// k_bn_act_pool_fwd): S1[c] = sum_g dP[g][c] / (n_g + 1e-8) * F1[g][c], S2 likewise with F2; then
+// exactly k_bn_bwd_finalize_n.  fp64 accumulation over the graphs, fixed order.
+__global__ void __launch_bounds__(FIN_C * FIN_G) k_bn_pool_bwd_finalize(
+    const float* __restrict__ dP, const float* __restrict__ Fsum, const int32_t* __restrict__ gptr, int B,
+    int N, double count, int zero_coef, float* __restrict__ dgamma, float* __restrict__ dbeta,
+    float* __restrict__ bwc) {
+  __shared__ double sh[FIN_G][FIN_C][2];
+  __shared__ double sh2[FIN_G / 8][FIN_C][2];
+  const int cc = threadIdx.x % FIN_C, rg = threadIdx.x / FIN_C, c = blockIdx.x * FIN_C + cc;
+  double a1 = 0.0, a2 = 0.0;
+  if (c < N)
+    for (int g = rg; g < B; g += FIN_G) {
+      const float inv = 1.0f / ((float)(gptr[g + 1] - gptr[g]) + 1e-8f);
+      const float d = dP[(int64_t)g * N + c] * inv;
+      a1 += (double)(d * Fsum[(int64_t)g * N + c]);
+      a2 += (double)(d * Fsum[(int64_t)(B + g) * N + c]);
+    }
+  sh[rg][cc][0] = a1;
+  sh[rg][cc][1] = a2;
+  __syncthreads();
+  if (rg < FIN_G / 8) {
+    double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { t1 += sh[8 * rg + k][cc][0]; t2 += sh[8 * rg + k][cc][1]; }
+    sh2[rg][cc][0] = t1;
+    sh2[rg][cc][1] = t2;
+  }
+  __syncthreads();
+  if (rg == 0 && c < N) {
+    double S1 = 0.0, S2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < FIN_G / 8; ++k) { S1 += sh2[k][cc][0]; S2 += sh2[k][cc][1]; }
+    dbeta[c] = (float)S1;
+    dgamma[c] = (float)S2;
+    bwc[c] = zero_coef ? 0.f : (float)(S1 / count);
+    bwc[N + c] = zero_coef ? 0.f : (float)(S2 / count);
+  }
+}
+
 // forward apply (BWD=false): X' = drop(act(a*Y+b)), keep bytes out
 // backward apply (BWD=true): dY = a*(dZ - c1 - xhat*c2), dZ = dX'*drop'*act'
 template <bool BWD, typename T>
@@ -304,20 +344,26 @@ constexpr int PTHR = 1024;
 
 // grid = num_graphs * CS workgroups (capped): workgroup (g, cs) pools columns [cs, cs + 1) * N / CS of
 // graph g -- with few large graphs (64 x 1000-ROI) one workgroup per graph leaves most CUs idle
-template <typename T>
+// FSUM: also the per-graph factor sums F1[g][c] = sum_rows f, F2[g][c] = sum_rows f * xhat with
+// f = act' * keep / (1-p): the readout's gradient is constant per graph, so the BatchNorm-backward
+// sums of this layer are sum_g dP[g]/n_g * F1[g] and ... * F2[g] (k_bn_pool_bwd_finalize) -- the
+// backward statistics pass over Y is not needed.  Fsum = [2][B][N].
+template <typename T, bool FSUM>
 __global__ void __launch_bounds__(PTHR) k_bn_act_pool_fwd(
     const T* __restrict__ Y, const float* __restrict__ coef, int relu, DropCfg drop, int use_drop,
     uint8_t* __restrict__ mask_out, const int32_t* __restrict__ gptr, int B, float* __restrict__ P,
-    int N, int CS) {
+    int N, int CS, float* __restrict__ Fsum) {
   if (drop.dev_key) drop.key1 ^= drop.dev_key[0];
-  extern __shared__ float pred[];                    // [rpp][N / CS]
+  extern __shared__ float pred[];                    // [rpp][N / CS] (x 3 with factor sums)
   const int nch = N >> 2, nchb = nch / CS, NB = N / CS;
   const int cl = threadIdx.x % nchb, rr = threadIdx.x / nchb, rpp = PTHR / nchb;
   for (int u = blockIdx.x; u < B * CS; u += gridDim.x) {
     const int g = u / CS, c = (u - g * CS) * nchb + cl;
     const float4 ca = ld4(coef + 4 * c), cb = ld4(coef + N + 4 * c);
+    float4 cm = make_float4(0.f, 0.f, 0.f, 0.f), ci = cm;
+    if (FSUM) { cm = ld4(coef + 2 * N + 4 * c); ci = ld4(coef + 3 * N + 4 * c); }
     const int rbeg = gptr[g], rend = gptr[g + 1];
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), f1 = s, f2 = s;
     constexpr int U = 8;                             // rows in flight per thread
     for (int row0 = rbeg + rr; row0 < rend; row0 += U * rpp) {
       float4 yb[U];
@@ -338,19 +384,37 @@ __global__ void __launch_bounds__(PTHR) k_bn_act_pool_fwd(
             kb = drop_bits(drop, (uint32_t)i);
             if (mask_out) mask_out[i] = (uint8_t)kb;
           }
-          s.x += ((!relu || zx > 0.f) && (kb & 1u)) ? zx * drop.scale : 0.f;
-          s.y += ((!relu || zy > 0.f) && (kb & 2u)) ? zy * drop.scale : 0.f;
-          s.z += ((!relu || zz > 0.f) && (kb & 4u)) ? zz * drop.scale : 0.f;
-          s.w += ((!relu || zw > 0.f) && (kb & 8u)) ? zw * drop.scale : 0.f;
+          const float fx = ((!relu || zx > 0.f) && (kb & 1u)) ? drop.scale : 0.f;
+          const float fy = ((!relu || zy > 0.f) && (kb & 2u)) ? drop.scale : 0.f;
+          const float fz = ((!relu || zz > 0.f) && (kb & 4u)) ? drop.scale : 0.f;
+          const float fw = ((!relu || zw > 0.f) && (kb & 8u)) ? drop.scale : 0.f;
+          s.x += fx != 0.f ? zx * drop.scale : 0.f;
+          s.y += fy != 0.f ? zy * drop.scale : 0.f;
+          s.z += fz != 0.f ? zz * drop.scale : 0.f;
+          s.w += fw != 0.f ? zw * drop.scale : 0.f;
+          if (FSUM) {
+            f1.x += fx; f1.y += fy; f1.z += fz; f1.w += fw;
+            f2.x = fmaf(fx, (yb[u2].x - cm.x) * ci.x, f2.x); f2.y = fmaf(fy, (yb[u2].y - cm.y) * ci.y, f2.y);
+            f2.z = fmaf(fz, (yb[u2].z - cm.z) * ci.z, f2.z); f2.w = fmaf(fw, (yb[u2].w - cm.w) * ci.w, f2.w);
+          }
         }
       }
     }
-    if (rr < rpp) st4(pred + rr * NB + 4 * cl, s);
+    if (rr < rpp) {
+      st4(pred + rr * NB + 4 * cl, s);
+      if (FSUM) {
+        st4(pred + (rpp + rr) * NB + 4 * cl, f1);
+        st4(pred + (2 * rpp + rr) * NB + 4 * cl, f2);
+      }
+    }
     __syncthreads();
-    for (int e = threadIdx.x; e < NB; e += PTHR) {
+    for (int e = threadIdx.x; e < (FSUM ? 3 : 1) * NB; e += PTHR) {
+      const int part = e / NB, ee = e - part * NB;
       float tot = 0.f;
-      for (int k = 0; k < rpp; ++k) tot += pred[k * NB + e];
-      P[(int64_t)g * N + (u - g * CS) * NB + e] = tot / ((float)(rend - rbeg) + 1e-8f);
+      for (int k = 0; k < rpp; ++k) tot += pred[(part * rpp + k) * NB + ee];
+      const int64_t o = (int64_t)g * N + (u - g * CS) * NB + ee;
+      if (part == 0) P[o] = tot / ((float)(rend - rbeg) + 1e-8f);
+      else Fsum[(int64_t)(part - 1) * B * N + o] = tot;
     }
     __syncthreads();
   }
@@ -414,7 +478,7 @@ int bn_act_fwd_apply_t(const T* Y, const float* coef, int32_t relu, float p_drop
 template <typename T>
 int bn_act_pool_fwd_t(const T* Y, const float* coef, int32_t relu, float p_drop, uint64_t seed,
                       const uint32_t* seed_dev, uint8_t* mask_out, const int32_t* gptr,
-                      int32_t num_graphs, float* P, int32_t N, void* stream) {
+                      int32_t num_graphs, float* P, int32_t N, float* Fsum, void* stream) {
   if (num_graphs < 0 || !width_ok(N) || p_drop < 0.f || p_drop >= 1.f) return CGNN_EINVAL;
   if (num_graphs == 0) return CGNN_OK;
   if (!Y || !coef || !gptr || !P) return CGNN_EINVAL;
@@ -427,8 +491,12 @@ int bn_act_pool_fwd_t(const T* Y, const float* coef, int32_t relu, float p_drop,
   const int rpp = PTHR / ((N >> 2) / cs);
   const int64_t units = (int64_t)num_graphs * cs;
   const unsigned grid = (unsigned)(units < 2048 ? units : 2048);
-  k_bn_act_pool_fwd<T><<<grid, PTHR, (size_t)rpp * (N / cs) * sizeof(float), cgnn_stream(stream)>>>(
-      Y, coef, relu, d, use_drop, mask_out, gptr, num_graphs, P, N, cs);
+  if (Fsum)
+    k_bn_act_pool_fwd<T, true><<<grid, PTHR, (size_t)3 * rpp * (N / cs) * sizeof(float), cgnn_stream(stream)>>>(
+        Y, coef, relu, d, use_drop, mask_out, gptr, num_graphs, P, N, cs, Fsum);
+  else
+    k_bn_act_pool_fwd<T, false><<<grid, PTHR, (size_t)rpp * (N / cs) * sizeof(float), cgnn_stream(stream)>>>(
+        Y, coef, relu, d, use_drop, mask_out, gptr, num_graphs, P, N, cs, nullptr);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }
@@ -520,8 +588,20 @@ int cgnn_bn_act_fwd_apply(const float* Y, const float* coef, int32_t relu, float
 }
 int cgnn_bn_act_pool_fwd(const float* Y, const float* coef, int32_t relu, float p_drop, uint64_t seed,
                          const uint32_t* seed_dev, uint8_t* mask_out, const int32_t* gptr,
-                         int32_t num_graphs, float* P, int32_t N, void* stream) {
-  return bn_act_pool_fwd_t<float>(Y, coef, relu, p_drop, seed, seed_dev, mask_out, gptr, num_graphs, P, N, stream);
+                         int32_t num_graphs, float* P, int32_t N, float* Fsum, void* stream) {
+  return bn_act_pool_fwd_t<float>(Y, coef, relu, p_drop, seed, seed_dev, mask_out, gptr, num_graphs, P, N, Fsum,
+                                  stream);
+}
+
+int cgnn_bn_act_pool_bwd_finalize(const float* dP, const float* Fsum, const int32_t* gptr, int32_t num_graphs,
+                                  int32_t N, double count, int32_t zero_coef, float* dgamma, float* dbeta,
+                                  float* bwc, void* stream) {
+  if (num_graphs < 0 || !width_ok(N) || count <= 0.0 || !dP || !Fsum || !gptr || !dgamma || !dbeta || !bwc)
+    return CGNN_EINVAL;
+  k_bn_pool_bwd_finalize<<<(N + FIN_C - 1) / FIN_C, FIN_C * FIN_G, 0, cgnn_stream(stream)>>>(
+      dP, Fsum, gptr, num_graphs, N, count, zero_coef, dgamma, dbeta, bwc);
+  CGNN_CHECK_LAUNCH();
+  return CGNN_OK;
 }
 int cgnn_bn_act_bwd_stats(const float* dX, const float* Y, const uint8_t* mask, const float* coef,
                           int32_t relu, float p_drop, int64_t M, int32_t N, double* slab,
@@ -550,9 +630,9 @@ int cgnn_bn_act_fwd_apply_f16(const void* Y, const float* coef, int32_t relu, fl
 }
 int cgnn_bn_act_pool_fwd_f16(const void* Y, const float* coef, int32_t relu, float p_drop, uint64_t seed,
                              const uint32_t* seed_dev, uint8_t* mask_out, const int32_t* gptr,
-                             int32_t num_graphs, float* P, int32_t N, void* stream) {
+                             int32_t num_graphs, float* P, int32_t N, float* Fsum, void* stream) {
   return bn_act_pool_fwd_t<cgnn_h>(static_cast<const cgnn_h*>(Y), coef, relu, p_drop, seed, seed_dev, mask_out,
-                                   gptr, num_graphs, P, N, stream);
+                                   gptr, num_graphs, P, N, Fsum, stream);
 }
 int cgnn_bn_act_bwd_stats_f16(const void* dX, const void* Y, const uint8_t* mask, const float* coef,
                               int32_t relu, float p_drop, int64_t M, int32_t N, double* slab,

@@ -1175,6 +1175,21 @@ __global__ void __launch_bounds__(256) k_slab_reduce(const T* __restrict__ slab,
   }
 }
 
+// several f64 slab -> f32 vector reductions in one launch (blockIdx.y = job): the bias gradients of
+// all layers of a backward pass
+__global__ void __launch_bounds__(256) k_slab_reduce_multi(cgnn_reduce_jobs jobs) {
+  const int jb = blockIdx.y;
+  const int width = jobs.width[jb], rows = jobs.rows[jb];
+  const double* __restrict__ slab = jobs.slab[jb];
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (e >= width) return;                                  // (wave-uniform)
+  double s = 0.0;
+  for (int r = lane; r < rows; r += 64) s += slab[(int64_t)r * width + e];
+  s = cgnn_wave_sum(s);
+  if (lane == 0) jobs.out[jb][e] = (float)s;
+}
+
 __global__ void k_bn_finalize(const double* __restrict__ sums, double count,
                               const double* __restrict__ count_dev,
                               const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -1682,6 +1697,19 @@ int cgnn_slab_reduce_f32(const float* slab, int32_t rows, int32_t out_rows, int3
   const int width = out_rows * out_cols;
   k_slab_reduce<float><<<(width + 3) / 4, 256, 0, cgnn_stream(stream)>>>(
       slab, rows, width, nullptr, out, out_cols, take_cols, ld_out);
+  CGNN_CHECK_LAUNCH();
+  return CGNN_OK;
+}
+
+int cgnn_slab_reduce_f64_multi(const cgnn_reduce_jobs* jobs, void* stream) {
+  if (!jobs || jobs->n < 0 || jobs->n > CGNN_REDUCE_MAX_JOBS) return CGNN_EINVAL;
+  if (jobs->n == 0) return CGNN_OK;
+  int wmax = 0;
+  for (int j = 0; j < jobs->n; ++j) {
+    if (!jobs->slab[j] || !jobs->out[j] || jobs->rows[j] <= 0 || jobs->width[j] <= 0) return CGNN_EINVAL;
+    wmax = jobs->width[j] > wmax ? jobs->width[j] : wmax;
+  }
+  k_slab_reduce_multi<<<dim3((wmax + 3) / 4, jobs->n), 256, 0, cgnn_stream(stream)>>>(*jobs);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }

@@ -53,16 +53,31 @@ struct Chunk { cgnn_u32x4 a, b; };               // one wave-load pair: rows lro
 // Y[M, 32*NT] (half) = X[M, K] (half) * B + bias, fp32 accumulate.
 //   BT = false: B[k][c] = W[c*ldw + k] for k < Kw, else 0   (Y = X W^T, W fp32 [cols, Kw])
 //   BT = true : B[k][c] = W[k*ldw + c]                       (dX = dY W,  W fp32 [K, cols])
-template <int NT, bool BT>
+//
+// STATS (optional epilogue, per-workgroup fp64 partials -> stat_slab[blockIdx.x][2 * cols]):
+//   1  BatchNorm forward statistics of the (half-rounded) output: sum y | sum y^2 -- the projection
+//      in front of a BatchNorm leaves them behind instead of a statistics pass re-reading Y;
+// (The mirror image for the backward pass -- the BatchNorm-backward sums of the layer below in the
+// epilogue of dX = dT W, from that layer's output, keep bytes and coefficients -- was built and
+// measured: 38 us against 21 + 14 for the product and a separate statistics pass.  With one 32-row
+// block per wave at the config-5 shape nothing hides the epilogue's loads and 128 coefficient reads.)
+struct HgStats {
+  double* slab;                // [gridDim.x][2 * cols]
+};
+
+template <int NT, bool BT, int STATS>
 __global__ void __launch_bounds__(HG_THR) k_hgemm(const __half* __restrict__ X, int64_t ldx, int K,
                                                   const float* __restrict__ W, int ldw, int Kw,
                                                   const float* __restrict__ bias,
-                                                  __half* __restrict__ Y, int64_t ldy, int64_t M) {
+                                                  __half* __restrict__ Y, int64_t ldy, int64_t M, HgStats hs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char hg_lds[];
   uint4* Wl = reinterpret_cast<uint4*>(hg_lds);                       // [(s*NT + t)][lane] B fragments
   const int nsteps = K / 16, nchunks = K / 32;
-  __half* stg = reinterpret_cast<__half*>(hg_lds + (size_t)nsteps * NT * 64 * 16) +
-                (threadIdx.x >> 6) * (32 * HG_SLD);
+  // (with STATS the panel region is at least HG_NW x 2 x cols doubles: the final fold reuses it)
+  const size_t panel_bytes = STATS ? ((size_t)nsteps * NT * 64 * 16 > (size_t)HG_NW * 2 * 32 * NT * sizeof(double)
+                                          ? (size_t)nsteps * NT * 64 * 16 : (size_t)HG_NW * 2 * 32 * NT * sizeof(double))
+                                   : (size_t)nsteps * NT * 64 * 16;
+  __half* stg = reinterpret_cast<__half*>(hg_lds + panel_bytes) + (threadIdx.x >> 6) * (32 * HG_SLD);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
   const int lrow = lane >> 2, lpc = lane & 3;
   const int64_t nrb = (M + 31) / 32;
@@ -135,7 +150,9 @@ __global__ void __launch_bounds__(HG_THR) k_hgemm(const __half* __restrict__ X, 
   f32x16 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = f32x16{0};
-
+  double st1[STATS ? NT : 1], st2[STATS ? NT : 1];     // per-lane fp64 partial sums (sum y^2 cancels against mean^2)
+#pragma unroll
+  for (int t = 0; t < (STATS ? NT : 1); ++t) st1[t] = st2[t] = 0.0;
   auto process = [&](Chunk& buf) __attribute__((always_inline)) {
     *reinterpret_cast<cgnn_u32x4*>(stg + lrow * HG_SLD + 8 * lpc) = buf.a;
     *reinterpret_cast<cgnn_u32x4*>(stg + (16 + lrow) * HG_SLD + 8 * lpc) = buf.b;
@@ -161,6 +178,14 @@ __global__ void __launch_bounds__(HG_THR) k_hgemm(const __half* __restrict__ X, 
           _Float16 o[NT];
 #pragma unroll
           for (int t = 0; t < NT; ++t) o[t] = (_Float16)(acc[t][r] + bv[t]);
+          if (STATS == 1) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              const float v = (float)o[t];
+              st1[t] += (double)v;
+              st2[t] += (double)v * (double)v;
+            }
+          }
           __half* yp = Y + row * ldy + NT * j;
           if (NT == 8) {
             h8 v;
@@ -190,6 +215,28 @@ __global__ void __launch_bounds__(HG_THR) k_hgemm(const __half* __restrict__ X, 
     process(ring2);
     if (rb >= nrb) break;
     process(ring3);
+  }
+  if (STATS) {
+    // lanes l and l + 32 hold the same columns; the waves' partials meet in the (now idle) panel
+    constexpr int cols = 32 * NT;
+    __syncthreads();
+    double* red = reinterpret_cast<double*>(hg_lds);             // [HG_NW][2 * cols]
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const double a1 = (double)st1[t] + (double)__shfl_xor(st1[t], 32, 64);
+      const double a2 = (double)st2[t] + (double)__shfl_xor(st2[t], 32, 64);
+      if (h == 0) {
+        red[wave * 2 * cols + NT * j + t] = a1;
+        red[wave * 2 * cols + cols + NT * j + t] = a2;
+      }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * cols; e += HG_THR) {
+      double tot = 0.0;
+#pragma unroll
+      for (int w2 = 0; w2 < HG_NW; ++w2) tot += red[w2 * 2 * cols + e];
+      hs.slab[(int64_t)blockIdx.x * 2 * cols + e] = tot;
+    }
   }
 }
 
@@ -329,14 +376,20 @@ __global__ void __launch_bounds__(256) k_pad_cast(const float* __restrict__ X, i
   }
 }
 
-size_t hg_lds_bytes(int K, int nt) { return (size_t)K * nt * 64 + (size_t)HG_NW * 32 * HG_SLD * sizeof(__half); }
+// B fragments + the waves' slabs; the statistics fold reuses
+// the panel, which must then hold HG_NW x 2 x cols doubles
+size_t hg_lds_bytes(int K, int nt, int stats) {
+  size_t panel = (size_t)K * nt * 64;
+  if (stats && panel < (size_t)HG_NW * 2 * 32 * nt * sizeof(double)) panel = (size_t)HG_NW * 2 * 32 * nt * sizeof(double);
+  return panel + (size_t)HG_NW * 32 * HG_SLD * sizeof(__half);
+}
 
-template <int NT, bool BT>
+template <int NT, bool BT, int STATS>
 bool hg_attr() {
   static bool done[CGNN_MAX_DEVICES] = {};
   bool& d = done[cgnn_device_ordinal()];
   if (!d) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_hgemm<NT, BT>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_hgemm<NT, BT, STATS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return false;
     d = true;
@@ -344,19 +397,25 @@ bool hg_attr() {
   return true;
 }
 
-template <bool BT>
+template <bool BT, int STATS>
 int hg_launch(const __half* X, int64_t ldx, int K, const float* W, int ldw, int Kw, const float* bias,
-              __half* Y, int64_t ldy, int64_t M, int cols, hipStream_t st) {
+              __half* Y, int64_t ldy, int64_t M, int cols, hipStream_t st, HgStats hs = HgStats{}) {
   const int nt = cols / 32;
   const int grid = cgnn_fused_grid();
-  const size_t lds = hg_lds_bytes(K, nt);
+  const size_t lds = hg_lds_bytes(K, nt, STATS);
+  if (lds > 160 * 1024) return CGNN_EUNSUPPORTED;
 #define HG_CASE(NTV)                                                                              \
   case NTV:                                                                                       \
-    if (!hg_attr<NTV, BT>()) return CGNN_ELAUNCH;                                                 \
-    k_hgemm<NTV, BT><<<grid, HG_THR, lds, st>>>(X, ldx, K, W, ldw, Kw, bias, Y, ldy, M);          \
+    if (!hg_attr<NTV, BT, STATS>()) return CGNN_ELAUNCH;                                          \
+    k_hgemm<NTV, BT, STATS><<<grid, HG_THR, lds, st>>>(X, ldx, K, W, ldw, Kw, bias, Y, ldy, M, hs); \
     break;
   switch (nt) {
-    HG_CASE(2) HG_CASE(4) HG_CASE(8)
+    HG_CASE(4) HG_CASE(8)
+    case 2:
+      if (STATS) return CGNN_EUNSUPPORTED;
+      if (!hg_attr<2, BT, 0>()) return CGNN_ELAUNCH;
+      k_hgemm<2, BT, 0><<<grid, HG_THR, lds, st>>>(X, ldx, K, W, ldw, Kw, bias, Y, ldy, M, hs);
+      break;
     default: return CGNN_EUNSUPPORTED;
   }
 #undef HG_CASE
@@ -394,8 +453,22 @@ int cgnn_linear_fwd_f16(const void* X, int64_t ldx, int32_t K, const float* W, i
     return CGNN_EUNSUPPORTED;
   if (M == 0) return CGNN_OK;
   if (!X || !W || !Y) return CGNN_EINVAL;
-  return hg_launch<false>(static_cast<const __half*>(X), ldx, K, W, ldw, Kw, bias, static_cast<__half*>(Y), ldy, M,
-                          N, cgnn_stream(stream));
+  return hg_launch<false, 0>(static_cast<const __half*>(X), ldx, K, W, ldw, Kw, bias, static_cast<__half*>(Y), ldy, M,
+                             N, cgnn_stream(stream));
+}
+
+int cgnn_linear_fwd_stats_f16(const void* X, int64_t ldx, int32_t K, const float* W, int32_t ldw, int32_t Kw,
+                              const float* bias, void* Y, int64_t ldy, int64_t M, int32_t N, double* stat_slab,
+                              void* stream) {
+  if (M < 0 || K <= 0 || N <= 0 || Kw <= 0 || Kw > K || ldw < Kw || ldx < K || ldy < N || !stat_slab) return CGNN_EINVAL;
+  if (!hg_shape_ok(K, N) || N < 128 || ldx % 8 || ldy % 8 || (reinterpret_cast<uintptr_t>(X) & 15) ||
+      (reinterpret_cast<uintptr_t>(Y) & 15) || (reinterpret_cast<uintptr_t>(W) & 15))
+    return CGNN_EUNSUPPORTED;
+  if (!X || !W || !Y) return CGNN_EINVAL;
+  HgStats hs{};
+  hs.slab = stat_slab;
+  return hg_launch<false, 1>(static_cast<const __half*>(X), ldx, K, W, ldw, Kw, bias, static_cast<__half*>(Y), ldy, M,
+                             N, cgnn_stream(stream), hs);
 }
 
 int cgnn_linear_bwd_input_f16(const void* dY, int64_t lddy, const float* W, int32_t ldw, void* dX,
@@ -406,8 +479,8 @@ int cgnn_linear_bwd_input_f16(const void* dY, int64_t lddy, const float* W, int3
     return CGNN_EUNSUPPORTED;
   if (M == 0) return CGNN_OK;
   if (!dY || !W || !dX) return CGNN_EINVAL;
-  return hg_launch<true>(static_cast<const __half*>(dY), lddy, N, W, ldw, N, nullptr, static_cast<__half*>(dX),
-                         lddx, M, K, cgnn_stream(stream));
+  return hg_launch<true, 0>(static_cast<const __half*>(dY), lddy, N, W, ldw, N, nullptr, static_cast<__half*>(dX),
+                            lddx, M, K, cgnn_stream(stream));
 }
 
 int64_t cgnn_linear_bwd_weight_f16_workspace_bytes(int64_t M, int32_t N, int32_t K) {

@@ -32,7 +32,7 @@ from typing import List, Optional
 import torch
 
 from . import _lib, ops
-from .sage_path import bn_modules_ok
+from .sage_path import bn_modules_ok, pooled_bn_backward_coefs
 from .structure import BatchStructure
 
 MAX_NODES = 1024          # dense pitch limit of cgnn_dense_adj_f16
@@ -90,7 +90,7 @@ P0_COLS = 64             # layer 0's input features ride in one 64-column half p
 
 
 class _Saved:
-    __slots__ = ("s", "mb", "xs", "ys", "coefs", "masks", "ws", "p0", "p", "training")
+    __slots__ = ("s", "mb", "xs", "ys", "coefs", "masks", "ws", "p0", "p", "training", "fsum")
 
 
 def _f32(dev, *shape):
@@ -128,8 +128,15 @@ class GcnHalfEncode(torch.autograd.Function):
                     # A_hat (X0 W0^T) == (A_hat X0) W0^T: aggregate the few input columns (one
                     # 64-column half panel through the dense operator), then project
                     sv.p0 = _agg(s, mf, ops.pad_cast_f16(x0, P0_COLS))    # [Nn, 64] half, cols >= F0 zero
-                    y = ops.linear_fwd_f16_raw(sv.p0, w, b)               # K = 64 panel, W0 [H, F0]
-                slab, srows = None, rows
+                    y = None
+                    if training:                                           # statistics in the epilogue
+                        y, slab = ops.linear_fwd_stats_f16_raw(sv.p0, w, b, int(lib.cgnn_fused_grid()))
+                        srows = int(lib.cgnn_fused_grid())
+                    if y is None:
+                        y = ops.linear_fwd_f16_raw(sv.p0, w, b)           # K = 64 panel, W0 [H, F0]
+                        slab, srows = None, rows
+                else:
+                    slab, srows = None, rows
                 if li > 0:
                     t = ops.linear_fwd_f16_raw(x, w)                       # half in / out, fp32 accumulate
                     if training:                                           # statistics in the epilogue
@@ -153,9 +160,12 @@ class GcnHalfEncode(torch.autograd.Function):
                 sv.xs.append(x); sv.ys.append(y); sv.coefs.append(coef); sv.masks.append(mask); sv.ws.append(w)
                 if li == L - 1:
                     pooled = _f32(dev, B, hid)
+                    # per-graph factor sums: the backward statistics of this layer need no pass over Y
+                    sv.fsum = _f32(dev, 2, B, hid) if any(ctx.needs_input_grad) else None
                     _lib.check(lib.cgnn_bn_act_pool_fwd_f16(_lib.ptr(y), _lib.ptr(coef), 1, p, seed, rw,
                                                             _lib.ptr(mask), _lib.ptr(s.gptr), B,
-                                                            _lib.ptr(pooled), hid, sp), "cgnn_bn_act_pool_fwd_f16")
+                                                            _lib.ptr(pooled), hid, _lib.ptr(sv.fsum), sp),
+                               "cgnn_bn_act_pool_fwd_f16")
                     break
                 xn = torch.empty_like(y)
                 _lib.check(lib.cgnn_bn_act_fwd_apply_f16(_lib.ptr(y), _lib.ptr(coef), 1, p, seed, rw,
@@ -180,27 +190,30 @@ class GcnHalfEncode(torch.autograd.Function):
         with _lib.device_guard(dev):
             rows = int(lib.cgnn_bn_act_slab_rows(n_nodes))
             dx = None                           # last layer: gradient rebuilt from dP inside the kernels
+            deferred = _lib.DeferredReduce()
             for li in range(L - 1, -1, -1):
                 x, y, coef, mask, w = sv.xs[li], sv.ys[li], sv.coefs[li], sv.masks[li], sv.ws[li]
                 hid = w.shape[0]
                 pool = (_lib.ptr(dP), _lib.ptr(s.node_graph), _lib.ptr(s.gptr)) if li == L - 1 else (None, None, None)
-                slab = torch.empty(rows, 2 * hid, dtype=torch.float64, device=dev)
-                _lib.check(lib.cgnn_bn_act_bwd_stats_f16(_lib.ptr(dx), _lib.ptr(y), _lib.ptr(mask), _lib.ptr(coef),
-                                                         1, sv.p, n_nodes, hid, _lib.ptr(slab), *pool, sp),
-                           "cgnn_bn_act_bwd_stats_f16")
-                dgamma, dbeta, bwc = _f32(dev, hid), _f32(dev, hid), _f32(dev, 2 * hid)
-                _lib.check(lib.cgnn_bn_act_bwd_finalize(_lib.ptr(slab), rows, hid, float(max(n_nodes, 1)), None,
-                                                        int(not sv.training), _lib.ptr(dgamma), _lib.ptr(dbeta),
-                                                        _lib.ptr(bwc), sp), "cgnn_bn_act_bwd_finalize")
+                if li == L - 1 and sv.fsum is not None:
+                    dgamma, dbeta, bwc = pooled_bn_backward_coefs(lib, dP, sv.fsum, s, hid, n_nodes, sv.training, sp, dev)
+                else:
+                    slab, srows = torch.empty(rows, 2 * hid, dtype=torch.float64, device=dev), rows
+                    _lib.check(lib.cgnn_bn_act_bwd_stats_f16(_lib.ptr(dx), _lib.ptr(y), _lib.ptr(mask), _lib.ptr(coef),
+                                                             1, sv.p, n_nodes, hid, _lib.ptr(slab), *pool, sp),
+                               "cgnn_bn_act_bwd_stats_f16")
+                    dgamma, dbeta, bwc = _f32(dev, hid), _f32(dev, hid), _f32(dev, 2 * hid)
+                    _lib.check(lib.cgnn_bn_act_bwd_finalize(_lib.ptr(slab), srows, hid, float(max(n_nodes, 1)), None,
+                                                            int(not sv.training), _lib.ptr(dgamma), _lib.ptr(dbeta),
+                                                            _lib.ptr(bwc), sp), "cgnn_bn_act_bwd_finalize")
                 cs_rows = int(lib.cgnn_bn_act_apply_blocks(n_nodes, hid))
                 cs_slab = torch.empty(cs_rows, hid, dtype=torch.float64, device=dev)
                 dy = torch.empty_like(y)
                 _lib.check(lib.cgnn_bn_act_bwd_apply_f16(_lib.ptr(dx), _lib.ptr(y), _lib.ptr(mask), _lib.ptr(coef),
                                                          _lib.ptr(bwc), 1, sv.p, 0, _lib.ptr(cs_slab), _lib.ptr(dy),
                                                          n_nodes, hid, *pool, sp), "cgnn_bn_act_bwd_apply_f16")
-                db = _f32(dev, hid)            # the bias is added after the aggregation: db = colsum(dY)
-                _lib.check(lib.cgnn_slab_reduce_f64(_lib.ptr(cs_slab), cs_rows, hid, _lib.ptr(db), sp),
-                           "cgnn_slab_reduce_f64")
+                db = _f32(dev, hid)
+                deferred.add(cs_slab, cs_rows, hid, db)       # all layers' db: one launch at the end
                 if li == 0:
                     # Y0 = (A_hat X0) W0^T + b0: dW0 = dY0^T P0, no aggregation in the backward
                     dw = ops.linear_bwd_weight_f16_raw(dy, sv.p0, w.shape[1])
@@ -209,6 +222,7 @@ class GcnHalfEncode(torch.autograd.Function):
                 dt = _agg(s, sv.mb, dy)             # dT = A_hat^T dY
                 grads[4 * li:4 * li + 4] = [ops.linear_bwd_weight_f16_raw(dt, x), db, dgamma, dbeta]
                 dx = ops.linear_bwd_input_f16_raw(dt, w)                   # dX = dT W
+            deferred.flush(sp)
         ctx.sv = None
         return (None, None, *grads)
 

@@ -25,6 +25,7 @@ import torch
 
 from . import _lib, ops
 from .sage_path import (PAD_K, PAD_MIN_ROWS, TILE_ROWS, _f32, _linear_fwd_stats, bn_backward_coefs,
+                        pooled_bn_backward_coefs,
                         bn_forward_coef, bn_modules_ok, sync_group_of)
 from .structure import BatchStructure
 
@@ -47,7 +48,7 @@ def eligible(model, batch, structure: BatchStructure) -> Optional[str]:
 
 class _Saved:
     __slots__ = ("s", "ell", "norm", "xs", "ys", "coefs", "masks", "p", "training", "ws", "p0", "padded",
-                 "sync_group", "count_block")
+                 "sync_group", "count_block", "fsum")
 
 
 class GcnWideEncode(torch.autograd.Function):
@@ -119,9 +120,10 @@ class GcnWideEncode(torch.autograd.Function):
                 sv.xs.append(x); sv.ys.append(y); sv.coefs.append(coef); sv.masks.append(mask); sv.ws.append(w)
                 if li == L - 1:
                     pooled = _f32(dev, s.num_graphs, hid)
+                    sv.fsum = _f32(dev, 2, s.num_graphs, hid) if (sv.sync_group is None and any(ctx.needs_input_grad)) else None
                     _lib.check(lib.cgnn_bn_act_pool_fwd(_lib.ptr(y), _lib.ptr(coef), 1, p, seed, rw,
                                                         _lib.ptr(mask), _lib.ptr(s.gptr), s.num_graphs,
-                                                        _lib.ptr(pooled), hid, st()), "cgnn_bn_act_pool_fwd")
+                                                        _lib.ptr(pooled), hid, _lib.ptr(sv.fsum), st()), "cgnn_bn_act_pool_fwd")
                     break
                 xn = torch.empty_like(y)
                 _lib.check(lib.cgnn_bn_act_fwd_apply(_lib.ptr(y), _lib.ptr(coef), 1, p, seed, rw,
@@ -148,18 +150,22 @@ class GcnWideEncode(torch.autograd.Function):
         grads: List[Optional[torch.Tensor]] = [None] * (4 * L)
         with _lib.device_guard(dev):
             dx = None                      # last layer: gradient rebuilt from dP inside the kernels
+            deferred = _lib.DeferredReduce()
             rows = int(lib.cgnn_bn_act_slab_rows(n_nodes))
             for li in range(L - 1, -1, -1):
                 x, y, coef, mask, w = sv.xs[li], sv.ys[li], sv.coefs[li], sv.masks[li], sv.ws[li]
                 hid, fin = w.shape[0], x.shape[1]
-                slab = torch.empty(rows, 2 * hid, dtype=torch.float64, device=dev)
                 pool = (_lib.ptr(dP), _lib.ptr(s.node_graph), _lib.ptr(s.gptr)) if li == L - 1 \
                     else (None, None, None)
-                _lib.check(lib.cgnn_bn_act_bwd_stats(_lib.ptr(dx), _lib.ptr(y), _lib.ptr(mask),
-                                                     _lib.ptr(coef), 1, sv.p, n_nodes, hid,
-                                                     _lib.ptr(slab), *pool, st()), "cgnn_bn_act_bwd_stats")
-                dgamma, dbeta, bwc = bn_backward_coefs(lib, slab, rows, hid, n_nodes, sv.training,
-                                                       sv.sync_group, sv.count_block, st(), dev)
+                if li == L - 1 and sv.fsum is not None:
+                    dgamma, dbeta, bwc = pooled_bn_backward_coefs(lib, dP, sv.fsum, s, hid, n_nodes, sv.training, st(), dev)
+                else:
+                    slab = torch.empty(rows, 2 * hid, dtype=torch.float64, device=dev)
+                    _lib.check(lib.cgnn_bn_act_bwd_stats(_lib.ptr(dx), _lib.ptr(y), _lib.ptr(mask),
+                                                         _lib.ptr(coef), 1, sv.p, n_nodes, hid,
+                                                         _lib.ptr(slab), *pool, st()), "cgnn_bn_act_bwd_stats")
+                    dgamma, dbeta, bwc = bn_backward_coefs(lib, slab, rows, hid, n_nodes, sv.training,
+                                                           sv.sync_group, sv.count_block, st(), dev)
                 cs_rows = int(lib.cgnn_bn_act_apply_blocks(n_nodes, hid))
                 cs_slab = torch.empty(cs_rows, hid, dtype=torch.float64, device=dev)
                 dy = torch.empty_like(y)
@@ -168,8 +174,7 @@ class GcnWideEncode(torch.autograd.Function):
                                                      _lib.ptr(cs_slab), _lib.ptr(dy), n_nodes, hid,
                                                      *pool, st()), "cgnn_bn_act_bwd_apply")
                 db = _f32(dev, hid)
-                _lib.check(lib.cgnn_slab_reduce_f64(_lib.ptr(cs_slab), cs_rows, hid, _lib.ptr(db), st()),
-                           "cgnn_slab_reduce_f64")
+                deferred.add(cs_slab, cs_rows, hid, db)       # all layers' db: one launch at the end
                 if li == 0:
                     # Y0 = P0 W0^T + b  ->  dW0 = dY0^T P0 (no aggregation in the backward)
                     if sv.padded:
@@ -186,6 +191,7 @@ class GcnWideEncode(torch.autograd.Function):
                 ops.linear_bwd_weight_raw(dt, x, dw, 0)
                 grads[4 * li:4 * li + 4] = [dw, db, dgamma, dbeta]
                 dx = ops.linear_bwd_input_raw(dt, w, 0, fin)
+            deferred.flush(st())
         ctx.sv = None
         return (None, None, *grads)
 

@@ -292,6 +292,24 @@ def linear_fwd_f16_raw(x, w, bias=None) -> torch.Tensor:
     return y
 
 
+def linear_fwd_stats_f16_raw(x, w, bias, grid: int):
+    """linear_fwd_f16_raw that also leaves the BatchNorm statistics of Y (sum | sum of squares per
+    column, fp64 per-workgroup partials [grid, 2N]) -- or (None, None) outside the kernel's shapes."""
+    lib = _lib.load()
+    _need_half(x, "x")
+    m, k = x.shape
+    n, kw = w.shape
+    y = torch.empty(m, n, dtype=torch.float16, device=x.device)
+    slab = torch.empty(grid, 2 * n, dtype=torch.float64, device=x.device)
+    with _lib.device_guard(x.device), _lib.timed("cgnn_linear_fwd_stats_f16", f"K={k},N={n}"):
+        rc = lib.cgnn_linear_fwd_stats_f16(_lib.ptr(x), x.stride(0), k, _lib.ptr(w), w.stride(0), kw, _lib.ptr(bias),
+                                           _lib.ptr(y), y.stride(0), m, n, _lib.ptr(slab), _lib.stream_ptr())
+    if rc == _lib.CGNN_EUNSUPPORTED:
+        return None, None
+    _lib.check(rc, "cgnn_linear_fwd_stats_f16")
+    return y, slab
+
+
 def linear_bwd_input_f16_raw(dy, w) -> torch.Tensor:
     """dX = dY W: dY half [M, N], W fp32 [N, K]; dX half [M, K]."""
     lib = _lib.load()

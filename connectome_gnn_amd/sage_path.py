@@ -45,7 +45,7 @@ def eligible(model, batch, structure: BatchStructure) -> Optional[str]:
 
 class _Saved:
     __slots__ = ("s", "ell", "norm", "xs", "aggs", "zs", "coefs", "masks", "p", "training", "ws", "xa0",
-                 "sync_group", "count_block")
+                 "sync_group", "count_block", "fsum")
 
 
 PAD_K = 32          # layer 0: [x0 | agg(x0) | 0] packed to one 32-wide panel
@@ -124,6 +124,18 @@ def bn_backward_coefs(lib, slab, rows, hid, n_nodes, training, sync_group, count
                                             _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(bwc), sp),
                "cgnn_bn_act_bwd_finalize")
     return local_dgamma, local_dbeta, bwc
+
+
+def pooled_bn_backward_coefs(lib, dP, fsum, s, hid, n_nodes, training, sp, dev):
+    """(dgamma, dbeta, bwc) of the LAST layer from the factor sums its pooled forward pass left
+    (cgnn_bn_act_pool_fwd's Fsum): the readout's gradient is constant per graph, so no pass over the
+    layer's [Nn, H] output is needed for the BatchNorm-backward sums."""
+    dgamma, dbeta, bwc = _f32(dev, hid), _f32(dev, hid), _f32(dev, 2 * hid)
+    _lib.check(lib.cgnn_bn_act_pool_bwd_finalize(_lib.ptr(dP), _lib.ptr(fsum), _lib.ptr(s.gptr), s.num_graphs, hid,
+                                                 float(max(n_nodes, 1)), int(not training), _lib.ptr(dgamma),
+                                                 _lib.ptr(dbeta), _lib.ptr(bwc), sp),
+               "cgnn_bn_act_pool_bwd_finalize")
+    return dgamma, dbeta, bwc
 
 
 def _linear_fwd_stats(lib, x1, x2, w, b, grid, relu: bool = True):
@@ -232,9 +244,12 @@ class SageEncode(torch.autograd.Function):
                 if li == L - 1:
                     # last layer: BatchNorm + dropout + mean-pool in one pass, X' never written
                     pooled = _f32(dev, s.num_graphs, hid)
+                    # (factor sums for the backward statistics; under sync-BN the sums are exchanged
+                    # through the slab of the ordinary statistics pass instead)
+                    sv.fsum = _f32(dev, 2, s.num_graphs, hid) if (sv.sync_group is None and any(ctx.needs_input_grad)) else None
                     _lib.check(lib.cgnn_bn_act_pool_fwd(_lib.ptr(z), _lib.ptr(coef), 0, p, seed, rw,
                                                         _lib.ptr(mask), _lib.ptr(s.gptr), s.num_graphs,
-                                                        _lib.ptr(pooled), hid, st()),
+                                                        _lib.ptr(pooled), hid, _lib.ptr(sv.fsum), st()),
                                "cgnn_bn_act_pool_fwd")
                     break
                 pending = (z, coef, seed, rw, mask)
@@ -257,20 +272,24 @@ class SageEncode(torch.autograd.Function):
         grads: List[Optional[torch.Tensor]] = [None] * (4 * L)
         with _lib.device_guard(dev):
             dx = None                      # last layer: gradient rebuilt from dP inside the kernels
+            deferred = _lib.DeferredReduce()
             rows = int(lib.cgnn_bn_act_slab_rows(n_nodes))
             for li in range(L - 1, -1, -1):
                 x, agg, z, coef, mask, w = (sv.xs[li], sv.aggs[li], sv.zs[li], sv.coefs[li],
                                             sv.masks[li], sv.ws[li])
                 hid, fin = w.shape[0], x.shape[1]
                 # ---- BatchNorm + dropout backward, ReLU' of the layer and db in two passes
-                slab = torch.empty(rows, 2 * hid, dtype=torch.float64, device=dev)
                 pool = (_lib.ptr(dP), _lib.ptr(s.node_graph), _lib.ptr(s.gptr)) if li == L - 1 \
                     else (None, None, None)
-                _lib.check(lib.cgnn_bn_act_bwd_stats(_lib.ptr(dx), _lib.ptr(z), _lib.ptr(mask),
-                                                     _lib.ptr(coef), 0, sv.p, n_nodes, hid,
-                                                     _lib.ptr(slab), *pool, st()), "cgnn_bn_act_bwd_stats")
-                dgamma, dbeta, bwc = bn_backward_coefs(lib, slab, rows, hid, n_nodes, sv.training,
-                                                       sv.sync_group, sv.count_block, st(), dev)
+                if li == L - 1 and sv.fsum is not None:
+                    dgamma, dbeta, bwc = pooled_bn_backward_coefs(lib, dP, sv.fsum, s, hid, n_nodes, sv.training, st(), dev)
+                else:
+                    slab = torch.empty(rows, 2 * hid, dtype=torch.float64, device=dev)
+                    _lib.check(lib.cgnn_bn_act_bwd_stats(_lib.ptr(dx), _lib.ptr(z), _lib.ptr(mask),
+                                                         _lib.ptr(coef), 0, sv.p, n_nodes, hid,
+                                                         _lib.ptr(slab), *pool, st()), "cgnn_bn_act_bwd_stats")
+                    dgamma, dbeta, bwc = bn_backward_coefs(lib, slab, rows, hid, n_nodes, sv.training,
+                                                           sv.sync_group, sv.count_block, st(), dev)
                 cs_rows = int(lib.cgnn_bn_act_apply_blocks(n_nodes, hid))
                 cs_slab = torch.empty(cs_rows, hid, dtype=torch.float64, device=dev)
                 dpre = torch.empty_like(z)
@@ -279,8 +298,7 @@ class SageEncode(torch.autograd.Function):
                                                      _lib.ptr(cs_slab), _lib.ptr(dpre), n_nodes, hid,
                                                      *pool, st()), "cgnn_bn_act_bwd_apply")
                 db = _f32(dev, hid)
-                _lib.check(lib.cgnn_slab_reduce_f64(_lib.ptr(cs_slab), cs_rows, hid, _lib.ptr(db), st()),
-                           "cgnn_slab_reduce_f64")
+                deferred.add(cs_slab, cs_rows, hid, db)       # all layers' db: one launch at the end
                 # ---- dW = dPre^T [X | A]
                 if li == 0 and sv.xa0 is not None:
                     dwp = _f32(dev, hid, PAD_K)
@@ -301,6 +319,7 @@ class SageEncode(torch.autograd.Function):
                 dcat = ops.linear_bwd_input_raw(dpre, w, 0, 2 * fin)
                 dx = ops.aggregate_tiled_raw(s, sv.ell, ops.AGG_TRANSPOSED | ops.AGG_PRE_DIV,
                                              dcat[:, fin:], sv.norm.den, None, None, yadd=dcat[:, :fin])
+            deferred.flush(st())
         ctx.sv = None
         return (None, None, *grads)
 

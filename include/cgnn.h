@@ -174,6 +174,13 @@ int cgnn_linear_fwd_f16(const void* X, int64_t ldx, int32_t K, const float* W, i
                         const float* bias, void* Y, int64_t ldy, int64_t M, int32_t N, void* stream);
 int cgnn_linear_bwd_input_f16(const void* dY, int64_t lddy, const float* W, int32_t ldw, void* dX,
                               int64_t lddx, int64_t M, int32_t N, int32_t K, void* stream);
+/* cgnn_linear_fwd_f16 with the BatchNorm statistics of its output left behind by the epilogue
+ * (per-workgroup fp64 partials, stat_slab [cgnn_fused_grid()][2 * N]: sum | sum of squares of the
+ * half-rounded output columns, N = 128 or 256; combined by cgnn_bn_act_finalize with rows =
+ * cgnn_fused_grid()): the projection in front of a BatchNorm (models.py:111,208) needs no statistics pass. */
+int cgnn_linear_fwd_stats_f16(const void* X, int64_t ldx, int32_t K, const float* W, int32_t ldw, int32_t Kw,
+                              const float* bias, void* Y, int64_t ldy, int64_t M, int32_t N, double* stat_slab,
+                              void* stream);
 int64_t cgnn_linear_bwd_weight_f16_workspace_bytes(int64_t M, int32_t N, int32_t K);
 int cgnn_linear_bwd_weight_f16(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW,
                                int32_t ldw, int32_t Kw, int64_t M, int32_t N, int32_t K, void* slab,
@@ -508,7 +515,7 @@ int cgnn_bn_act_fwd_apply_f16(const void* Y, const float* coef, int32_t relu, fl
                               int32_t N, void* stream);
 int cgnn_bn_act_pool_fwd_f16(const void* Y, const float* coef, int32_t relu, float p_drop, uint64_t seed,
                              const uint32_t* seed_dev, uint8_t* mask_out, const int32_t* gptr,
-                             int32_t num_graphs, float* P, int32_t N, void* stream);
+                             int32_t num_graphs, float* P, int32_t N, float* Fsum, void* stream);
 int cgnn_bn_act_bwd_stats_f16(const void* dX, const void* Y, const uint8_t* mask, const float* coef,
                               int32_t relu, float p_drop, int64_t M, int32_t N, double* slab,
                               const float* dP, const int32_t* node_graph, const int32_t* gptr,
@@ -577,6 +584,17 @@ int cgnn_slab_reduce_f32(const float* slab, int32_t rows, int32_t out_rows, int3
                          int32_t take_cols, float* out, int32_t ld_out, void* stream);
 int cgnn_slab_reduce_f64(const double* slab, int32_t rows, int32_t width, float* out,
                          void* stream);
+/* up to CGNN_REDUCE_MAX_JOBS of the f64 form in ONE launch (the bias gradients of every layer of a
+ * backward pass: their per-block column sums are final long before the pass ends) */
+#define CGNN_REDUCE_MAX_JOBS 8
+typedef struct cgnn_reduce_jobs {
+  int32_t n;
+  const double* slab[CGNN_REDUCE_MAX_JOBS];
+  int32_t rows[CGNN_REDUCE_MAX_JOBS];
+  int32_t width[CGNN_REDUCE_MAX_JOBS];
+  float* out[CGNN_REDUCE_MAX_JOBS];
+} cgnn_reduce_jobs;
+int cgnn_slab_reduce_f64_multi(const cgnn_reduce_jobs* jobs, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * BatchNorm1d (+ReLU) + dropout for the layered path (any power-of-two width 4..1024),
@@ -609,7 +627,14 @@ int cgnn_bn_act_fwd_apply(const float* Y, const float* coef, int32_t relu, float
  * dP[node_graph[r],:] / (n_g + 1e-8), rebuilt per row (dX may then be NULL). */
 int cgnn_bn_act_pool_fwd(const float* Y, const float* coef, int32_t relu, float p_drop, uint64_t seed,
                          const uint32_t* seed_dev, uint8_t* mask_out, const int32_t* gptr,
-                         int32_t num_graphs, float* P, int32_t N, void* stream);
+                         int32_t num_graphs, float* P, int32_t N, float* Fsum, void* stream);
+/* Fsum (nullable, float [2][B][N]): the pooled pass also leaves the per-graph factor sums
+ * F1[g][c] = sum_rows f, F2[g][c] = sum_rows f * xhat (f = act' * keep / (1-p)); the readout's
+ * gradient is constant per graph, so this layer's BatchNorm-backward sums follow from them without
+ * a pass over Y:  cgnn_bn_act_pool_bwd_finalize == cgnn_bn_act_bwd_stats(dP form) + cgnn_bn_act_bwd_finalize. */
+int cgnn_bn_act_pool_bwd_finalize(const float* dP, const float* Fsum, const int32_t* gptr, int32_t num_graphs,
+                                  int32_t N, double count, int32_t zero_coef, float* dgamma, float* dbeta,
+                                  float* bwc, void* stream);
 int cgnn_bn_act_bwd_stats(const float* dX, const float* Y, const uint8_t* mask, const float* coef,
                           int32_t relu, float p_drop, int64_t M, int32_t N, double* slab,
                           const float* dP, const int32_t* node_graph, const int32_t* gptr,

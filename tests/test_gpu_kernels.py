@@ -708,3 +708,99 @@ def test_half_storage_projection_bwd_weight(m, n, k, kw):
     xf = torch.randn(9, 5, generator=g).to(DEV)
     pc = ops.pad_cast_f16(xf, 64)
     assert pc.shape == (9, 64) and torch.equal(pc[:, :5], xf.half()) and not pc[:, 5:].any()
+
+
+@pytest.mark.parametrize("m,k,n,kw", [(64000, 64, 256, 5), (4097, 128, 128, 128), (1000, 256, 256, 256), (31, 64, 128, 64)])
+def test_half_storage_projection_with_statistics_epilogue(m, k, n, kw):
+    """cgnn_linear_fwd_stats_f16: the same output as cgnn_linear_fwd_f16 bit for bit, and the column
+    sums / sums of squares of that (half-rounded) output in the per-workgroup fp64 slab."""
+    from connectome_gnn_amd import _lib, ops
+    g = torch.Generator().manual_seed(m + k + n)
+    x = (torch.randn(m, k, generator=g) * 0.7 + 0.2).half().to(DEV)
+    w = (torch.randn(n, kw, generator=g) / math.sqrt(kw)).to(DEV)
+    b = torch.randn(n, generator=g).to(DEV)
+    grid = int(_lib.load().cgnn_fused_grid())
+    y, slab = ops.linear_fwd_stats_f16_raw(x, w, b, grid)
+    assert y is not None and slab.shape == (grid, 2 * n)
+    assert torch.equal(y, ops.linear_fwd_f16_raw(x, w, b))
+    s = slab.sum(dim=0)
+    yd = y.double()
+    torch.testing.assert_close(s[:n], yd.sum(dim=0), rtol=1e-12, atol=1e-9)
+    torch.testing.assert_close(s[n:], (yd * yd).sum(dim=0), rtol=1e-12, atol=1e-9)
+    assert ops.linear_fwd_stats_f16_raw(x, w[:64], b[:64], grid) == (None, None)      # N = 64: not covered
+
+
+@pytest.mark.parametrize("sizes,n,relu,p,half", [([1000, 37, 500], 256, True, 0.3, True), ([84] * 9, 64, False, 0.3, False),
+                                                 ([360, 1, 200], 128, True, 0.0, False), ([5] * 300, 64, False, 0.5, True)])
+def test_pooled_bn_pass_factor_sums_give_the_backward_statistics(sizes, n, relu, p, half):
+    """cgnn_bn_act_pool_fwd(Fsum) + cgnn_bn_act_pool_bwd_finalize == the dP form of
+    cgnn_bn_act_bwd_stats + cgnn_bn_act_bwd_finalize (the pass over Y they replace), and the pooled
+    rows / keep bytes are those of the pass without factor sums."""
+    from connectome_gnn_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(len(sizes) + n)
+    m, bsz = sum(sizes), len(sizes)
+    y = (torch.randn(m, n, generator=g) * 1.3 + 0.2).to(DEV)
+    y = y.half() if half else y
+    coef = torch.cat([torch.rand(n, generator=g) + 0.5, torch.randn(n, generator=g) * 0.3,
+                      torch.randn(n, generator=g) * 0.2, torch.rand(n, generator=g) + 0.7]).to(DEV)
+    gptr = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int32, device=DEV)
+    node_graph = torch.repeat_interleave(torch.arange(bsz, dtype=torch.int32), torch.tensor(sizes)).to(DEV)
+    dP = torch.randn(bsz, n, generator=g).to(DEV)
+    sfx = "_f16" if half else ""
+    sp = _lib.stream_ptr(torch.device(DEV))
+    outs = []
+    for with_f in (False, True):
+        pooled = torch.empty(bsz, n, device=DEV)
+        mask = torch.zeros(m * (n // 4), dtype=torch.uint8, device=DEV)
+        fsum = torch.empty(2, bsz, n, device=DEV) if with_f else None
+        _lib.check(getattr(lib, "cgnn_bn_act_pool_fwd" + sfx)(_lib.ptr(y), _lib.ptr(coef), int(relu), p, 1234, None,
+                                                             _lib.ptr(mask), _lib.ptr(gptr), bsz, _lib.ptr(pooled), n,
+                                                             _lib.ptr(fsum), sp), "pool_fwd")
+        outs.append((pooled, mask, fsum))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    _, mask, fsum = outs[1]
+    got = [torch.empty(n, device=DEV), torch.empty(n, device=DEV), torch.empty(2 * n, device=DEV)]
+    _lib.check(lib.cgnn_bn_act_pool_bwd_finalize(_lib.ptr(dP), _lib.ptr(fsum), _lib.ptr(gptr), bsz, n, float(m), 0,
+                                                 *(_lib.ptr(t) for t in got), sp), "pool_bwd_finalize")
+    rows = int(lib.cgnn_bn_act_slab_rows(m))
+    slab = torch.empty(rows, 2 * n, dtype=torch.float64, device=DEV)
+    _lib.check(getattr(lib, "cgnn_bn_act_bwd_stats" + sfx)(None, _lib.ptr(y), _lib.ptr(mask), _lib.ptr(coef), int(relu), p,
+                                                          m, n, _lib.ptr(slab), _lib.ptr(dP), _lib.ptr(node_graph),
+                                                          _lib.ptr(gptr), sp), "bwd_stats")
+    want = [torch.empty(n, device=DEV), torch.empty(n, device=DEV), torch.empty(2 * n, device=DEV)]
+    _lib.check(lib.cgnn_bn_act_bwd_finalize(_lib.ptr(slab), rows, n, float(m), None, 0, *(_lib.ptr(t) for t in want), sp),
+               "bwd_finalize")
+    for a, b in zip(got, want):
+        torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-5 * float(b.abs().max()) + 1e-7)
+
+
+def test_gather_rows_and_multi_reduce():
+    """cgnn_gather_rows (several row gathers by one id list, 16- and 4-byte paths) and
+    cgnn_slab_reduce_f64_multi (several slab folds in one launch) against torch indexing / sums."""
+    from connectome_gnn_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    s = 37
+    srcs = [torch.randn(s, 84, 5, generator=g).to(DEV), torch.randint(0, 9, (s,), generator=g).to(DEV),
+            torch.randint(0, 1 << 20, (s, 7), generator=g, dtype=torch.int32).to(DEV), torch.randn(s, 84, generator=g).to(DEV)]
+    ids = torch.tensor([3, 3, 36, 0, 17, 5, 36], dtype=torch.long, device=DEV)
+    dsts = [torch.empty((ids.numel(),) + tuple(t.shape[1:]), dtype=t.dtype, device=DEV) for t in srcs]
+    jobs = _lib.CgnnGatherJobs()
+    jobs.n = len(srcs)
+    for i, (a, b) in enumerate(zip(srcs, dsts)):
+        jobs.src[i], jobs.dst[i], jobs.row_bytes[i] = a.data_ptr(), b.data_ptr(), a[0].numel() * a.element_size()
+    sp = _lib.stream_ptr(torch.device(DEV))
+    _lib.check(lib.cgnn_gather_rows(jobs, _lib.ptr(ids), ids.numel(), sp), "gather_rows")
+    for a, b in zip(srcs, dsts):
+        assert torch.equal(b, a.index_select(0, ids))
+    jobs.row_bytes[1] = 6
+    assert lib.cgnn_gather_rows(jobs, _lib.ptr(ids), ids.numel(), sp) == _lib.CGNN_EINVAL      # not a multiple of 4
+    red = _lib.DeferredReduce()
+    slabs = [torch.randn(r, w, generator=g, dtype=torch.float64).to(DEV) for r, w in ((1024, 256), (3, 64), (250, 128))]
+    outs = [torch.empty(t.shape[1], device=DEV) for t in slabs]
+    for t, o in zip(slabs, outs):
+        red.add(t, t.shape[0], t.shape[1], o)
+    red.flush(sp)
+    for t, o in zip(slabs, outs):
+        torch.testing.assert_close(o, t.sum(dim=0).float(), rtol=1e-6, atol=1e-6)
