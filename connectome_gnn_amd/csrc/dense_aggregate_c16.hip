@@ -124,13 +124,17 @@ __global__ void __launch_bounds__(C_THR) k_dense_agg_c(
     const uint32_t* __restrict__ sent, const int32_t* __restrict__ sstep, const uint32_t* __restrict__ soff,
     int P, const int32_t* __restrict__ gptr, int B, const __half* __restrict__ X, int64_t ldx,
     int nslices, const float* __restrict__ bias, __half* __restrict__ Y, int64_t ldy,
-    double* __restrict__ stat_slab) {
+    double* __restrict__ stat_slab, int rparts) {
   extern __shared__ __attribute__((aligned(16))) __half Xt[];       // [64][KP], the fragment slabs, wacc
   const int KP = c_kp(P);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   __half* frag2 = Xt + 64 * KP + wave * 1024;                        // this wave's two [64 lanes][8] slabs
   const int NRB = P >> 5;
-  const int units = B * nslices;
+  // a graph's work = nslices column slices x rparts runs of row blocks (rparts > 1 when the batch has
+  // fewer (graph, slice) pairs than the chip has CUs -- layer 0's single 64-column panel of a 64-graph
+  // batch would otherwise occupy a quarter of them; the parts re-stage the same slice from L2)
+  const int sub = nslices * rparts;
+  const int units = B * sub;
   // the slabs start (and are always left) all zero
   *reinterpret_cast<uint4*>(frag2 + 8 * lane) = make_uint4(0u, 0u, 0u, 0u);
   *reinterpret_cast<uint4*>(frag2 + 512 + 8 * lane) = make_uint4(0u, 0u, 0u, 0u);
@@ -144,23 +148,26 @@ __global__ void __launch_bounds__(C_THR) k_dense_agg_c(
   // at the same time, so the graph's operator lists come from HBM once and from that XCD's L2
   // for the other slices (consecutive workgroups are on DIFFERENT XCDs: PMC showed 215 MB per
   // launch against 117 MB of compulsory bytes with the plain u = blockIdx order)
-  const bool xcd_map = (gridDim.x % 8 == 0) && ((gridDim.x / 8) % nslices == 0);
+  const bool xcd_map = (gridDim.x % 8 == 0) && ((gridDim.x / 8) % sub == 0);
   for (int it = 0;; ++it) {
     int u;
     if (xcd_map) {
       const int per_xcd = gridDim.x / 8;                           // workgroups per XCD
       const int x = blockIdx.x % 8, i = blockIdx.x / 8;
-      const int gg = it * (gridDim.x / nslices) + x * (per_xcd / nslices) + i / nslices;
-      u = gg * nslices + i % nslices;
+      const int gg = it * (gridDim.x / sub) + x * (per_xcd / sub) + i / sub;
+      u = gg * sub + i % sub;
       if (it * (int)gridDim.x >= units) break;
       if (gg >= B) continue;
     } else {
       u = it * gridDim.x + blockIdx.x;
       if (u >= units) break;
     }
-    const int g = u / nslices, slice = u - g * nslices;
+    const int g = u / sub, rem = u - g * sub;
+    const int slice = rem % nslices, part = rem / nslices;
     const int base = gptr[g], n = gptr[g + 1] - base;
     const int ksteps = (n + 15) >> 4;
+    const int nrbn = (n + 31) >> 5, rb_per = (nrbn + rparts - 1) / rparts;
+    const int rb_lo = part * rb_per, rb_hi = min(nrbn, rb_lo + rb_per);
 
     // ---- transpose the [n x 64] slice of X into LDS; k in [n, 16*ksteps) is zero-filled
     __syncthreads();
@@ -192,7 +199,7 @@ __global__ void __launch_bounds__(C_THR) k_dense_agg_c(
     __syncthreads();
 
     double st1[2] = {0.0, 0.0}, st2[2] = {0.0, 0.0};
-    for (int rb = wave; 32 * rb < n; rb += C_NW) {
+    for (int rb = rb_lo + wave; rb < rb_hi; rb += C_NW) {
       const int64_t row = (int64_t)g * NRB + rb;
       const __half* b0 = Xt + r * KP + 8 * h;       // column 2r   (LDS row c/2 + 32*(c%2))
       const __half* b1 = b0 + 32 * KP;              // column 2r+1
@@ -378,9 +385,12 @@ int cgnn_dense_aggregate_c16(const void* dfrag, const int32_t* dstep, const uint
   if (num_graphs == 0) return CGNN_OK;
   if (!dfrag || !dstep || !doff || !sent || !sstep || !soff || !gptr || !X || !Y) return CGNN_EINVAL;
   if (!pack_attr()) return CGNN_ELAUNCH;
-  k_dense_agg_c<<<cgnn_fused_grid(), C_THR, c_lds(P, F), cgnn_stream(stream)>>>(
+  const int grid = cgnn_fused_grid();
+  int rparts = 1;
+  while (rparts < 4 && (int64_t)num_graphs * (F / 64) * rparts * 2 <= grid) rparts *= 2;
+  k_dense_agg_c<<<grid, C_THR, c_lds(P, F), cgnn_stream(stream)>>>(
       static_cast<const __half*>(dfrag), dstep, doff, sent, sstep, soff, P, gptr, num_graphs,
-      static_cast<const __half*>(X), ldx, F / 64, bias, static_cast<__half*>(Y), ldy, stat_slab);
+      static_cast<const __half*>(X), ldx, F / 64, bias, static_cast<__half*>(Y), ldy, stat_slab, rparts);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }
