@@ -22,6 +22,7 @@
 //   edges add up in fp32 before the one rounding to half, exactly as cgnn_dense_adj_f16 builds M.
 #include <hip/hip_fp16.h>
 #include "common.h"
+#include "drop_ew.h"
 
 namespace {
 
@@ -119,12 +120,33 @@ __global__ void __launch_bounds__(256) k_dense_pack(
 }
 
 // ------------------------------------------------------------------------------ Y_g = M_g X_g
+// BNB (backward of a GCN layer: dT = A_hat^T dY): X is not read but FORMED while the slice is staged,
+//   dY = a * (dX' * f - c1 - xhat * c2),  f = act' * keep / (1-p),  xhat = (Yl - mean) * invstd
+// from the gradient of the layer's activation (dX', or the readout's dP[graph] / n_g for the last
+// layer), the layer's pre-BatchNorm output Yl, its keep bytes, coefficient block and the backward
+// coefficients c1|c2 -- the arithmetic of k_bn_act_apply<true> (elementwise.hip), rounded to half as the
+// stored dY would be.  dY feeds nothing but this product (and db = column sums of dY, left per graph in
+// cs_slab [B][F] fp64), so the apply pass, its write of dY and this kernel's read of it disappear.
+struct DenseBnBwd {
+  const __half* dX;          // [M][ldx] or NULL (then dP)
+  const float* dP;           // [B][F] readout gradient (last layer) or NULL
+  const __half* Yl;          // [M][ldy]
+  int64_t ldyl;
+  const uint8_t* mask;       // [M][F/4] or NULL
+  const float* coef;         // [a | b | mean | invstd] x F
+  const float* bwc;          // [c1 | c2] x F
+  int relu;
+  float scale;
+  double* cs_slab;           // [B][F]
+};
+
+template <bool BNB>
 __global__ void __launch_bounds__(C_THR) k_dense_agg_c(
     const __half* __restrict__ dfrag, const int32_t* __restrict__ dstep, const uint32_t* __restrict__ doff,
     const uint32_t* __restrict__ sent, const int32_t* __restrict__ sstep, const uint32_t* __restrict__ soff,
     int P, const int32_t* __restrict__ gptr, int B, const __half* __restrict__ X, int64_t ldx,
     int nslices, const float* __restrict__ bias, __half* __restrict__ Y, int64_t ldy,
-    double* __restrict__ stat_slab, int rparts) {
+    double* __restrict__ stat_slab, int rparts, DenseBnBwd bb) {
   extern __shared__ __attribute__((aligned(16))) __half Xt[];       // [64][KP], the fragment slabs, wacc
   const int KP = c_kp(P);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
@@ -171,7 +193,7 @@ __global__ void __launch_bounds__(C_THR) k_dense_agg_c(
 
     // ---- transpose the [n x 64] slice of X into LDS; k in [n, 16*ksteps) is zero-filled
     __syncthreads();
-    {
+    if (!BNB) {
       const int piece = threadIdx.x & 7;
       constexpr int SU = 4;                         // rows in flight per thread
       for (int k0 = threadIdx.x >> 3; k0 < 16 * ksteps; k0 += SU * (C_THR / 8)) {
@@ -195,8 +217,85 @@ __global__ void __launch_bounds__(C_THR) k_dense_agg_c(
           }
         }
       }
+    } else {
+      // the same transposition of dY, formed here from dX' (or dP), Yl, the keep bytes and coefficients
+      const int piece = threadIdx.x & 7;
+      const int F = 64 * nslices, c0 = 64 * slice + 8 * piece;
+      float ca[8], cb[8], cm[8], ci[8], c1[8], c2[8], gp[8], cs[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        ca[i] = bb.coef[c0 + i]; cb[i] = bb.coef[F + c0 + i];
+        cm[i] = bb.coef[2 * F + c0 + i]; ci[i] = bb.coef[3 * F + c0 + i];
+        c1[i] = bb.bwc[c0 + i]; c2[i] = bb.bwc[F + c0 + i];
+        cs[i] = 0.f;
+        gp[i] = 0.f;
+      }
+      if (bb.dP) {
+        const float inv = 1.0f / ((float)n + 1e-8f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) gp[i] = bb.dP[(int64_t)g * F + c0 + i] * inv;
+      }
+      constexpr int SU = 3;
+      for (int k0 = threadIdx.x >> 3; k0 < 16 * ksteps; k0 += SU * (C_THR / 8)) {
+        uint4 vy[SU], vx[SU];
+        uint32_t kb[SU];
+#pragma unroll
+        for (int q = 0; q < SU; ++q) {
+          const int k = k0 + q * (C_THR / 8);
+          vy[q] = vx[q] = make_uint4(0u, 0u, 0u, 0u);
+          kb[q] = 0xFFu;
+          if (k < n) {
+            vy[q] = *reinterpret_cast<const uint4*>(bb.Yl + (int64_t)(base + k) * bb.ldyl + c0);
+            if (bb.dX) vx[q] = *reinterpret_cast<const uint4*>(bb.dX + (int64_t)(base + k) * ldx + c0);
+            if (bb.mask) {
+              const uint8_t* mp = bb.mask + (int64_t)(base + k) * (F >> 2) + (c0 >> 2);
+              kb[q] = (uint32_t)(mp[0] & 0xFu) | ((uint32_t)(mp[1] & 0xFu) << 4);
+            }
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < SU; ++q) {
+          const int k = k0 + q * (C_THR / 8);
+          if (k < 16 * ksteps) {
+            const __half* hy = reinterpret_cast<const __half*>(&vy[q]);
+            const __half* hx = reinterpret_cast<const __half*>(&vx[q]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              float d = 0.f;
+              if (k < n) {
+                const float y = __half2float(hy[i]);
+                const float gx = bb.dX ? __half2float(hx[i]) : gp[i];
+                const float z = fmaf(ca[i], y, cb[i]);
+                const float f = ((!bb.relu || z > 0.f) && ((kb[q] >> i) & 1u)) ? bb.scale : 0.f;
+                d = bn_bwd_dy(ca[i], gx, f, c1[i], y, cm[i], ci[i], c2[i]);
+                cs[i] += d;
+              }
+              const int c = 8 * piece + i;
+              Xt[((c >> 1) + 32 * (c & 1)) * KP + k] = __float2half_rn(d);
+            }
+          }
+        }
+      }
+      // db: column sums of dY over the graph.  Lanes with the same piece sit 8 apart in a wave; the 12
+      // waves' partials meet in the (unused here) statistics area behind the slabs.
+      if (part == 0) {
+        float* csr = reinterpret_cast<float*>(Xt + 64 * KP + C_NW * 1024);          // [C_NW][64]
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float v = cs[i];
+          v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+          if (lane < 8) csr[wave * 64 + 8 * piece + i] = v;
+        }
+      }
     }
     __syncthreads();
+    if (BNB && part == 0 && threadIdx.x < 64) {
+      const float* csr = reinterpret_cast<const float*>(Xt + 64 * KP + C_NW * 1024);
+      double tot = 0.0;
+#pragma unroll
+      for (int w2 = 0; w2 < C_NW; ++w2) tot += (double)csr[w2 * 64 + threadIdx.x];
+      bb.cs_slab[(int64_t)g * 64 * nslices + 64 * slice + threadIdx.x] = tot;
+    }
 
     double st1[2] = {0.0, 0.0}, st2[2] = {0.0, 0.0};
     for (int rb = rb_lo + wave; rb < rb_hi; rb += C_NW) {
@@ -319,8 +418,12 @@ __global__ void __launch_bounds__(C_THR) k_dense_agg_c(
   }
 }
 
+// transposed slice + the waves' fragment slabs + the statistics area (running column sums of the
+// forward statistics, or the waves' bias-gradient partials of the BNB form: C_NW x 64 floats)
 size_t c_lds(int P, int F) {
-  return ((size_t)64 * c_kp(P) + (size_t)C_NW * 1024) * sizeof(__half) + (size_t)2 * F * sizeof(double);
+  const size_t area = (size_t)2 * F * sizeof(double) > (size_t)C_NW * 64 * sizeof(float) ? (size_t)2 * F * sizeof(double)
+                                                                                       : (size_t)C_NW * 64 * sizeof(float);
+  return ((size_t)64 * c_kp(P) + (size_t)C_NW * 1024) * sizeof(__half) + area;
 }
 
 bool pack_attr() {
@@ -331,7 +434,9 @@ bool pack_attr() {
                             hipFuncAttributeMaxDynamicSharedMemorySize, 32 * C_MAXP * 4) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_dense_pack<true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 32 * C_MAXP * 4) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_dense_agg_c),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_dense_agg_c<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_dense_agg_c<true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return false;
     d = true;
@@ -388,9 +493,47 @@ int cgnn_dense_aggregate_c16(const void* dfrag, const int32_t* dstep, const uint
   const int grid = cgnn_fused_grid();
   int rparts = 1;
   while (rparts < 4 && (int64_t)num_graphs * (F / 64) * rparts * 2 <= grid) rparts *= 2;
-  k_dense_agg_c<<<grid, C_THR, c_lds(P, F), cgnn_stream(stream)>>>(
+  k_dense_agg_c<false><<<grid, C_THR, c_lds(P, F), cgnn_stream(stream)>>>(
       static_cast<const __half*>(dfrag), dstep, doff, sent, sstep, soff, P, gptr, num_graphs,
-      static_cast<const __half*>(X), ldx, F / 64, bias, static_cast<__half*>(Y), ldy, stat_slab, rparts);
+      static_cast<const __half*>(X), ldx, F / 64, bias, static_cast<__half*>(Y), ldy, stat_slab, rparts,
+      DenseBnBwd{});
+  CGNN_CHECK_LAUNCH();
+  return CGNN_OK;
+}
+
+int cgnn_dense_aggregate_c16_bnbwd(const void* dfrag, const int32_t* dstep, const uint32_t* doff,
+                                   const uint32_t* sent, const int32_t* sstep, const uint32_t* soff,
+                                   int32_t P, const int32_t* gptr, int32_t num_graphs, const void* dX,
+                                   int64_t lddx, const float* dP, const void* Yl, int64_t ldyl,
+                                   const uint8_t* mask, const float* coef, const float* bwc, int32_t relu,
+                                   float p_drop, int32_t F, void* dT, int64_t lddt, double* cs_slab,
+                                   void* stream) {
+  if (num_graphs < 0 || P <= 0 || F <= 0 || ldyl < F || lddt < F || (dX && lddx < F)) return CGNN_EINVAL;
+  if ((!dX) == (!dP) || !Yl || !coef || !bwc || !cs_slab || p_drop < 0.f || p_drop >= 1.f || (p_drop > 0.f && !mask))
+    return CGNN_EINVAL;
+  if (P > C_MAXP || P % 64 || F % 64 || ldyl % 8 || (dX && lddx % 8) || c_lds(P, F) > 160 * 1024) return CGNN_EUNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(dX) | reinterpret_cast<uintptr_t>(Yl)) & 15) return CGNN_EUNSUPPORTED;
+  if (num_graphs == 0) return CGNN_OK;
+  if (!dfrag || !dstep || !doff || !sent || !sstep || !soff || !gptr || !dT) return CGNN_EINVAL;
+  if (!pack_attr()) return CGNN_ELAUNCH;
+  const int grid = cgnn_fused_grid();
+  int rparts = 1;
+  while (rparts < 4 && (int64_t)num_graphs * (F / 64) * rparts * 2 <= grid) rparts *= 2;
+  DenseBnBwd bb;
+  bb.dX = static_cast<const __half*>(dX);
+  bb.dP = dP;
+  bb.Yl = static_cast<const __half*>(Yl);
+  bb.ldyl = ldyl;
+  bb.mask = p_drop > 0.f ? mask : nullptr;
+  bb.coef = coef;
+  bb.bwc = bwc;
+  bb.relu = relu;
+  bb.scale = p_drop > 0.f ? (float)(1.0 / (1.0 - (double)p_drop)) : 1.0f;
+  bb.cs_slab = cs_slab;
+  k_dense_agg_c<true><<<grid, C_THR, c_lds(P, F), cgnn_stream(stream)>>>(
+      static_cast<const __half*>(dfrag), dstep, doff, sent, sstep, soff, P, gptr, num_graphs,
+      static_cast<const __half*>(dX), dX ? lddx : 0, F / 64, nullptr, static_cast<__half*>(dT), lddt, nullptr,
+      rparts, bb);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }

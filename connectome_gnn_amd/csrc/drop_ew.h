@@ -30,6 +30,27 @@ __device__ __forceinline__ uint32_t drop_bits(const DropCfg& d, uint32_t chunk_i
   return b;
 }
 
+// One element of BatchNorm's backward, dY = a * ((g*f - c1) - xhat*c2) with xhat = (y - mean) * invstd,
+// in ONE fixed sequence of separately rounded operations: k_bn_act_apply<true> (elementwise.hip) and
+// the aggregate that forms dY while staging (dense_aggregate_c16.hip) must produce the same bits, and
+// neither `#pragma clang fp contract(off)` nor expression shape survives inlining into kernels that
+// are otherwise compiled with contraction on -- so the operations are spelled as instructions.
+__device__ __forceinline__ float ew_mul(float a, float b) {
+  float r;
+  asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float ew_sub(float a, float b) {
+  float r;
+  asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float bn_bwd_dy(float a, float g, float f, float c1, float y, float mean,
+                                           float invstd, float c2) {
+  const float xhat = ew_mul(ew_sub(y, mean), invstd);
+  return ew_mul(a, ew_sub(ew_sub(ew_mul(g, f), c1), ew_mul(xhat, c2)));
+}
+
 inline DropCfg make_drop(float p, uint64_t seed, int* use_drop) {
   DropCfg d;
   *use_drop = (p > 0.f) ? 1 : 0;

@@ -312,10 +312,10 @@ __global__ void __launch_bounds__(256) k_bn_act_apply(
       const float4 g = pg.dP ? pool_grad(pg, i / nch, N, c) : EW_LD(dXp + 4 * i);
       const float4 cm = ld4(coef + 2 * N + 4 * c), ci = ld4(coef + 3 * N + 4 * c);
       const float4 c1 = ld4(bwc + 4 * c), c2 = ld4(bwc + N + 4 * c);
-      float4 d = make_float4(ca.x * (g.x * fx - c1.x - (y.x - cm.x) * ci.x * c2.x),
-                             ca.y * (g.y * fy - c1.y - (y.y - cm.y) * ci.y * c2.y),
-                             ca.z * (g.z * fz - c1.z - (y.z - cm.z) * ci.z * c2.z),
-                             ca.w * (g.w * fw - c1.w - (y.w - cm.w) * ci.w * c2.w));
+      float4 d = make_float4(bn_bwd_dy(ca.x, g.x, fx, c1.x, y.x, cm.x, ci.x, c2.x),
+                             bn_bwd_dy(ca.y, g.y, fy, c1.y, y.y, cm.y, ci.y, c2.y),
+                             bn_bwd_dy(ca.z, g.z, fz, c1.z, y.z, cm.z, ci.z, c2.z),
+                             bn_bwd_dy(ca.w, g.w, fw, c1.w, y.w, cm.w, ci.w, c2.w));
       if (relu_in) {
         d.x = y.x > 0.f ? d.x : 0.f; d.y = y.y > 0.f ? d.y : 0.f;
         d.z = y.z > 0.f ? d.z : 0.f; d.w = y.w > 0.f ? d.w : 0.f;

@@ -206,20 +206,30 @@ class GcnHalfEncode(torch.autograd.Function):
                     _lib.check(lib.cgnn_bn_act_bwd_finalize(_lib.ptr(slab), srows, hid, float(max(n_nodes, 1)), None,
                                                             int(not sv.training), _lib.ptr(dgamma), _lib.ptr(dbeta),
                                                             _lib.ptr(bwc), sp), "cgnn_bn_act_bwd_finalize")
-                cs_rows = int(lib.cgnn_bn_act_apply_blocks(n_nodes, hid))
-                cs_slab = torch.empty(cs_rows, hid, dtype=torch.float64, device=dev)
-                dy = torch.empty_like(y)
-                _lib.check(lib.cgnn_bn_act_bwd_apply_f16(_lib.ptr(dx), _lib.ptr(y), _lib.ptr(mask), _lib.ptr(coef),
-                                                         _lib.ptr(bwc), 1, sv.p, 0, _lib.ptr(cs_slab), _lib.ptr(dy),
-                                                         n_nodes, hid, *pool, sp), "cgnn_bn_act_bwd_apply_f16")
                 db = _f32(dev, hid)
-                deferred.add(cs_slab, cs_rows, hid, db)       # all layers' db: one launch at the end
+                if li > 0 and isinstance(sv.mb, ops.DensePack):
+                    # dT = A_hat^T dY with dY formed while the aggregate stages its slices: no apply
+                    # pass, dY is never written (db from the per-graph column sums it leaves)
+                    dt, cs_slab = ops.dense_aggregate_c16_bnbwd_raw(
+                        s, sv.mb, dx, dP if li == L - 1 else None, y, mask, coef, bwc, True, sv.p)
+                    deferred.add(cs_slab, s.num_graphs, hid, db)
+                    dy = None
+                else:
+                    cs_rows = int(lib.cgnn_bn_act_apply_blocks(n_nodes, hid))
+                    cs_slab = torch.empty(cs_rows, hid, dtype=torch.float64, device=dev)
+                    dy = torch.empty_like(y)
+                    _lib.check(lib.cgnn_bn_act_bwd_apply_f16(_lib.ptr(dx), _lib.ptr(y), _lib.ptr(mask), _lib.ptr(coef),
+                                                             _lib.ptr(bwc), 1, sv.p, 0, _lib.ptr(cs_slab), _lib.ptr(dy),
+                                                             n_nodes, hid, *pool, sp), "cgnn_bn_act_bwd_apply_f16")
+                    deferred.add(cs_slab, cs_rows, hid, db)       # all layers' db: one launch at the end
+                    dt = None
                 if li == 0:
                     # Y0 = (A_hat X0) W0^T + b0: dW0 = dY0^T P0, no aggregation in the backward
                     dw = ops.linear_bwd_weight_f16_raw(dy, sv.p0, w.shape[1])
                     grads[0:4] = [dw, db, dgamma, dbeta]
                     break
-                dt = _agg(s, sv.mb, dy)             # dT = A_hat^T dY
+                if dt is None:
+                    dt = _agg(s, sv.mb, dy)         # dT = A_hat^T dY
                 grads[4 * li:4 * li + 4] = [ops.linear_bwd_weight_f16_raw(dt, x), db, dgamma, dbeta]
                 dx = ops.linear_bwd_input_f16_raw(dt, w)                   # dX = dT W
             deferred.flush(sp)

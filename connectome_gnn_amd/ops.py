@@ -270,6 +270,24 @@ def dense_aggregate_c16_raw(structure, pack: DensePack, x, bias=None, stat_slab=
     return y
 
 
+def dense_aggregate_c16_bnbwd_raw(structure, pack: DensePack, dx, dP, yl, mask, coef, bwc, relu: bool, p: float):
+    """dT = M_g dY with dY = BatchNorm'(dX' * act' * drop') formed while the slices are staged
+    (cgnn_dense_aggregate_c16_bnbwd): returns (dT half [M, F], cs_slab fp64 [B, F] = per-graph column
+    sums of dY).  Exactly one of dx (half [M, F]) and dP (fp32 [B, F], readout gradient)."""
+    lib = _lib.load()
+    n, f = yl.shape
+    dt = torch.empty(n, f, dtype=torch.float16, device=yl.device)
+    cs = torch.empty(structure.num_graphs, f, dtype=torch.float64, device=yl.device)
+    with _lib.device_guard(yl.device), _lib.timed("cgnn_dense_aggregate_c16_bnbwd", f"F={f}"):
+        _lib.check(lib.cgnn_dense_aggregate_c16_bnbwd(
+            _lib.ptr(pack.dfrag), _lib.ptr(pack.dstep), _lib.ptr(pack.doff), _lib.ptr(pack.sent),
+            _lib.ptr(pack.sstep), _lib.ptr(pack.soff), pack.pitch, _lib.ptr(structure.gptr), structure.num_graphs,
+            _lib.ptr(dx), 0 if dx is None else dx.stride(0), _lib.ptr(dP), _lib.ptr(yl), yl.stride(0), _lib.ptr(mask),
+            _lib.ptr(coef), _lib.ptr(bwc), int(relu), float(p), f, _lib.ptr(dt), dt.stride(0), _lib.ptr(cs),
+            _lib.stream_ptr()), "cgnn_dense_aggregate_c16_bnbwd")
+    return dt, cs
+
+
 # ---- fp16-storage projections (gemm_h16.hip): activations half, weights / weight gradients fp32
 def _need_half(t: torch.Tensor, what: str) -> None:
     _require_device(t, what)

@@ -385,6 +385,22 @@ int cgnn_dense_aggregate_c16(const void* dfrag, const int32_t* dstep, const uint
                              int32_t P, const int32_t* gptr, int32_t num_graphs, const void* X,
                              int64_t ldx, int32_t F, const float* bias, void* Y, int64_t ldy,
                              double* stat_slab, void* stream);
+/* The backward product dT = A_hat^T dY of a GCN layer with dY never materialised: the slice handed to
+ * the matrix cores is formed while it is staged,
+ *     dY = a * (dX' * f - c1 - xhat * c2),   f = relu' * keep / (1-p),   xhat = (Yl - mean) * invstd
+ * (the arithmetic of cgnn_bn_act_bwd_apply_f16, models.py:208-210 through autograd), from the gradient
+ * of the layer's activation -- dX' [M, F] half, or for the last layer the readout gradient dP [B, F]
+ * fp32 (row gradient dP[graph] / (n_g + 1e-8)); exactly one of the two -- the layer's pre-BatchNorm
+ * output Yl, keep bytes, coefficient block `coef` and the backward coefficients `bwc`.  dY feeds
+ * nothing else but the bias gradient: its column sums are left per graph in cs_slab [B][F] fp64
+ * (combine with cgnn_slab_reduce_f64(cs_slab, B, F, db)). */
+int cgnn_dense_aggregate_c16_bnbwd(const void* dfrag, const int32_t* dstep, const uint32_t* doff,
+                                   const uint32_t* sent, const int32_t* sstep, const uint32_t* soff,
+                                   int32_t P, const int32_t* gptr, int32_t num_graphs, const void* dX,
+                                   int64_t lddx, const float* dP, const void* Yl, int64_t ldyl,
+                                   const uint8_t* mask, const float* coef, const float* bwc, int32_t relu,
+                                   float p_drop, int32_t F, void* dT, int64_t lddt, double* cs_slab,
+                                   void* stream);
 
 
 /* Layer 0 forward.  X0 [Nn,F0] (F0 <= 16), W0 [64,F0], bias [64] -> Y [Nn,64];

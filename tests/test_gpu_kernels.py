@@ -804,3 +804,40 @@ def test_gather_rows_and_multi_reduce():
     red.flush(sp)
     for t, o in zip(slabs, outs):
         torch.testing.assert_close(o, t.sum(dim=0).float(), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("sizes,deg,f,p,pooled", [([1000, 37, 500], 60, 256, 0.3, False), ([84] * 5, 8, 64, 0.0, False),
+                                                   ([1008, 3], 130, 128, 0.3, True), ([64, 1, 200], 3, 64, 0.5, True)])
+def test_dense_aggregate_with_bn_backward_prologue_equals_two_passes(sizes, deg, f, p, pooled):
+    """cgnn_dense_aggregate_c16_bnbwd (dY = BatchNorm'(dX' * relu' * drop') formed while the slices are
+    staged, db left per graph) == cgnn_bn_act_bwd_apply_f16 followed by cgnn_dense_aggregate_c16: the
+    same half-rounded dY goes through the same MFMAs (bit-identical dT), the bias gradient agrees to
+    the order of its fp64 fold."""
+    from connectome_gnn_amd import _lib, ops
+    lib = _lib.load()
+    ei, w, ptr, bid, nn_ = _rand_graph_batch(sizes, deg, 23)
+    b = _batch(ei, w, ptr, bid, nn_, f).to(DEV)
+    s = b.structure()
+    norm = s.gcn_norm()
+    pk = ops.dense_pack_f16(s, norm.coef_src, norm.selfc, True)
+    g = torch.Generator().manual_seed(f + len(sizes))
+    y = (torch.randn(nn_, f, generator=g) * 1.2 + 0.1).half().to(DEV)
+    dx = None if pooled else (torch.randn(nn_, f, generator=g) * 0.3).half().to(DEV)
+    dP = torch.randn(len(sizes), f, generator=g).to(DEV) if pooled else None
+    coef = torch.cat([torch.rand(f, generator=g) + 0.5, torch.randn(f, generator=g) * 0.3,
+                      torch.randn(f, generator=g) * 0.2, torch.rand(f, generator=g) + 0.7]).to(DEV)
+    bwc = (torch.randn(2 * f, generator=g) * 0.05).to(DEV)
+    mask = torch.randint(0, 16, (nn_ * f // 4,), generator=g, dtype=torch.uint8).to(DEV) if p > 0 else None
+    sp = _lib.stream_ptr(torch.device(DEV))
+    rows = int(lib.cgnn_bn_act_apply_blocks(nn_, f))
+    cs = torch.empty(rows, f, dtype=torch.float64, device=DEV)
+    dy = torch.empty_like(y)
+    pool = (_lib.ptr(dP), _lib.ptr(s.node_graph), _lib.ptr(s.gptr)) if pooled else (None, None, None)
+    _lib.check(lib.cgnn_bn_act_bwd_apply_f16(_lib.ptr(dx), _lib.ptr(y), _lib.ptr(mask), _lib.ptr(coef), _lib.ptr(bwc), 1, p, 0,
+                                             _lib.ptr(cs), _lib.ptr(dy), nn_, f, *pool, sp), "bwd_apply")
+    want = ops.dense_aggregate_c16_raw(s, pk, dy)
+    got, cs2 = ops.dense_aggregate_c16_bnbwd_raw(s, pk, dx, dP, y, mask, coef, bwc, True, p)
+    assert cs2.shape == (len(sizes), f)
+    assert torch.equal(got, want)
+    db_want, db_got = cs.sum(0), cs2.sum(0)
+    torch.testing.assert_close(db_got, db_want, rtol=1e-6, atol=1e-6 * float(dy.float().abs().sum(0).max()) + 1e-9)
