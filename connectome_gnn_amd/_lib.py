@@ -166,7 +166,8 @@ PROTOTYPES = {
     "cgnn_aggregate_tiled_bn_f32": (c_int, [TP, I32, P, I64, I32, P, P, P, P, I64, P, I32, F32, U64, P, P, P, I64, P]),
     "cgnn_slab_reduce_f64_multi": (c_int, [ctypes.POINTER(CgnnReduceJobs), P]),
     "cgnn_gather_f32": (c_int, [P, P, I64, P, P]),
-    "cgnn_gather_rows": (c_int, [ctypes.POINTER(CgnnGatherJobs), P, I32, P]),
+    "cgnn_gather_rows": (c_int, [ctypes.POINTER(CgnnGatherJobs), P, I32, P, P]),
+    "cgnn_epoch_advance": (c_int, [P, I64, P, F32, P, P]),
     "cgnn_gcn_dis": (c_int, [P, P, I64, P, P]),
     "cgnn_fused_grid": (c_int, []),
     "cgnn_gcn_fused_fwd_first": (c_int, [TP, P, I32, P, P, P, P, P]),

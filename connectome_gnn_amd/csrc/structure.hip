@@ -433,10 +433,19 @@ int scan_i32(int32_t* counts, int64_t n, int32_t* tile_sums, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? CGNN_OK : CGNN_ELAUNCH;
 }
 
+// bookkeeping of a replayed epoch, one thread: the next batch's position and the running loss tally
+__global__ void k_epoch_advance(int64_t* cursor, int64_t step, const float* __restrict__ loss, float weight,
+                                float* tally) {
+  if (tally) tally[0] += loss[0] * weight;
+  cursor[0] += step;
+}
+
 // Several row gathers by ONE id list in one launch (resident datasets: node features, labels, block
 // offsets and `dis` of a batch's subjects): dst_j[i] = src_j[ids[i]], rows of row_bytes_j bytes.
 // blockIdx.y = job, blockIdx.x strides over the ids; 16-byte words when a job's rows allow it.
-__global__ void __launch_bounds__(256) k_gather_rows(cgnn_gather_jobs jobs, const int64_t* __restrict__ ids, int nids) {
+__global__ void __launch_bounds__(256) k_gather_rows(cgnn_gather_jobs jobs, const int64_t* __restrict__ ids, int nids,
+                                                     const int64_t* __restrict__ ids_offset) {
+  if (ids_offset) ids += ids_offset[0];          // the batch's position in a longer id list (device cursor)
   const int jb = blockIdx.y;
   const int64_t rb = jobs.row_bytes[jb];
   const char* src = static_cast<const char*>(jobs.src[jb]);
@@ -618,7 +627,8 @@ int cgnn_bell_fill(const int32_t* tile_ptr, const int32_t* tile_blk, int32_t num
   return CGNN_OK;
 }
 
-int cgnn_gather_rows(const cgnn_gather_jobs* jobs, const int64_t* ids, int32_t num_ids, void* stream) {
+int cgnn_gather_rows(const cgnn_gather_jobs* jobs, const int64_t* ids, int32_t num_ids,
+                     const int64_t* ids_offset, void* stream) {
   if (!jobs || jobs->n < 0 || jobs->n > CGNN_GATHER_MAX_JOBS || num_ids < 0) return CGNN_EINVAL;
   if (jobs->n == 0 || num_ids == 0) return CGNN_OK;
   if (!ids) return CGNN_EINVAL;
@@ -627,7 +637,15 @@ int cgnn_gather_rows(const cgnn_gather_jobs* jobs, const int64_t* ids, int32_t n
         ((reinterpret_cast<uintptr_t>(jobs->src[j]) | reinterpret_cast<uintptr_t>(jobs->dst[j])) & 3))
       return CGNN_EINVAL;
   const int gx = num_ids < 2048 ? num_ids : 2048;
-  k_gather_rows<<<dim3(gx, jobs->n), 256, 0, cgnn_stream(stream)>>>(*jobs, ids, num_ids);
+  k_gather_rows<<<dim3(gx, jobs->n), 256, 0, cgnn_stream(stream)>>>(*jobs, ids, num_ids, ids_offset);
+  CGNN_CHECK_LAUNCH();
+  return CGNN_OK;
+}
+
+int cgnn_epoch_advance(int64_t* cursor, int64_t step, const float* loss, float weight, float* tally,
+                       void* stream) {
+  if (!cursor || (tally && !loss)) return CGNN_EINVAL;
+  k_epoch_advance<<<1, 1, 0, cgnn_stream(stream)>>>(cursor, step, loss, weight, tally);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }

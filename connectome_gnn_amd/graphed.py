@@ -98,11 +98,16 @@ class GraphedTrainStep:
             self.graph_tail = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_tail, pool=self.graph.pool(), **mode):
                 self.optimizer.step()
+                self._end_of_step()
         else:
             with torch.cuda.graph(self.graph, **mode):
                 self.loss = self._fwd_bwd()
                 self._exchange()
                 self.optimizer.step()
+                self._end_of_step()
+
+    def _end_of_step(self) -> None:
+        """Captured after the optimizer step (subclasses: per-step bookkeeping on the device)."""
 
     def _has_sync_bn(self) -> bool:
         import torch.distributed as dist
@@ -142,23 +147,62 @@ class GraphedResidentStep(GraphedTrainStep):
     """One captured step for EVERY batch of a given size drawn from a device-resident dataset with a
     per-subject structure cache (structure_cache.py: one graph per tile, the per-tile GCN path).
 
-    The batch is assembled inside the graph -- five gathers by the subject ids in a fixed device
-    buffer (node features, labels, the two block-offset rows, `dis`) -- so a replay is: copy this
-    batch's ids into the buffer, launch.  ``Trainer(graph=True)`` uses it for ResidentBatch inputs:
-    a loader that re-shuffles every epoch (the reference's semantics, graph.py:190-197) then runs at
-    replay speed instead of issuing ~45 launches per step from Python."""
+    The batch is assembled inside the graph -- one launch gathers node features, labels, the two
+    block-offset rows and `dis` by the subject ids (cgnn_gather_rows) -- and the ids are a WINDOW of a
+    fixed device buffer whose position is a device cursor that the captured step itself advances
+    (cgnn_epoch_advance, which also adds loss x graphs to a device tally).  So an epoch is: copy this
+    rank's permutation into the buffer once (``run_epoch``), then nothing but graph launches --
+    ``Trainer(graph=True)`` over a loader that re-shuffles every epoch (the reference's semantics,
+    graph.py:190-197) runs at the speed of replaying one fixed batch.  ``step(batch)`` remains for single
+    batches (ids copied to the front of the buffer, cursor reset)."""
 
     def __init__(self, model, optimizer, first_batch, loss_fn=None, **kw):
         from .structure_cache import ResidentBatch
+        from . import _lib
         cache = first_batch._cache
-        self.ids_buf = first_batch._ids.clone()
-        cache.static(int(self.ids_buf.numel()))            # batch-size constants exist before capture
+        dev = cache.dataset.x.device
+        b = int(first_batch._ids.numel())
+        self._b, self._lib = b, _lib
+        self.order_buf = torch.zeros(max(int(cache.dataset.num_subjects), b), dtype=torch.long, device=dev)
+        self.order_buf[:b].copy_(first_batch._ids)
+        self.cursor = torch.zeros(1, dtype=torch.long, device=dev)
+        self.tally = torch.zeros(1, dtype=torch.float32, device=dev)       # sum of loss x graphs since take_tally()
+        self.ids_buf = self.order_buf[:b]                                   # (the window at cursor 0)
+        cache.static(b)                                    # batch-size constants exist before capture
         super().__init__(model, optimizer, first_batch, loss_fn,
-                         make_batch=lambda: ResidentBatch(cache, self.ids_buf), **kw)
+                         make_batch=lambda: ResidentBatch(cache, self.ids_buf, ids_offset=self.cursor), **kw)
+        # the warm-up passes and the capture left cursor / tally wherever they were: start clean
+        self.cursor.zero_()
+        self.tally.zero_()
+
+    def _end_of_step(self) -> None:
+        lib = self._lib
+        dev = self.cursor.device
+        with lib.device_guard(dev):
+            lib.check(lib.load().cgnn_epoch_advance(lib.ptr(self.cursor), self._b, lib.ptr(self.loss), float(self._b),
+                                                    lib.ptr(self.tally), lib.stream_ptr(dev)), "cgnn_epoch_advance")
 
     def __call__(self, batch=None) -> torch.Tensor:
         if batch is not None:
-            # the ids as the loader handed them over (host): one small copy, no gather is launched
+            # the ids as the loader handed them over: one small copy, no gather is launched
             self.ids_buf.copy_(getattr(batch, "_ids_src", batch._ids), non_blocking=True)
+        self.cursor.zero_()
         return super().__call__()
 
+    def run_epoch(self, ids: torch.Tensor, steps: int) -> None:
+        """``steps`` consecutive batches of this step's size whose subject ids are ``ids`` (device,
+        steps x batch_size, in order): one copy, then only replays.  Losses pile up in ``tally``."""
+        n = steps * self._b
+        if int(ids.numel()) != n or n > int(self.order_buf.numel()):
+            raise ValueError("run_epoch: ids must hold steps x batch_size subject ids (at most the dataset's size)")
+        self.order_buf[:n].copy_(ids, non_blocking=True)
+        self.cursor.zero_()
+        self.tally.zero_()              # (single-batch calls in between also fed it: their losses were read directly)
+        for _ in range(steps):
+            super().__call__()
+
+    def take_tally(self) -> torch.Tensor:
+        """Sum of loss x graphs over the replays since the last call (device scalar); resets it."""
+        out = self.tally.clone()
+        self.tally.zero_()
+        return out.reshape(())

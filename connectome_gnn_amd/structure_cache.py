@@ -178,8 +178,12 @@ class ResidentBatch(ConnectomeBatch):
     fields bit-identical to ``assemble_batch`` -- so handing the batch to a captured step that reads
     only its subject ids launches nothing."""
 
-    def __init__(self, cache: SubjectStructureCache, ids: torch.Tensor):
+    def __init__(self, cache: SubjectStructureCache, ids: torch.Tensor, ids_offset: Optional[torch.Tensor] = None):
+        """ids_offset (device int64 [1], optional): the batch is ``ids[offset : offset + len(ids)]`` of a
+        longer id buffer that starts at ``ids`` -- the offset is read by the assembling kernel, so a
+        captured step walks an epoch's permutation without any per-step host copy."""
         self._cache, self._ids_src = cache, ids      # as handed in (host ids of a loader: no copy yet)
+        self._ids_offset = ids_offset
         self._b = int(ids.numel())
         self._lazy = {}
         self._coo = None
@@ -211,8 +215,8 @@ class ResidentBatch(ConnectomeBatch):
                 jobs.src[i], jobs.dst[i] = src.data_ptr(), dst.data_ptr()
                 jobs.row_bytes[i] = src[0].numel() * src.element_size()
             with _lib.device_guard(dev):
-                _lib.check(_lib.load().cgnn_gather_rows(jobs, _lib.ptr(self._ids), b, _lib.stream_ptr(dev)),
-                           "cgnn_gather_rows")
+                _lib.check(_lib.load().cgnn_gather_rows(jobs, _lib.ptr(self._ids), b, _lib.ptr(self._ids_offset),
+                                                        _lib.stream_ptr(dev)), "cgnn_gather_rows")
             self._lazy["asm"] = (x, y, od, os_, dis)
         return self._lazy["asm"]
 
@@ -225,6 +229,8 @@ class ResidentBatch(ConnectomeBatch):
     num_nodes = property(lambda self: self._b * self._cache.n)
 
     def _materialise(self):
+        if self._ids_offset is not None:
+            raise RuntimeError("a cursor-addressed ResidentBatch (captured epoch replay) has no fixed COO fields")
         if self._coo is None:
             from .resident import assemble_batch
             full = assemble_batch(self._cache.dataset, self._ids)

@@ -210,13 +210,47 @@ class Trainer:
         self.optimizer.step()
         return loss.detach()
 
+    def _replay_epoch(self, loader, tally: "_DeviceTally") -> bool:
+        """A whole epoch of a ``ResidentDataLoader(structure_cache=True)`` from captured steps: this
+        rank's permutation goes to the device once, every run of equal-sized batches whose step is
+        already captured is nothing but graph launches (GraphedResidentStep.run_epoch: the ids are read
+        through a device cursor, the loss tally is kept by the captured step).  Batches whose size has
+        no captured step yet take the ordinary path (which captures it).  False = not applicable."""
+        from .resident import ResidentDataLoader
+        cache = getattr(loader, "structure_cache", None)
+        if not (self.graph and isinstance(loader, ResidentDataLoader) and cache is not None
+                and not loader.cache_batches):
+            return False
+        from .structure_cache import ResidentBatch
+        chunks = list(loader._chunks())
+        i = 0
+        while i < len(chunks):
+            size = int(chunks[i].numel())
+            j = i
+            while j < len(chunks) and int(chunks[j].numel()) == size:
+                j += 1
+            step = self._graphs.get(("resident", id(cache), size))
+            if step is None or self._data_parallel():
+                # first sighting of this size (the ordinary path captures it); under data parallelism
+                # the exchange sits between two graphs per step, which the per-batch path handles
+                for c in chunks[i:j]:
+                    tally.add_scaled(self.train_step(ResidentBatch(cache, c), _borrow=True), size)
+            else:
+                run = chunks[i:j]
+                ids = run[0] if len(run) == 1 else torch.cat(run)
+                step.run_epoch(ids.to(step.order_buf.device), len(run))
+                tally.add(step.take_tally(), size * len(run))
+            i = j
+        return True
+
     def train_epoch(self, loader) -> float:
         """One pass over ``loader``; mean loss weighted by graphs per batch (train.py:52-54)."""
         self.model.train()
         tally = _DeviceTally()
-        for batch in loader:
-            graphs = batch.num_graphs
-            tally.add_scaled(self.train_step(batch, _borrow=True), graphs)
+        if not self._replay_epoch(loader, tally):
+            for batch in loader:
+                graphs = batch.num_graphs
+                tally.add_scaled(self.train_step(batch, _borrow=True), graphs)
         (loss_sum,), seen = self._global_tallies(loader, tally)
         return loss_sum / max(seen, 1)
 

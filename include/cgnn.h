@@ -264,7 +264,9 @@ int cgnn_gather_f32(const float* src, const int32_t* idx, int64_t n, float* out,
  * row_bytes[j] bytes (a multiple of 4; pointers 4-byte aligned).  The on-device form of the
  * reference's collate for device-resident regular datasets (graph.py:143-167 stacks node features and
  * labels per graph) extended to the per-subject structure arrays: node features, labels, blocked-ELL
- * block offsets and `dis` of a batch leave in one kernel. */
+ * block offsets and `dis` of a batch leave in one kernel.
+ * ids_offset (nullable, device): the id list starts at ids + *ids_offset -- a captured step reads the
+ * batch's position in the epoch's permutation from a device cursor, so replays need no host copy. */
 #define CGNN_GATHER_MAX_JOBS 8
 typedef struct cgnn_gather_jobs {
   int32_t n;
@@ -272,7 +274,12 @@ typedef struct cgnn_gather_jobs {
   void* dst[CGNN_GATHER_MAX_JOBS];
   int64_t row_bytes[CGNN_GATHER_MAX_JOBS];
 } cgnn_gather_jobs;
-int cgnn_gather_rows(const cgnn_gather_jobs* jobs, const int64_t* ids, int32_t num_ids, void* stream);
+int cgnn_gather_rows(const cgnn_gather_jobs* jobs, const int64_t* ids, int32_t num_ids,
+                     const int64_t* ids_offset, void* stream);
+/* End-of-step bookkeeping of an epoch replayed from one captured step (reference train.py:52-54 keeps
+ * the running loss on the host): *tally += *loss * weight (tally nullable), *cursor += step. */
+int cgnn_epoch_advance(int64_t* cursor, int64_t step, const float* loss, float weight, float* tally,
+                       void* stream);
 
 /* GCN degree normalisation, models.py:97-105, every step: dis[i] = (sum of row i of w_src
  * (COO order) + 1 + 1e-8)^-1/2 with w_src the edge weights in src-CSR slot order. */

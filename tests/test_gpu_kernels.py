@@ -791,11 +791,20 @@ def test_gather_rows_and_multi_reduce():
     for i, (a, b) in enumerate(zip(srcs, dsts)):
         jobs.src[i], jobs.dst[i], jobs.row_bytes[i] = a.data_ptr(), b.data_ptr(), a[0].numel() * a.element_size()
     sp = _lib.stream_ptr(torch.device(DEV))
-    _lib.check(lib.cgnn_gather_rows(jobs, _lib.ptr(ids), ids.numel(), sp), "gather_rows")
+    _lib.check(lib.cgnn_gather_rows(jobs, _lib.ptr(ids), ids.numel(), None, sp), "gather_rows")
     for a, b in zip(srcs, dsts):
         assert torch.equal(b, a.index_select(0, ids))
+    # the id list as a window of a longer one, its position read from a device cursor
+    cursor = torch.tensor([2], dtype=torch.long, device=DEV)
+    tally = torch.tensor([0.5], device=DEV)
+    _lib.check(lib.cgnn_gather_rows(jobs, _lib.ptr(ids), 4, _lib.ptr(cursor), sp), "gather_rows")
+    for a, b in zip(srcs, dsts):
+        assert torch.equal(b[:4], a.index_select(0, ids[2:6]))
+    _lib.check(lib.cgnn_epoch_advance(_lib.ptr(cursor), 4, _lib.ptr(torch.tensor([0.25], device=DEV)), 8.0, _lib.ptr(tally), sp),
+               "epoch_advance")
+    assert int(cursor) == 6 and float(tally) == 2.5
     jobs.row_bytes[1] = 6
-    assert lib.cgnn_gather_rows(jobs, _lib.ptr(ids), ids.numel(), sp) == _lib.CGNN_EINVAL      # not a multiple of 4
+    assert lib.cgnn_gather_rows(jobs, _lib.ptr(ids), ids.numel(), None, sp) == _lib.CGNN_EINVAL   # not a multiple of 4
     red = _lib.DeferredReduce()
     slabs = [torch.randn(r, w, generator=g, dtype=torch.float64).to(DEV) for r, w in ((1024, 256), (3, 64), (250, 128))]
     outs = [torch.empty(t.shape[1], device=DEV) for t in slabs]
