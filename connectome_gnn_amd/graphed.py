@@ -71,7 +71,10 @@ class GraphedTrainStep:
         if split and self._has_sync_bn():
             raise ValueError("SyncBatchNorm exchanges statistics inside forward/backward: a captured "
                              "step needs collectives='captured' (or use per-rank BatchNorm)")
-        model.prepare_batch(batch)                          # host syncs happen here, not in capture
+        try:
+            model.prepare_batch(batch, reuse=True)          # host syncs happen here, not in capture
+        except TypeError:                                   # (a model with the reference's signature)
+            model.prepare_batch(batch)
         if getattr(model, "rng_device_state", None) is None:
             model.rng_device_state = torch.randint(0, 2 ** 31 - 1, (16,), dtype=torch.int32, device=dev)
         side = torch.cuda.Stream(device=dev)

@@ -223,11 +223,17 @@ class _ConnectomeModel(nn.Module):
             return l2(y)
         return self.classifier(pooled)
 
-    def prepare_batch(self, batch: ConnectomeBatch) -> None:
+    def prepare_batch(self, batch: ConnectomeBatch, reuse: bool = False) -> None:
         """Build every piece of static per-batch metadata this model will use (CSR, and the
         blocked-ELL of the fused path) now -- these builds read sizes back to the host, so they
-        must not happen inside a HIP-graph capture or a timed region."""
+        must not happen inside a HIP-graph capture or a timed region.  reuse=True says the batch
+        will be trained on repeatedly (cached batches, captured steps): structure work that only
+        pays when amortised is then done too (the per-tile GCN path's degree-ordered twin)."""
         s = batch.structure()
+        if reuse:
+            self._prepare_reused(batch, s)
+            if getattr(s, "__dict__", {}).get("_degree_twin") is not None:
+                return                                  # the encoder runs on the twin's metadata
         if self.storage == "fp16":
             from . import gcn_half_path
             gcn_half_path.dense_operators(s)
@@ -238,6 +244,9 @@ class _ConnectomeModel(nn.Module):
 
     def _try_fused(self, batch, structure) -> bool:
         return False
+
+    def _prepare_reused(self, batch, structure) -> None:
+        """Hook of prepare_batch(reuse=True)."""
 
     def _agreed_fused(self, batch, structure) -> bool:
         """``_try_fused`` -- and, while training with SyncBatchNorm across ranks, the same answer
@@ -308,6 +317,18 @@ class GCNConnectome(_ConnectomeModel):
         from . import fused, gcn_half_path, gcn_wide_path
         path = {"tile": fused, "wide": gcn_wide_path, "half": gcn_half_path}[self._fused_kind]
         return path.encode(self, batch, structure)
+
+    def _prepare_reused(self, batch, structure) -> None:
+        # per-tile path on a batch that is trained on repeatedly: run it on the degree-ordered twin
+        # (less blocked-ELL padding; structure.degree_ordered_twin).  Not under cross-rank BatchNorm,
+        # where the ranks must agree on the path anyway, and not for cached subject structures.
+        from .structure import BatchStructure
+        if isinstance(structure, BatchStructure) and self._try_fused(batch, structure) \
+                and self._fused_kind == "tile" and self.impl != "layered" \
+                and not any(isinstance(bn, nn.SyncBatchNorm) for bn in self.batch_norms):
+            twin = structure.degree_ordered_twin()
+            twin.fused_meta(_TILE_ROWS, _grid(), 1.0)
+            twin.permuted_features(batch.node_features)
 
 
 class GraphSAGEConnectome(_ConnectomeModel):

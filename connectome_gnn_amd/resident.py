@@ -88,7 +88,9 @@ class ResidentDataLoader:
             order = torch.randperm(n) if self.shuffle else torch.arange(n)
         dev = self.dataset.x.device
         if dev.type == "cuda":
-            order = order.to(dev)
+            # (from pinned memory, asynchronously: a pageable upload would make the host wait for every
+            # step already queued on this stream -- one pipeline bubble per epoch)
+            order = order.pin_memory().to(dev, non_blocking=True)
         for lo in range(0, n, self.batch_size):
             hi = min(n, lo + self.batch_size)
             if self.world_size > 1:
@@ -113,7 +115,10 @@ class ResidentDataLoader:
                 for chunk in self._chunks():
                     b = assemble_batch(self.dataset, chunk)
                     if self.prepare is not None:
-                        self.prepare(b)
+                        try:
+                            self.prepare(b, reuse=True)      # kept batches: amortised structure work pays
+                        except TypeError:
+                            self.prepare(b)
                     self._cache.append(b)
             order = torch.randperm(len(self._cache)).tolist() if self.shuffle == "batches" \
                 else range(len(self._cache))

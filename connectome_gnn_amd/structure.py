@@ -111,6 +111,7 @@ class BatchStructure:
                             else torch.zeros(nn_, dtype=torch.int32, device=dev))
             f = None
             eptr = getattr(batch, "_eptr", None)
+            s.__dict__["_eptr_host"] = eptr
             if (not force_generic and eptr is not None and eptr.numel() == batch.num_graphs + 1
                     and int(eptr[-1]) == ne and batch.num_graphs > 0):
                 # COO grouped by graph: whole graphs are built in LDS by one workgroup each
@@ -141,6 +142,56 @@ class BatchStructure:
         s.block_diagonal = f[1] == 0
         s.max_in_degree, s.max_out_degree = f[2], f[3]
         return s
+
+    # -- internal node order of the fused per-tile GCN path ---------------------------------
+    def degree_ordered_twin(self) -> "BatchStructure":
+        """The same batch with every graph's nodes renumbered by decreasing degree (in + out, ties in
+        the old order), as a structure of its own; ``twin.perm`` (int64 [Nn]) maps its node ids to
+        this structure's.  The blocked-ELL pads every row to the widest row of its 16-row block:
+        19 % of the steps the tile kernels walk on 360-ROI small-world graphs in node order, 3 % in
+        degree order.  A GCN with a mean-pool readout is invariant under the renumbering, and every
+        per-node array of the fused encoder is internal to it, so the encoder can run on the twin
+        (node features gathered through ``perm`` on entry) while the batch's public arrays stay as
+        they are.  Built once per batch on request (`model.prepare_batch(batch, reuse=True)`): it
+        costs a second CSR / blocked-ELL build, which pays for batches that are trained on repeatedly."""
+        twin = self.__dict__.get("_degree_twin")
+        if twin is not None:
+            return twin
+        ei = self._edge_index
+        dev = ei.device
+        nn_ = self.num_nodes
+        one = torch.ones(ei.shape[1], dtype=torch.long, device=dev)
+        deg = torch.zeros(nn_, dtype=torch.long, device=dev).index_add_(0, ei[0], one).index_add_(0, ei[1], one)
+        gid = self.node_graph.to(torch.long)
+        # one stable sort by (graph asc, degree desc): nodes stay inside their graph's run
+        key = gid * (int(deg.max()) + 1 if nn_ else 1) + (deg.max() - deg if nn_ else deg)
+        perm = torch.argsort(key, stable=True)                     # twin id -> this id
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(nn_, device=dev)
+
+        class _Shim:                                               # what BatchStructure.build reads of a batch
+            pass
+        shim = _Shim()
+        shim.edge_index = inv[ei]                                  # same COO order: still grouped by graph
+        shim.edge_weight = self._edge_weight
+        shim.num_nodes, shim.num_graphs = nn_, self.num_graphs
+        shim.batch = gid
+        shim.ptr = self.gptr.to(torch.long)
+        shim._eptr = self.__dict__.get("_eptr_host")
+        twin = BatchStructure.build(shim)
+        twin.perm = perm
+        twin.__dict__["_is_twin"] = True
+        self.__dict__["_degree_twin"] = twin
+        return twin
+
+    def permuted_features(self, x: torch.Tensor) -> torch.Tensor:
+        """Node features in this (twin) structure's node order; cached per feature tensor version."""
+        key = (x.data_ptr(), x._version, tuple(x.shape))
+        hit = self.__dict__.get("_xperm")
+        if hit is None or hit[0] != key:
+            hit = (key, x.index_select(0, self.perm).contiguous())
+            self.__dict__["_xperm"] = hit
+        return hit[1]
 
     # -- normalisations: layer independent, recomputed once per forward pass ----------------
     def gcn_norm(self) -> GcnNorm:

@@ -378,6 +378,7 @@ def test_graphed_step_matches_eager_and_redraws_dropout(kind):
         torch.manual_seed(11)
         m = cls(5, 64, dropout=0.0).to(DEV).train()
         opt = torch.optim.Adam(m.parameters(), lr=1e-2, capturable=True)
+        m.prepare_batch(b, reuse=True)      # (what the captured step does: both runs on the same node order)
 
         def eager():
             opt.zero_grad(set_to_none=True)
@@ -604,6 +605,8 @@ def test_models_random_batches_vs_oracle(trial):
     ("gcn", 100, 10, 128, 12, "auto", "fused"),      # wide one-node GCN encoder
     ("gcn", 84, 8, 64, 8, "layered", "layered"),     # op-by-op path
     ("sage", 84, 8, 64, 8, "layered", "layered"),
+    ("gcn", 84, 8, 64, 24, "twin", "fused"),         # per-tile kernels on the degree-ordered twin
+    ("gcn", 360, 14, 64, 6, "twin", "fused"),        # (what bench.py's resident batches run: prepare_batch(reuse=True))
 ])
 def test_dropout_on_matches_oracle_with_replayed_masks(kind, n, k, hidden, nb, impl, want):
     """train() with dropout 0.3 -- the mode bench.py times.  The HIP path's own keep decisions
@@ -614,11 +617,17 @@ def test_dropout_on_matches_oracle_with_replayed_masks(kind, n, k, hidden, nb, i
     import connectome_gnn_amd as C
     b = C.collate_graphs(C.generate_dataset(nb, n, k, seed=321))
     torch.manual_seed(11)
-    m = _model(kind, 5, hidden, dropout=0.3, impl=impl)
+    twin = impl == "twin"
+    m = _model(kind, 5, hidden, dropout=0.3, impl="auto" if twin else impl)
     sd0 = {k_: v.clone() for k_, v in m.state_dict().items()}
     m = m.to(DEV).train()
     m.record_dropout = True
     bd = b.to(DEV)
+    if twin:
+        m.prepare_batch(bd, reuse=True)
+        tw = bd.structure().__dict__.get("_degree_twin")
+        assert tw is not None and not torch.equal(tw.perm, torch.arange(b.num_nodes, device=DEV))
+        assert torch.equal(torch.sort(tw.perm).values, torch.arange(b.num_nodes, device=DEV))
     lg = m(bd)
     loss_g = torch.nn.functional.cross_entropy(lg, bd.labels)
     loss_g.backward()
@@ -878,3 +887,38 @@ def test_relabel_by_degree_is_an_invariance(kind):
     torch.testing.assert_close(outs[0][1], outs[1][1], rtol=2e-5, atol=2e-6)
     for a, c in zip(outs[0][2], outs[1][2]):
         torch.testing.assert_close(a, c, rtol=1e-3, atol=1e-5 * float(a.abs().max()) + 2e-6)
+
+
+def test_degree_ordered_twin_is_the_same_model_on_ragged_batches():
+    """prepare_batch(reuse=True): the per-tile GCN encoder runs on the batch's degree-ordered twin
+    (every graph's nodes renumbered by decreasing degree inside the structure; node features gathered
+    through the permutation).  Same logits, loss and gradients as on the batch's own order up to the
+    order of the sums; less blocked-ELL padding; the public batch untouched."""
+    import connectome_gnn_amd as C
+    gs = C.generate_dataset(5, 84, 8, seed=9) + C.generate_dataset(3, 200, 12, seed=10) + C.generate_dataset(2, 33, 4, seed=11)
+    b = C.collate_graphs(gs).to(DEV)
+    ei0 = b.edge_index.clone()
+    outs = []
+    for reuse in (False, True):
+        torch.manual_seed(2)
+        m = C.GCNConnectome(5, 64, dropout=0.0).to(DEV).train()
+        if reuse:
+            m.prepare_batch(b, reuse=True)
+        lg = m(b)
+        assert m.impl_used == "fused"
+        torch.nn.functional.cross_entropy(lg, b.labels).backward()
+        outs.append((lg.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters()}))
+    s = b.structure()
+    tw = s.__dict__["_degree_twin"]
+    assert torch.equal(b.edge_index, ei0)
+    grid = 256
+    pad = lambda st: int(st.fused_meta(384, grid).blk_off_dst[-1])
+    assert pad(tw) < pad(s)                                           # fewer padded blocked-ELL entries
+    # nodes stay inside their graphs
+    assert torch.equal(s.node_graph.to(torch.long)[tw.perm], s.node_graph.to(torch.long))
+    torch.testing.assert_close(outs[1][0], outs[0][0], rtol=1e-5, atol=2e-6)
+    for k, g0 in outs[0][1].items():
+        if k.startswith("convs.") and k.endswith(".bias"):
+            continue
+        g1 = outs[1][1][k]
+        assert float((g1 - g0).abs().max()) <= 2e-5 * float(g0.abs().max()) + 2e-6, k
