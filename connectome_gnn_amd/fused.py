@@ -367,21 +367,13 @@ def encode(model, batch, structure: BatchStructure) -> torch.Tensor:
         if isinstance(bn, torch.nn.SyncBatchNorm) and model.training and dist.is_initialized() \
                 and dist.get_world_size(bn.process_group) > 1:
             sync_group = bn.process_group if bn.process_group is not None else dist.group.WORLD
-    x0 = batch.node_features
-    twin = getattr(structure, "__dict__", {}).get("_degree_twin")
-    if twin is not None:
-        # the encoder runs on the batch's degree-ordered twin (structure.degree_ordered_twin: less
-        # blocked-ELL padding); only the node features enter in the batch's own order
-        structure, x0 = twin, twin.permuted_features(x0)
+    # (on the batch's degree-ordered twin when one was prepared: less blocked-ELL padding; only the node
+    # features enter in the batch's own order)
+    from .structure import twin_view, unpermute_record
+    structure, x0, twin = twin_view(structure, batch.node_features)
     meta = {"structure": structure, "batch_norms": list(model.batch_norms),
             "training": model.training, "dropout": float(model.dropout), "sync_group": sync_group,
             "rng_state": getattr(model, "rng_device_state", None), "record": model._dropout_record()}
     out = FusedGCNEncode.apply(x0, meta, *params)
-    rec = meta.get("record")
-    if twin is not None and rec is not None and rec.get("layers") is not None:
-        # keep bytes are recorded per node of the twin: hand them out in the batch's node order
-        inv = torch.empty_like(twin.perm)
-        inv[twin.perm] = torch.arange(twin.perm.numel(), device=twin.perm.device)
-        rec["layers"] = [None if m is None else m.view(twin.num_nodes, -1).index_select(0, inv).reshape(-1)
-                         for m in rec["layers"]]
+    unpermute_record(twin, meta.get("record"))
     return out

@@ -246,7 +246,18 @@ class _ConnectomeModel(nn.Module):
         return False
 
     def _prepare_reused(self, batch, structure) -> None:
-        """Hook of prepare_batch(reuse=True)."""
+        """prepare_batch(reuse=True): the one-node encoders over LDS tiles (per-tile GCN, wide GCN,
+        GraphSAGE) run on the batch's degree-ordered twin (structure.degree_ordered_twin: 19 % -> 3 % of
+        blocked-ELL padding on small-world connectomes).  Not under cross-rank BatchNorm (the ranks
+        agree on paths there), not for cached subject structures, not for the dense fp16 operator."""
+        from .structure import BatchStructure
+        if not isinstance(structure, BatchStructure) or self.impl == "layered" or self.storage == "fp16" \
+                or any(isinstance(bn, nn.SyncBatchNorm) for bn in self.batch_norms) \
+                or not self._try_fused(batch, structure):
+            return
+        twin = structure.degree_ordered_twin()
+        twin.fused_meta(_TILE_ROWS, _grid(), 1.0 if self._relu_after_bn else 0.0)
+        twin.permuted_features(batch.node_features)
 
     def _agreed_fused(self, batch, structure) -> bool:
         """``_try_fused`` -- and, while training with SyncBatchNorm across ranks, the same answer
@@ -317,19 +328,6 @@ class GCNConnectome(_ConnectomeModel):
         from . import fused, gcn_half_path, gcn_wide_path
         path = {"tile": fused, "wide": gcn_wide_path, "half": gcn_half_path}[self._fused_kind]
         return path.encode(self, batch, structure)
-
-    def _prepare_reused(self, batch, structure) -> None:
-        # per-tile path on a batch that is trained on repeatedly: run it on the degree-ordered twin
-        # (less blocked-ELL padding; structure.degree_ordered_twin).  Not under cross-rank BatchNorm,
-        # where the ranks must agree on the path anyway, and not for cached subject structures.
-        from .structure import BatchStructure
-        if isinstance(structure, BatchStructure) and self._try_fused(batch, structure) \
-                and self._fused_kind == "tile" and self.impl != "layered" \
-                and not any(isinstance(bn, nn.SyncBatchNorm) for bn in self.batch_norms):
-            twin = structure.degree_ordered_twin()
-            twin.fused_meta(_TILE_ROWS, _grid(), 1.0)
-            twin.permuted_features(batch.node_features)
-
 
 class GraphSAGEConnectome(_ConnectomeModel):
     """conv (ReLU inside) -> BatchNorm1d -> dropout per layer -- no ReLU after BN

@@ -328,7 +328,11 @@ def encode(model, batch, structure: BatchStructure) -> torch.Tensor:
     params = []
     for conv, bn in zip(model.convs, model.batch_norms):
         params += [conv.linear.weight, conv.linear.bias, bn.weight, bn.bias]
+    from .structure import twin_view, unpermute_record
+    structure, x0, twin = twin_view(structure, batch.node_features)
     cfg = {"structure": structure, "batch_norms": list(model.batch_norms), "training": model.training,
            "dropout": float(model.dropout), "rng_state": getattr(model, "rng_device_state", None),
            "sync_group": sync_group_of(model), "record": model._dropout_record()}
-    return SageEncode.apply(batch.node_features, cfg, *params)
+    out = SageEncode.apply(x0, cfg, *params)
+    unpermute_record(twin, cfg.get("record"))
+    return out

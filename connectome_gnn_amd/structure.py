@@ -44,6 +44,27 @@ class SageNorm:
 TILED_MAX_ROWS = 384      # CGNN_FUSED_MAX_ROWS: rows of one LDS tile
 
 
+def twin_view(structure, x: torch.Tensor):
+    """(structure', x', twin): the batch's degree-ordered twin and the node features in its order when
+    one has been prepared (``BatchStructure.degree_ordered_twin`` via ``model.prepare_batch(batch,
+    reuse=True)``), else the inputs and None.  The one-node encoders call this on entry: all their
+    per-node arrays are internal, so they run on the twin unchanged."""
+    twin = getattr(structure, "__dict__", {}).get("_degree_twin")
+    if twin is None:
+        return structure, x, None
+    return twin, twin.permuted_features(x), twin
+
+
+def unpermute_record(twin, rec) -> None:
+    """Keep bytes recorded per node of the twin -> the batch's node order (parity hook)."""
+    if twin is None or rec is None or rec.get("layers") is None:
+        return
+    inv = torch.empty_like(twin.perm)
+    inv[twin.perm] = torch.arange(twin.perm.numel(), device=twin.perm.device)
+    rec["layers"] = [None if m is None else m.view(twin.num_nodes, -1).index_select(0, inv).reshape(-1)
+                     for m in rec["layers"]]
+
+
 @dataclass
 class FusedMeta:
     """Static per-batch metadata of the fused per-tile kernels (see include/cgnn.h)."""

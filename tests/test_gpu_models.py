@@ -607,6 +607,8 @@ def test_models_random_batches_vs_oracle(trial):
     ("sage", 84, 8, 64, 8, "layered", "layered"),
     ("gcn", 84, 8, 64, 24, "twin", "fused"),         # per-tile kernels on the degree-ordered twin
     ("gcn", 360, 14, 64, 6, "twin", "fused"),        # (what bench.py's resident batches run: prepare_batch(reuse=True))
+    ("sage", 360, 14, 128, 4, "twin", "fused"),      # GraphSAGE and the wide GCN encoder on the twin
+    ("gcn", 100, 10, 128, 12, "twin", "fused"),
 ])
 def test_dropout_on_matches_oracle_with_replayed_masks(kind, n, k, hidden, nb, impl, want):
     """train() with dropout 0.3 -- the mode bench.py times.  The HIP path's own keep decisions
