@@ -158,8 +158,8 @@ def end_to_end(C, ds, model, opt, bsz: int, epochs: int = 6) -> dict:
 
     def timed_epochs(ld, trainer=None, n_epochs=epochs):
         trainer = trainer or tr
-        for _ in range(2):               # (the first epochs of a loader grow the allocator's pools on its side stream)
-            trainer.train_epoch(ld)
+        for _ in range(4):               # (the first epochs of a loader grow the allocator's pools on its side
+            trainer.train_epoch(ld)       # stream: single slow epochs, 3-8 ms per step, until they have settled)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(n_epochs):
