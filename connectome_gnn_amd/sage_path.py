@@ -56,10 +56,24 @@ def _f32(dev, *shape):
     return torch.empty(*shape, dtype=torch.float32, device=dev)
 
 
+def _agg_narrow_tiled(s, ell, norm, x, out=None):
+    """The same mean for a narrow x (layer 0's few input features) through the LDS-tiled aggregate on a
+    zero-padded 64-column panel -- for structures that carry no CSR (the per-subject structure cache)."""
+    f = x.shape[1]
+    panel = torch.nn.functional.pad(x, (0, 64 * ((f + 63) // 64) - f))
+    agg = ops.aggregate_tiled_raw(s, ell, ops.AGG_POST_DIV, panel, None, norm.den, None)[:, :f]
+    if out is None:
+        return agg.contiguous()
+    out.copy_(agg)
+    return out
+
+
 def _agg_fwd(s: BatchStructure, ell, norm, x):
     """weighted mean of in-neighbours, models.py:146-149"""
     if s.tiled_ok(x.shape[1]):
         return ops.aggregate_tiled_raw(s, ell, ops.AGG_POST_DIV, x, None, norm.den, None)
+    if getattr(s, "cached_subjects", False):
+        return _agg_narrow_tiled(s, ell, norm, x)
     return ops.aggregate_raw(s.rowptr_dst, s.col_dst, norm.w_dst, None, norm.den, None, x)
 
 
@@ -212,8 +226,11 @@ class SageEncode(torch.autograd.Function):
                     # 32-wide panels so that the tall weight-stationary GEMMs apply (K = 10 would
                     # otherwise run the per-tile kernels at a few % of the matrix-core rate)
                     xa = torch.nn.functional.pad(x, (0, PAD_K - fin))        # one pass: [x0 | 0]
-                    agg = ops.aggregate_raw(s.rowptr_dst, s.col_dst, sv.norm.w_dst, None, sv.norm.den,
-                                            None, x, out=xa[:, fin:2 * fin])
+                    if getattr(s, "cached_subjects", False):
+                        agg = _agg_narrow_tiled(s, sv.ell, sv.norm, x, out=xa[:, fin:2 * fin])
+                    else:
+                        agg = ops.aggregate_raw(s.rowptr_dst, s.col_dst, sv.norm.w_dst, None, sv.norm.den,
+                                                None, x, out=xa[:, fin:2 * fin])
                     wp = torch.nn.functional.pad(w, (0, PAD_K - 2 * fin))
                     sv.xa0 = xa
                     gemm_in = (xa, None, wp)

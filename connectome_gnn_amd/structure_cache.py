@@ -25,8 +25,9 @@ under the cache every graph gets a tile of its own.  The tile kernels then walk 
 issuing ~45 launches per step from Python, which is what a freshly shuffled batch costs otherwise
 (`Trainer(graph=True)` replays ONE captured step per batch size over such a loader).
 
-Scope: the per-tile fused GCN path (hidden 64) on regular datasets (<= 384 nodes per graph); anything
-else keeps the ordinary per-batch build.
+Scope: the per-tile fused GCN path (hidden 64) and the GraphSAGE encoder (sage_path.py; its own ELL
+family without self-loops and `den` per subject, built on first use) on regular datasets (<= 384 nodes
+per graph); anything else keeps the ordinary per-batch build.
 """
 from __future__ import annotations
 
@@ -42,34 +43,55 @@ from .synthetic import PackedDataset
 MAX_ROWS = 384
 
 
+KINDS = {"gcn": 1.0, "sage": 0.0}        # family -> weight of the ELL's self-loop entry (models.py:97-100 / :146)
+
+
+class _Family:
+    """One model family's per-subject arrays: blocked-ELL entries of both orderings, each subject's
+    block-offset rows (absolute offsets into the entry arrays) and its per-node normaliser (GCN:
+    `dis`, models.py:97-105; GraphSAGE: `den` = in-weight sum + 1e-8, models.py:146-149)."""
+    __slots__ = ("ent_dst", "ent_src", "blk_off_dst", "blk_off_src", "norm")
+
+
 class SubjectStructureCache:
-    """Blocked-ELL entries (both orderings), block offsets and `dis` of every subject of a dataset."""
+    """Blocked-ELL entries (both orderings), block offsets and the per-node normaliser of every subject
+    of a dataset, per model family (GCN: self-loop entry + `dis`; GraphSAGE: no self-loop + `den`).  The
+    GCN family is built with the cache, the GraphSAGE one on first use."""
 
     def __init__(self, ds: PackedDataset, chunk: int = 2048):
-        from .resident import assemble_batch
-        lib = _lib.load()
         n = int(ds.x.shape[1])
         if not (0 < n <= MAX_ROWS):
             raise ValueError(f"structure cache: a graph must fit one LDS tile (<= {MAX_ROWS} nodes), got {n}")
-        dev = ds.x.device
-        self.dataset, self.n = ds, n
+        self.dataset, self.n, self._chunk = ds, n, chunk
         self.nb = (n + 15) // 16                                     # 16-row blocks per graph
+        self._fam = {}
+        self._static = {}
+        self.family("gcn")
+
+    def family(self, kind: str) -> _Family:
+        if kind in self._fam:
+            return self._fam[kind]
+        from .resident import assemble_batch
+        lib = _lib.load()
+        ds, n = self.dataset, self.n
+        dev = ds.x.device
         S = ds.num_subjects
         grid = int(lib.cgnn_fused_grid())
         ents = {"dst": [], "src": []}
         offs = {"dst": [], "src": []}
-        dis = []
+        norm = []
         base = {"dst": 0, "src": 0}
-        for lo in range(0, S, chunk):
-            ids = torch.arange(lo, min(S, lo + chunk), device=dev)
+        for lo in range(0, S, self._chunk):
+            ids = torch.arange(lo, min(S, lo + self._chunk), device=dev)
             b = assemble_batch(ds, ids)
             s = b.structure()
             if not s.block_diagonal:
                 raise ValueError("structure cache: a subject has edges outside its graph")
-            m = s.fused_meta(n, grid)                   # row cap = one graph: a tile per subject
+            m = s.fused_meta(n, grid, KINDS[kind])      # row cap = one graph: a tile per subject
             if int(m.tile_ptr.numel()) - 1 != ids.numel():
                 raise ValueError("structure cache: tiles are not one graph each")
-            dis.append(s.gcn_dis(m).view(ids.numel(), n))
+            per_node = s.gcn_dis(m) if kind == "gcn" else s.sage_norm(backward_coef=False).den
+            norm.append(per_node.view(ids.numel(), n).clone())
             for name, blk_off, ent in (("dst", m.blk_off_dst, m.ent_dst), ("src", m.blk_off_src, m.ent_src)):
                 used = int(blk_off[-1])                               # entries (8 bytes each)
                 ents[name].append(ent[:used * 8].clone())
@@ -82,16 +104,25 @@ class SubjectStructureCache:
         for name in ("dst", "src"):
             if base[name] > 2 ** 31 - 17:
                 raise ValueError("structure cache exceeds 2^31 entries; cache a smaller dataset")
-        self.ent_dst, self.ent_src = torch.cat(ents["dst"]), torch.cat(ents["src"])
-        self.blk_off_dst = torch.cat(offs["dst"]).to(torch.int32).contiguous()     # [S, nb + 1]
-        self.blk_off_src = torch.cat(offs["src"]).to(torch.int32).contiguous()
-        self.dis = torch.cat(dis).contiguous()                                     # [S, n]
-        self._static = {}
+        f = _Family()
+        f.ent_dst, f.ent_src = torch.cat(ents["dst"]), torch.cat(ents["src"])
+        f.blk_off_dst = torch.cat(offs["dst"]).to(torch.int32).contiguous()     # [S, nb + 1]
+        f.blk_off_src = torch.cat(offs["src"]).to(torch.int32).contiguous()
+        f.norm = torch.cat(norm).contiguous()                                  # [S, n]
+        self._fam[kind] = f
+        return f
+
+    # the GCN family under its historical names
+    ent_dst = property(lambda self: self.family("gcn").ent_dst)
+    ent_src = property(lambda self: self.family("gcn").ent_src)
+    blk_off_dst = property(lambda self: self.family("gcn").blk_off_dst)
+    blk_off_src = property(lambda self: self.family("gcn").blk_off_src)
+    dis = property(lambda self: self.family("gcn").norm)
 
     def static(self, b: int):
         """Arrays that depend on the batch size only."""
         if b not in self._static:
-            dev = self.dis.device
+            dev = self.dataset.x.device
             tile_ptr = (torch.arange(b + 1, device=dev, dtype=torch.int32) * self.n).contiguous()
             tile_blk = (torch.arange(b + 1, device=dev, dtype=torch.int32) * (self.nb + 1)).contiguous()
             node_graph = torch.arange(b, device=dev, dtype=torch.int32).repeat_interleave(self.n).contiguous()
@@ -100,58 +131,59 @@ class SubjectStructureCache:
 
 
 class CachedStructure:
-    """What the fused per-tile GCN encoder asks of a batch structure, assembled from the cache.  The
-    three gathers run on first use: a batch that `Trainer(graph=True)` only takes the subject ids
-    from (the captured step assembles its own) costs no launch at all."""
+    """What the one-node encoders over LDS tiles (per-tile GCN; GraphSAGE) ask of a batch structure,
+    assembled from the cache.  `family(kind)` -- (block offsets dst, src, per-node normaliser) of the
+    batch -- comes from the batch's own single assembly launch when its owner provides one
+    (ResidentBatch), else from three gathers."""
+    cached_subjects = True
 
     def __init__(self, cache: SubjectStructureCache, ids, b: int, assembled=None):
         """ids: the subject ids on the cache's device, or a callable that returns them.
-        assembled: callable returning (blk_off_dst, blk_off_src, dis) of the batch when its owner
-        gathers them together with the node features (ResidentBatch: one launch for all five)."""
+        assembled(kind): callable returning (blk_off_dst, blk_off_src, norm) of the batch."""
         self.cache, self._ids_src, self._assembled = cache, ids, assembled
         self.num_graphs, self.num_nodes = b, b * cache.n
         self.max_nodes_per_graph = cache.n
         self.block_diagonal = True
         tile_ptr, tile_blk, node_graph = cache.static(b)
         self.gptr, self.node_graph = tile_ptr, node_graph
-        self._meta_ = self._dis_ = None
+        self._metas = {}
 
     @property
     def _ids(self) -> torch.Tensor:
         return self._ids_src() if callable(self._ids_src) else self._ids_src
 
-    @property
-    def _meta(self) -> FusedMeta:
-        if self._meta_ is None:
+    def _family(self, kind: str):
+        """(FusedMeta, per-node normaliser) of this batch for one model family."""
+        if kind not in self._metas:
             cache, b = self.cache, self.num_graphs
+            fam = cache.family(kind)
             tile_ptr, tile_blk, _ = cache.static(b)
             if self._assembled is not None:
-                od, os_, self._dis_ = self._assembled()
+                od, os_, norm = self._assembled(kind)
             else:
-                od = cache.blk_off_dst.index_select(0, self._ids).view(-1)
-                os_ = cache.blk_off_src.index_select(0, self._ids).view(-1)
-            self._meta_ = FusedMeta(tile_ptr, tile_blk, cache.n, b * (cache.nb + 1), od, cache.ent_dst,
-                                    os_, cache.ent_src, None)
-        return self._meta_
+                od = fam.blk_off_dst.index_select(0, self._ids).view(-1)
+                os_ = fam.blk_off_src.index_select(0, self._ids).view(-1)
+                norm = fam.norm.index_select(0, self._ids).view(-1)
+            meta = FusedMeta(tile_ptr, tile_blk, cache.n, b * (cache.nb + 1), od, fam.ent_dst, os_, fam.ent_src, None)
+            self._metas[kind] = (meta, norm)
+        return self._metas[kind]
 
-    @property
-    def _dis(self) -> torch.Tensor:
-        if self._dis_ is None:
-            if self._assembled is not None:
-                self._dis_ = self._assembled()[2]
-            else:
-                self._dis_ = self.cache.dis.index_select(0, self._ids).view(-1)
-        return self._dis_
-
-    # -- the interface fused.py / models.py use
+    # -- the interface fused.py / sage_path.py / models.py use
     def fused_meta(self, max_rows: int, num_workgroups: int, self_weight: float = 1.0) -> FusedMeta:
-        if max_rows != MAX_ROWS or self_weight != 1.0:
-            raise ValueError("cached structure serves the GCN tile path only")
-        return self._meta
+        kind = {v: k for k, v in KINDS.items()}.get(float(self_weight))
+        if max_rows != MAX_ROWS or kind is None:
+            raise ValueError("cached structure: tiles of 384 rows, GCN (self-loop 1) or GraphSAGE (none) metadata")
+        return self._family(kind)[0]
 
     def gcn_dis(self, meta: FusedMeta) -> torch.Tensor:
         """Per-subject `dis`, gathered (a function of the subject's edge weights only)."""
-        return self._dis
+        return self._family("gcn")[1]
+
+    def sage_norm(self, backward_coef: bool = True):
+        """Per-subject `den`, gathered; the per-edge arrays of the gather-form kernels do not exist here
+        (the tiled aggregate divides by `den` itself)."""
+        from .structure import SageNorm
+        return SageNorm(self._family("sage")[1], None, None)
 
     def tiles_struct(self, meta: FusedMeta, dis: Optional[torch.Tensor] = None):
         t = _lib.CgnnTiles()
@@ -165,11 +197,11 @@ class CachedStructure:
         return t
 
     def tiled_ok(self, width: int) -> bool:
-        return False
+        return width % 64 == 0 and self.num_nodes > 0
 
     def __getattr__(self, name):
-        raise AttributeError(f"CachedStructure has no '{name}': it serves the per-tile fused GCN encoder only "
-                             "(use a loader without structure_cache for other models)")
+        raise AttributeError(f"CachedStructure has no '{name}': it serves the per-tile fused GCN encoder and the "
+                             "GraphSAGE encoder only (no CSR: use a loader without structure_cache for other paths)")
 
 
 class ResidentBatch(ConnectomeBatch):
@@ -187,7 +219,7 @@ class ResidentBatch(ConnectomeBatch):
         self._b = int(ids.numel())
         self._lazy = {}
         self._coo = None
-        self._structure = CachedStructure(cache, lambda: self._ids, self._b, assembled=lambda: self._assemble()[2:])
+        self._structure = CachedStructure(cache, lambda: self._ids, self._b, assembled=self._assembled_family)
         self._structure_key = None
         self._eptr = None
 
@@ -197,28 +229,55 @@ class ResidentBatch(ConnectomeBatch):
         return self._lazy[name]
 
     def _assemble(self):
-        """Node features, labels, both block-offset rows and `dis` of the batch's subjects in ONE
-        launch (cgnn_gather_rows) -- on first access of any of them."""
+        """Node features and labels of the batch's subjects -- and the block-offset rows and per-node
+        normaliser of every model family the cache has built -- in ONE launch (cgnn_gather_rows), on
+        first access of any of them.  -> (x, labels, {kind: (blk_off_dst, blk_off_src, norm)})"""
         if "asm" not in self._lazy:
             cache, ds, b = self._cache, self._cache.dataset, self._b
             dev = ds.x.device
             x = torch.empty(b * cache.n, ds.x.shape[2], dtype=ds.x.dtype, device=dev)
             y = torch.empty(b, dtype=ds.labels.dtype, device=dev)
-            od = torch.empty(b * (cache.nb + 1), dtype=torch.int32, device=dev)
-            os_ = torch.empty(b * (cache.nb + 1), dtype=torch.int32, device=dev)
-            dis = torch.empty(b * cache.n, dtype=torch.float32, device=dev)
+            pairs = [(ds.x, x), (ds.labels, y)]
+            fams = {}
+            for kind in list(cache._fam):
+                fams[kind] = self._family_buffers(kind, pairs)
+            self._gather(pairs)
+            self._lazy["asm"] = (x, y, fams)
+        return self._lazy["asm"]
+
+    def _family_buffers(self, kind, pairs):
+        cache, b = self._cache, self._b
+        dev = cache.dataset.x.device
+        fam = cache.family(kind)
+        od = torch.empty(b * (cache.nb + 1), dtype=torch.int32, device=dev)
+        os_ = torch.empty(b * (cache.nb + 1), dtype=torch.int32, device=dev)
+        norm = torch.empty(b * cache.n, dtype=torch.float32, device=dev)
+        pairs += [(fam.blk_off_dst, od), (fam.blk_off_src, os_), (fam.norm, norm)]
+        return od, os_, norm
+
+    def _gather(self, pairs):
+        dev = self._cache.dataset.x.device
+        for lo in range(0, len(pairs), _lib.GATHER_MAX_JOBS):
             jobs = _lib.CgnnGatherJobs()
-            pairs = ((ds.x, x), (ds.labels, y), (cache.blk_off_dst, od), (cache.blk_off_src, os_), (cache.dis, dis))
-            jobs.n = len(pairs)
-            for i, (src, dst) in enumerate(pairs):
+            chunk = pairs[lo:lo + _lib.GATHER_MAX_JOBS]
+            jobs.n = len(chunk)
+            for i, (src, dst) in enumerate(chunk):
                 assert src.is_contiguous()
                 jobs.src[i], jobs.dst[i] = src.data_ptr(), dst.data_ptr()
                 jobs.row_bytes[i] = src[0].numel() * src.element_size()
             with _lib.device_guard(dev):
-                _lib.check(_lib.load().cgnn_gather_rows(jobs, _lib.ptr(self._ids), b, _lib.ptr(self._ids_offset),
+                _lib.check(_lib.load().cgnn_gather_rows(jobs, _lib.ptr(self._ids), self._b, _lib.ptr(self._ids_offset),
                                                         _lib.stream_ptr(dev)), "cgnn_gather_rows")
-            self._lazy["asm"] = (x, y, od, os_, dis)
-        return self._lazy["asm"]
+
+    def _assembled_family(self, kind):
+        """A family's (blk_off_dst, blk_off_src, norm) of this batch; a family the cache builds only now
+        (first GraphSAGE batch on a cache that served GCN so far) gets a launch of its own."""
+        fams = self._assemble()[2]
+        if kind not in fams:
+            pairs = []
+            fams[kind] = self._family_buffers(kind, pairs)
+            self._gather(pairs)
+        return fams[kind]
 
     _ids = property(lambda self: self._get("ids", lambda: self._ids_src.to(device=self._cache.dataset.x.device, dtype=torch.long).contiguous()))
     node_features = property(lambda self: self._assemble()[0])

@@ -112,9 +112,9 @@ def test_subject_structure_cache_equals_per_batch_build():
     ref = assemble_batch(ds, batches[0]._ids)
     assert batches[0]._coo is None
     assert torch.equal(batches[0].edge_index, ref.edge_index) and torch.equal(batches[0].batch, ref.batch)
-    # other models are refused loudly, not served a wrong structure
+    # paths the cache has no arrays for (it carries no CSR) are refused loudly, not served a wrong structure
     with pytest.raises((AttributeError, ValueError, RuntimeError)):
-        C.GraphSAGEConnectome(5, 64).to("cuda")(batches[1])
+        C.GCNConnectome(5, 128).to("cuda")(batches[1])
     with pytest.raises(ValueError):       # a graph must fit one LDS tile
         ResidentDataLoader(generate_packed(2, 400, 8, seed=1).to("cuda"), batch_size=2, structure_cache=True)
 
@@ -158,6 +158,39 @@ def test_subject_structure_cache_small_graphs_get_a_tile_each(n, k):
             assert float((a - c).abs().max()) <= 2e-5 * scale + 2e-6, nm
 
 
+@pytest.mark.parametrize("n,k,hidden", [(360, 14, 128), (84, 8, 64)])
+def test_subject_structure_cache_serves_graphsage(n, k, hidden):
+    """The cache's GraphSAGE family (blocked-ELL without self-loops, `den` per subject; built on first
+    use) and the layer-0 mean through the tiled aggregate on a padded panel (the cache carries no
+    CSR): the same training steps as through assemble_batch + the per-batch builders."""
+    import connectome_gnn_amd as C
+    from connectome_gnn_amd.resident import ResidentDataLoader, assemble_batch
+    from connectome_gnn_amd.synthetic import generate_packed
+    ds = generate_packed(24, n, k, seed=7).to("cuda")
+    torch.manual_seed(3)
+    batches = list(ResidentDataLoader(ds, batch_size=8, shuffle=True, structure_cache=True))
+    outs = []
+    for use_cache in (True, False):
+        torch.manual_seed(0)
+        m = C.GraphSAGEConnectome(5, hidden, dropout=0.0).to("cuda").train()
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+        res = []
+        for rb in batches:
+            b = rb if use_cache else assemble_batch(ds, rb._ids)
+            opt.zero_grad()
+            lg = m(b)
+            assert m.impl_used == "fused"
+            torch.nn.functional.cross_entropy(lg, b.labels).backward()
+            res.append((lg.detach().clone(), [p.grad.detach().clone() for p in m.parameters()]))
+            opt.step()
+        outs.append(res)
+    assert set(batches[0]._cache._fam) == {"gcn", "sage"}
+    for (la, ga), (lb, gb) in zip(*outs):
+        torch.testing.assert_close(la, lb, rtol=2e-5, atol=5e-6)
+        for a, c in zip(ga, gb):
+            assert float((a - c).abs().max()) <= 5e-5 * float(c.abs().max()) + 5e-6
+
+
 def test_trainer_graph_mode_replays_fresh_shuffled_resident_batches():
     """Trainer(graph=True) over a ResidentDataLoader(shuffle=True, structure_cache=True): every epoch
     re-draws the batch compositions (the reference's loader semantics, graph.py:190-197), yet all
@@ -170,16 +203,18 @@ def test_trainer_graph_mode_replays_fresh_shuffled_resident_batches():
     _trainer_replay_equals_eager(generate_packed(40, 360, 14, seed=4).to("cuda"))
     # 84-ROI graphs (BASELINE config 2): one tile per graph under the cache, same replay
     _trainer_replay_equals_eager(generate_packed(40, 84, 8, seed=4).to("cuda"), masks=False)
+    # GraphSAGE over the same kind of loader (the cache's second family)
+    _trainer_replay_equals_eager(generate_packed(40, 84, 8, seed=4).to("cuda"), masks=False, cls="sage")
 
 
-def _trainer_replay_equals_eager(ds, masks=True):
+def _trainer_replay_equals_eager(ds, masks=True, cls="gcn"):
     import connectome_gnn_amd as C
     from connectome_gnn_amd.graphed import GraphedResidentStep
     from connectome_gnn_amd.resident import ResidentDataLoader
     hist, finals = {}, {}
     for mode in ("eager", "graph"):
         torch.manual_seed(0)
-        m = C.GCNConnectome(5, 64, dropout=0.0)
+        m = (C.GCNConnectome if cls == "gcn" else C.GraphSAGEConnectome)(5, 64, dropout=0.0)
         opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-4, capturable=True)   # the same update both ways
         tr = C.Trainer(m, opt, device="cuda", graph=(mode == "graph"))
         ld = ResidentDataLoader(ds, batch_size=16, shuffle=True, structure_cache=True, prefetch=True,
