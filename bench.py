@@ -158,12 +158,29 @@ def end_to_end(C, ds, model, opt, bsz: int, epochs: int = 6) -> dict:
 
     def timed_epochs(ld, trainer=None, n_epochs=epochs):
         trainer = trainer or tr
-        for _ in range(4):               # (the first epochs of a loader grow the allocator's pools on its side
-            trainer.train_epoch(ld)       # stream: single slow epochs, 3-8 ms per step, until they have settled)
+        # untimed epochs until the loader's allocation pattern has settled (its side stream grows the
+        # caching allocator's pools over the first epochs: single epochs of 3-8 ms per step): stop when an
+        # epoch is within 10 % of the fastest so far, after at least 3 and at most 12
+        best = float("inf")
+        for ep in range(12):
+            torch.cuda.synchronize()
+            t_ep = time.perf_counter()
+            trainer.train_epoch(ld)
+            torch.cuda.synchronize()
+            t_ep = time.perf_counter() - t_ep
+            if os.environ.get("CGNN_BENCH_DEBUG"):
+                print(f"[bench] warm-up epoch {ep}: {t_ep * 1e3 / max(len(ld), 1):.3f} ms/step", file=sys.stderr, flush=True)
+            if ep >= 2 and t_ep <= 1.1 * best:
+                break
+            best = min(best, t_ep)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(n_epochs):
+            t_ep = time.perf_counter()
             trainer.train_epoch(ld)
+            if os.environ.get("CGNN_BENCH_DEBUG"):
+                torch.cuda.synchronize()
+                print(f"[bench] timed epoch: {(time.perf_counter() - t_ep) * 1e3 / max(len(ld), 1):.3f} ms/step", file=sys.stderr, flush=True)
         torch.cuda.synchronize()
         return time.perf_counter() - t0
 

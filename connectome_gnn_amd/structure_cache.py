@@ -31,6 +31,7 @@ per graph); anything else keeps the ordinary per-batch build.
 """
 from __future__ import annotations
 
+import weakref
 from typing import Optional
 
 import torch
@@ -219,7 +220,12 @@ class ResidentBatch(ConnectomeBatch):
         self._b = int(ids.numel())
         self._lazy = {}
         self._coo = None
-        self._structure = CachedStructure(cache, lambda: self._ids, self._b, assembled=self._assembled_family)
+        # (the structure reaches back to its batch through a WEAK reference: a strong one would make every
+        # batch a reference cycle that only the cyclic collector frees -- tens of MB of device tensors per
+        # batch piling up until a generation-2 collection stalls the loop for ~100 ms)
+        me = weakref.ref(self)
+        self._structure = CachedStructure(cache, lambda: me()._ids, self._b,
+                                          assembled=lambda kind: me()._assembled_family(kind))
         self._structure_key = None
         self._eptr = None
 
