@@ -521,15 +521,11 @@ __global__ void __launch_bounds__(PF_NTHR) k_gcn_fwd_pf(
     const int n = t.tile_ptr[tid + 1] - base;
     const int nblk = (n + 15) >> 4;
     const int gb0 = t.tile_blk[tid];
-    // phase B takes its blocks in SNAKE order (round u odd: from the other end): with a graph's nodes
-    // in degree order (structure.degree_ordered_twin) block widths fall from the first block to the
-    // last, and wave w's blocks w, w + 12 would make wave 0 the widest in both rounds (37 steps against a
-    // mean of 30 on 360-ROI small-world graphs); w and 23 - w add up to the same for every wave
     int boff[BPW], bwid[BPW];
 #pragma unroll
     for (int k = 0; k < BPW; ++k) {
       boff[k] = bwid[k] = 0;
-      const int bb = PF_NW * k + ((k & 1) ? PF_NW - 1 - cgnn_uniform(wave) : cgnn_uniform(wave));
+      const int bb = cgnn_uniform(wave) + PF_NW * k;
       if (bb < nblk) {
         boff[k] = t.blk_off_dst[gb0 + bb];
         bwid[k] = (t.blk_off_dst[gb0 + bb + 1] - boff[k]) >> 4;
@@ -599,14 +595,11 @@ __global__ void __launch_bounds__(PF_NTHR) k_gcn_fwd_pf(
     // ------------------------------------------------ phase B: aggregate, bias, store, statistics
 #pragma unroll
     for (int u = 0; u < BPW; ++u) {
-      const int b = PF_NW * u + ((u & 1) ? PF_NW - 1 - wave : wave);
-      if (b >= nblk) continue;                     // (wave-uniform)
+      const int b = wave + PF_NW * u;
+      if (b >= nblk) break;
       float4 ag[4];
       agg_block<CGNN_PF_G, true>(tile, pre, ent + (boff[u] >> 1), bwid[u], q, j, ag);
-      if (u + 1 < BPW) {
-        const int bn = PF_NW * (u + 1) + (((u + 1) & 1) ? PF_NW - 1 - wave : wave);
-        if (bn < nblk) pre = meta_issue<true>(ent + (boff[u + 1 < BPW ? u + 1 : u] >> 1), bwid[u + 1 < BPW ? u + 1 : u], q, j);
-      }
+      if (u + 1 < BPW && b + PF_NW < nblk) pre = meta_issue<true>(ent + (boff[u + 1 < BPW ? u + 1 : u] >> 1), bwid[u + 1 < BPW ? u + 1 : u], q, j);
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int row = 16 * b + 4 * q + it;
