@@ -274,7 +274,16 @@ __global__ void k_gcn_deg(const float* __restrict__ w, const int32_t* __restrict
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nn) return;
   float deg = 0.f;
-  for (int s = rowptr_src[i]; s < rowptr_src[i + 1]; ++s) deg += w[eid_src[s]];
+  int s = rowptr_src[i];
+  const int e = rowptr_src[i + 1];
+  for (; s + 8 <= e; s += 8) {                  // eight gathers in flight, the sum still in COO order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = w[eid_src[s + u]];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) deg += v[u];
+  }
+  for (; s < e; ++s) deg += w[eid_src[s]];
   deg += 1.0f;                                  // self-loop appended last (models.py:97-100)
   float d = 1.0f / sqrtf(deg + 1e-8f);          // pow(-0.5) == rsqrt on the CPU path
   dis[i] = d;

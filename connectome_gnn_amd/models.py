@@ -69,8 +69,9 @@ class GCNLayer(nn.Module):
         if norm is None:
             norm = structure.gcn_norm()
         s = structure
-        fwd = (s.rowptr_dst, s.col_dst, norm.coef_dst, norm.selfc, None)
-        bwd = (s.rowptr_src, s.col_src, norm.coef_src)
+        bf, bb = s.band_ops("gcn", norm) if hasattr(s, "band_ops") else (None, None)
+        fwd = (s.rowptr_dst, s.col_dst, norm.coef_dst, norm.selfc, None, bf)
+        bwd = (s.rowptr_src, s.col_src, norm.coef_src, bb)
         w = self.linear.weight
         if w.shape[1] < w.shape[0]:
             # A_hat (X W^T) == (A_hat X) W^T: aggregate at the narrower width first
@@ -104,8 +105,9 @@ class SAGELayer(nn.Module):
             meta = s.fused_meta(_TILE_ROWS, _grid(), 0.0)
             agg = ops.aggregate_tiled(x, None, s, meta, post=norm.den, post_div=True)
         else:
-            agg = ops.aggregate(x, None, (s.rowptr_dst, s.col_dst, norm.w_dst, None, norm.den),
-                                (s.rowptr_src, s.col_src, norm.coef_src_bwd))
+            bf, bb = s.band_ops("sage", norm) if hasattr(s, "band_ops") else (None, None)
+            agg = ops.aggregate(x, None, (s.rowptr_dst, s.col_dst, norm.w_dst, None, norm.den, bf),
+                                (s.rowptr_src, s.col_src, norm.coef_src_bwd, bb))
         # the [x || agg] concat is never materialised: two K-panels of one GEMM, ReLU epilogue
         return ops.linear(x, agg, self.linear.weight, self.linear.bias, relu=True)
 

@@ -30,8 +30,88 @@ def _scratch(nbytes: int, device) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------ raw launchers
-def aggregate_raw(rowptr, col, coef, selfc, rowdiv, bias, x, out=None) -> torch.Tensor:
-    """out: optional [n, f] destination (may be a column slice of a wider row-major buffer)."""
+class BandOp:
+    """The dense 32 x 16 fragments of one aggregation operator as pre-split MFMA operands
+    (cgnn_band_pack_f32) plus the CSR of the edges outside them: together the operator.  Static per
+    batch, like the CSR it is built from."""
+    __slots__ = ("bfrag", "bstep", "boff", "pitch", "rowptr", "col", "coef", "num_items", "covered")
+
+
+BAND_MIN_NNZ = 64          # a fragment goes to the matrix cores when it holds more non-zeros than this
+BAND_MIN_COVER = 0.5       # ... and the band form is used when such fragments hold at least this share of the edges
+
+
+def band_operator_f32(structure, rowptr, col, coef) -> Optional[BandOp]:
+    """BandOp of the CSR ordering (rowptr, col, coef) of ``structure`` -- or None when the graphs are
+    small enough for the LDS-tiled aggregate, too large for the fragment builder, or not dense enough."""
+    s = structure
+    if not s.block_diagonal or s.max_nodes_per_graph <= 384 or s.max_nodes_per_graph > 1024 or s.num_edges == 0:
+        return None
+    lib = _lib.load()
+    dev = coef.device
+    pitch = (s.max_nodes_per_graph + 63) // 64 * 64
+    steps, nrb = pitch // 16, pitch // 32
+    nrows = s.num_graphs * nrb
+    counts = torch.empty(nrows * steps, dtype=torch.int32, device=dev)
+    with _lib.device_guard(dev):
+        _lib.check(lib.cgnn_dense_pack_count(_lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(coef), None, _lib.ptr(s.gptr),
+                                             s.num_graphs, pitch, _lib.ptr(counts), _lib.stream_ptr()),
+                   "cgnn_dense_pack_count")
+        cnt = counts.view(nrows, steps).to(torch.int64)
+        is_d = cnt > BAND_MIN_NNZ
+        covered = float((cnt * is_d).sum()) / max(float(cnt.sum()), 1.0)      # host sync: collate-time
+        if covered < BAND_MIN_COVER:
+            return None
+        boff = torch.zeros(nrows + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(is_d.sum(1), 0, out=boff[1:])
+        items = int(boff[-1])
+        rank = torch.cumsum(is_d, 1) - is_d.to(torch.int64) + boff[:-1, None]
+        fpos = torch.where(is_d, rank, torch.full_like(cnt, 0xFFFFFFFF))
+        fpos32 = torch.where(fpos >= 2 ** 31, fpos - 2 ** 32, fpos).to(torch.int32).contiguous()
+        op = BandOp()
+        op.bfrag = torch.empty(max(items, 1) * 3 * 64 * 4, dtype=torch.int32, device=dev)     # 3 KB per fragment
+        op.bstep = torch.zeros(max(items, 1), dtype=torch.int32, device=dev)
+        _lib.check(lib.cgnn_band_pack_f32(_lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(coef), _lib.ptr(s.gptr), s.num_graphs,
+                                          pitch, _lib.ptr(fpos32), _lib.ptr(op.bfrag), _lib.ptr(op.bstep),
+                                          _lib.stream_ptr()), "cgnn_band_pack_f32")
+        # the CSR of the edges outside the listed fragments (COO order inside a row is kept)
+        nn_ = s.num_nodes
+        deg = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
+        rows = torch.repeat_interleave(torch.arange(nn_, device=dev), deg)
+        g = s.node_graph.to(torch.int64)[rows]
+        gbase = s.gptr.to(torch.int64)[g]
+        frag = (g * nrb + (rows - gbase) // 32) * steps + (col.to(torch.int64) - gbase) // 16
+        keep = ~is_d.reshape(-1)[frag]
+        op.col, op.coef = col[keep].contiguous(), coef[keep].contiguous()
+        rp = torch.zeros(nn_ + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(torch.bincount(rows[keep], minlength=nn_), 0, out=rp[1:])
+        op.rowptr = rp.to(torch.int32)
+        torch.cuda.current_stream(dev).synchronize()        # fpos32 is a temporary of this call
+    op.boff, op.pitch, op.num_items, op.covered = boff.to(torch.int32), pitch, items, covered
+    return op
+
+
+def band_aggregate_add_raw(structure, band: BandOp, x, rowdiv, y) -> None:
+    """y += (dense fragments of the operator) x (/ rowdiv), cgnn_band_aggregate_f32."""
+    lib = _lib.load()
+    n, f = x.shape
+    with _lib.device_guard(x.device), _lib.timed("cgnn_band_aggregate_f32", f"F={f}"):
+        _lib.check(lib.cgnn_band_aggregate_f32(
+            _lib.ptr(band.bfrag), _lib.ptr(band.bstep), _lib.ptr(band.boff), band.pitch, _lib.ptr(structure.gptr),
+            structure.num_graphs, _lib.ptr(x), x.stride(0), f, _lib.ptr(rowdiv), _lib.ptr(y), y.stride(0),
+            _lib.stream_ptr()), "cgnn_band_aggregate_f32")
+
+
+def aggregate_raw(rowptr, col, coef, selfc, rowdiv, bias, x, out=None, band=None) -> torch.Tensor:
+    """out: optional [n, f] destination (may be a column slice of a wider row-major buffer).
+    band = (structure, BandOp): the operator's dense fragments go to the matrix cores
+    (band_aggregate.hip) and only the remaining edges through the gather kernel."""
+    if band is not None and x.shape[1] % 32 == 0 and x.stride(0) % 2 == 0 and x.data_ptr() % 8 == 0 and (
+            out is None or (out.stride(0) % 2 == 0 and out.data_ptr() % 8 == 0)):
+        st, op = band
+        y = aggregate_raw(op.rowptr, op.col, op.coef, selfc, rowdiv, bias, x, out)
+        band_aggregate_add_raw(st, op, x, rowdiv, y)
+        return y
     lib = _lib.load()
     n, f = x.shape
     y = torch.empty_like(x) if out is None else out
@@ -98,10 +178,10 @@ class _Aggregate(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, bias, fwd, bwd):
-        rowptr, col, coef, selfc, rowdiv = fwd
+        rowptr, col, coef, selfc, rowdiv = fwd[:5]
         x = _prep(x, "x")
         bias_c = _prep(bias, "bias")
-        y = aggregate_raw(rowptr, col, coef, selfc, rowdiv, bias_c, x)
+        y = aggregate_raw(rowptr, col, coef, selfc, rowdiv, bias_c, x, band=fwd[5] if len(fwd) > 5 else None)
         ctx.bwd = bwd
         ctx.selfc = selfc
         ctx.has_bias = bias is not None
@@ -110,10 +190,11 @@ class _Aggregate(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         dy = _prep(dy, "grad")
-        t_rowptr, t_col, t_coef = ctx.bwd
+        t_rowptr, t_col, t_coef = ctx.bwd[:3]
         dx = db = None
         if ctx.needs_input_grad[0]:
-            dx = aggregate_raw(t_rowptr, t_col, t_coef, ctx.selfc, None, None, dy)
+            dx = aggregate_raw(t_rowptr, t_col, t_coef, ctx.selfc, None, None, dy,
+                               band=ctx.bwd[3] if len(ctx.bwd) > 3 else None)
         if ctx.has_bias and ctx.needs_input_grad[1]:
             db = colsum_raw(dy)
         return dx, db, None, None
@@ -408,8 +489,9 @@ def aggregate_tiled(x, bias, structure, meta, pre=None, post=None, pre_div=False
 
 
 def aggregate(x, bias, fwd, bwd) -> torch.Tensor:
-    """fwd = (rowptr, col, coef, selfc|None, rowdiv|None) on the dst-sorted CSR;
-    bwd = (rowptr, col, coef) on the src-sorted CSR (coef already divided by rowdiv)."""
+    """fwd = (rowptr, col, coef, selfc|None, rowdiv|None [, band]) on the dst-sorted CSR;
+    bwd = (rowptr, col, coef [, band]) on the src-sorted CSR (coef already divided by rowdiv);
+    band = (structure, BandOp) or None (aggregate_raw)."""
     return _Aggregate.apply(x, bias, fwd, bwd)
 
 

@@ -214,6 +214,23 @@ class BatchStructure:
             self.__dict__["_xperm"] = hit
         return hit[1]
 
+    # -- dense fragments of the operators of large graphs (band_aggregate.hip) -----------------
+    def band_ops(self, kind: str, norm):
+        """(fwd, bwd) `(self, ops.BandOp)` pairs -- or (None, None) -- of the GCN / GraphSAGE operator:
+        built once per batch from the first normalisation computed for it (the coefficients are a
+        function of the batch's edge weights only), like the CSR and the blocked-ELL."""
+        hit = self.__dict__.setdefault("_band_ops", {})
+        if kind not in hit:
+            from . import ops
+            if kind == "gcn":
+                f = ops.band_operator_f32(self, self.rowptr_dst, self.col_dst, norm.coef_dst)
+                b = ops.band_operator_f32(self, self.rowptr_src, self.col_src, norm.coef_src) if f is not None else None
+            else:
+                f = ops.band_operator_f32(self, self.rowptr_dst, self.col_dst, norm.w_dst)
+                b = ops.band_operator_f32(self, self.rowptr_src, self.col_src, norm.coef_src_bwd) if f is not None else None
+            hit[kind] = ((self, f), (self, b)) if (f is not None and b is not None) else (None, None)
+        return hit[kind]
+
     # -- normalisations: layer independent, recomputed once per forward pass ----------------
     def gcn_norm(self) -> GcnNorm:
         """models.py:94-108 via cgnn_gcn_norm."""

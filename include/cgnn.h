@@ -409,6 +409,27 @@ int cgnn_dense_aggregate_c16_bnbwd(const void* dfrag, const int32_t* dstep, cons
                                    float p_drop, int32_t F, void* dT, int64_t lddt, double* cs_slab,
                                    void* stream);
 
+/* The DENSE FRAGMENTS of an aggregation operator applied in fp32 on the bf16 matrix pipe with exactly
+ * split operands (band_aggregate.hip) -- for graphs of more than 384 nodes in the reference's own
+ * arithmetic (models.py:112-114 / :146-149 and their autograd transposes at 1000 ROI), where the gather
+ * kernel cgnn_aggregate_f32 is bound by reading ~100 neighbour rows per output row out of L2.
+ *   cgnn_band_pack_f32: from one CSR ordering (as cgnn_dense_pack_count/fill: P = dense pitch, fpos
+ *     [num_graphs * P/32 * P/16] = position of a fragment in the dense list or 0xFFFFFFFF) the listed
+ *     fragments as MFMA A operands cut into three bf16 pieces: bfrag [items][3][64 lanes][8 bf16]
+ *     (3 KB per fragment), bstep [items] = k-step.  Duplicate edges add up in fp32.  Static per batch.
+ *   cgnn_band_aggregate_f32: Y[r,:] += (sum over the listed fragments of row block r/32) (/ rowdiv[r]);
+ *     boff [num_graphs * P/32 + 1] = item ranges of the (graph, row block)s; F % 32 == 0, ldx / ldy even,
+ *     X / Y 8-byte aligned, Y != X.  The caller runs cgnn_aggregate_f32 on the CSR of the edges OUTSIDE the
+ *     listed fragments first (it also carries the self-loop term, the row division and the bias) and
+ *     this on top: together the full operator, each matrix product exact to 2^-24 relative, the sums in
+ *     another order than the reference's. */
+int cgnn_band_pack_f32(const int32_t* rowptr, const int32_t* col, const float* coef, const int32_t* gptr,
+                       int32_t num_graphs, int32_t P, const uint32_t* fpos, void* bfrag, int32_t* bstep,
+                       void* stream);
+int cgnn_band_aggregate_f32(const void* bfrag, const int32_t* bstep, const int32_t* boff, int32_t P,
+                            const int32_t* gptr, int32_t num_graphs, const float* X, int64_t ldx, int32_t F,
+                            const float* rowdiv, float* Y, int64_t ldy, void* stream);
+
 
 /* Layer 0 forward.  X0 [Nn,F0] (F0 <= 16), W0 [64,F0], bias [64] -> Y [Nn,64];
  * stat_slab [grid][128] fp64 (sum(y) | sum(y^2)) or NULL (eval). */

@@ -632,6 +632,64 @@ def test_dense_per_fragment_operator_matches_dense(sizes, deg):
             torch.testing.assert_close(slab.sum(0)[128:], (yd * yd).sum(0), rtol=1e-9, atol=1e-7)
 
 
+@pytest.mark.parametrize("sizes,deg,min_nnz", [([1000, 437, 500], 60, 28), ([1024], 100, 50), ([500, 385], 130, 0),
+                                               ([1000, 3], 20, 1 << 20), ([640, 1, 400], 40, 18)])
+def test_band_operator_plus_remainder_is_the_gather_aggregate(monkeypatch, sizes, deg, min_nnz):
+    """cgnn_band_pack_f32 + cgnn_band_aggregate_f32 (dense fragments as exactly split bf16 MFMA products) on
+    top of the gather kernel over the remaining edges == the gather kernel over all edges, to fp32
+    rounding (each product exact to 2^-24, the sums in another order): forward and transposed, GCN
+    (self-loop term, bias) and GraphSAGE (row division); every edge is in exactly one of the two parts."""
+    from connectome_gnn_amd import ops
+    monkeypatch.setattr(ops, "BAND_MIN_NNZ", min_nnz)
+    monkeypatch.setattr(ops, "BAND_MIN_COVER", 0.0)
+    ei, w, ptr, bid, nn_ = _rand_graph_batch(sizes, deg, 23)
+    f = 96
+    b = _batch(ei, w, ptr, bid, nn_, f).to(DEV)
+    s = b.structure()
+    gn, sn = s.gcn_norm(), s.sage_norm()
+    x = b.node_features
+    bias = torch.randn(f, generator=torch.Generator().manual_seed(1)).to(DEV)
+    cases = ((s.rowptr_dst, s.col_dst, gn.coef_dst, gn.selfc, None, bias),
+             (s.rowptr_src, s.col_src, gn.coef_src, gn.selfc, None, None),
+             (s.rowptr_dst, s.col_dst, sn.w_dst, None, sn.den, None),
+             (s.rowptr_src, s.col_src, sn.coef_src_bwd, None, None, None))
+    for rowptr, col, coef, selfc, rowdiv, bb in cases:
+        op = ops.band_operator_f32(s, rowptr, col, coef)
+        assert op is not None
+        in_band = int(coef.numel()) - int(op.coef.numel())
+        assert abs(op.covered - in_band / coef.numel()) < 0.02    # (cells counted once, duplicate edges per edge)
+        if min_nnz == 0:
+            assert op.coef.numel() == 0                      # everything on the matrix cores
+        if min_nnz >= 1 << 20:
+            assert op.num_items == 0 and in_band == 0        # ... or nothing
+        want = ops.aggregate_raw(rowptr, col, coef, selfc, rowdiv, bb, x)
+        got = ops.aggregate_raw(rowptr, col, coef, selfc, rowdiv, bb, x, band=(s, op))
+        ref = _csr_apply_f64(rowptr, col, coef, selfc, rowdiv, bb, x)
+        scale = float(ref.abs().max())
+        err_w, err_g = float((want.double() - ref).abs().max()), float((got.double() - ref).abs().max())
+        assert err_g <= max(2.0 * err_w, 4e-7 * scale), (err_g, err_w, scale)
+        assert torch.equal(got, ops.aggregate_raw(rowptr, col, coef, selfc, rowdiv, bb, x, band=(s, op)))
+        # a column slice of a wider buffer as destination and source
+        wide = torch.zeros(nn_, 2 * f, device=DEV)
+        wide[:, f:] = x
+        ops.aggregate_raw(rowptr, col, coef, selfc, rowdiv, bb, wide[:, f:], out=wide[:, :f], band=(s, op))
+        assert torch.equal(wide[:, :f], got)
+
+
+def _csr_apply_f64(rowptr, col, coef, selfc, rowdiv, bias, x):
+    n = x.shape[0]
+    rows = torch.repeat_interleave(torch.arange(n, device=x.device), (rowptr[1:] - rowptr[:-1]).long())
+    y = torch.zeros(n, x.shape[1], dtype=torch.float64, device=x.device)
+    y.index_add_(0, rows, coef.double()[:, None] * x.double()[col.long()])
+    if selfc is not None:
+        y += selfc.double()[:, None] * x.double()
+    if rowdiv is not None:
+        y /= rowdiv.double()[:, None]
+    if bias is not None:
+        y += bias.double()
+    return y
+
+
 @pytest.mark.parametrize("p", [0.0, 0.3])
 def test_aggregate_tiled_with_bn_prologue_equals_two_passes(p):
     """cgnn_aggregate_tiled_bn_f32 (BatchNorm + dropout of the input applied while the tiles are
