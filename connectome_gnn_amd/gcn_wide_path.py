@@ -7,7 +7,10 @@ over a node array is one HIP kernel doing several things at once:
   forward, layer 0     P0 = A_hat X0 (narrow)                   cgnn_aggregate_f32
                        Y0 = P0 W0^T + b (+ BatchNorm statistics) cgnn_linear_fwd_stats_f32 (packed K=32)
   forward, layer l>0   T  = X W^T                                cgnn_linear_fwd_f32 (W in LDS)
-                       Y  = dis * (A_w + I)(dis * T) + b         cgnn_aggregate_tiled_f32 (LDS tiles)
+                       Y  = dis * (A_w + I)(dis * T) + b         cgnn_aggregate_tiled_f32 (LDS tiles); graphs of
+                                                                 more than 384 nodes: cgnn_aggregate_f32 (CSR
+                                                                 gather) + cgnn_band_aggregate_f32 (dense
+                                                                 fragments as split-bf16 MFMA products)
   every layer          X' = dropout(relu(BatchNorm(Y)))          cgnn_bn_act_* ; last layer fused with
                                                                  the readout (cgnn_bn_act_pool_fwd)
   backward, layer l    dY = BatchNorm'(dX' * drop' * relu'), db = colsum(dY)   cgnn_bn_act_bwd_*
@@ -37,8 +40,8 @@ def eligible(model, batch, structure: BatchStructure) -> Optional[str]:
         return "hidden_dim is not 64, 128, 256, ..."
     if model.convs[0].linear.weight.shape[1] >= hid:
         return "input features are not narrower than hidden_dim"
-    if not structure.tiled_ok(hid):
-        return "graphs do not fit an LDS tile (or edges cross graph boundaries)"
+    if not structure.tiled_ok(hid) and not isinstance(structure, BatchStructure):
+        return "graphs do not fit an LDS tile and the structure has no CSR form"
     if batch.node_features.requires_grad:
         return "node_features require grad"
     if not bn_modules_ok(model):
@@ -48,7 +51,7 @@ def eligible(model, batch, structure: BatchStructure) -> Optional[str]:
 
 class _Saved:
     __slots__ = ("s", "ell", "norm", "xs", "ys", "coefs", "masks", "p", "training", "ws", "p0", "padded",
-                 "sync_group", "count_block", "fsum")
+                 "sync_group", "count_block", "fsum", "tiled", "band")
 
 
 class GcnWideEncode(torch.autograd.Function):
@@ -71,8 +74,13 @@ class GcnWideEncode(torch.autograd.Function):
         grid = int(lib.cgnn_fused_grid())
         sv = _Saved()
         sv.s, sv.p, sv.training = s, p, training
-        sv.ell = s.fused_meta(TILE_ROWS, grid, 1.0)          # ELL with the self-loop entry
         sv.norm = s.gcn_norm()
+        hid_all = params[0].shape[0]
+        sv.tiled = s.tiled_ok(hid_all)
+        # graphs of <= 384 nodes: LDS tiles over the blocked-ELL (with the self-loop entry); larger ones:
+        # the CSR gather kernel, its dense fragments on the matrix cores where the batch has them
+        sv.ell = s.fused_meta(TILE_ROWS, grid, 1.0) if sv.tiled else None
+        sv.band = (None, None) if sv.tiled else s.band_ops("gcn", sv.norm)
         sv.xs, sv.ys, sv.coefs, sv.masks, sv.ws = [], [], [], [], []
         sv.p0, sv.padded = None, False
         sv.sync_group, sv.count_block = cfg.get("sync_group"), None
@@ -105,7 +113,11 @@ class GcnWideEncode(torch.autograd.Function):
                     sv.p0, sv.padded = p0, pad
                 else:
                     t = ops.linear_fwd_raw(x, None, w, None, False)
-                    y = ops.aggregate_tiled_raw(s, sv.ell, 0, t, nrm.dis, nrm.dis, b)
+                    if sv.tiled:
+                        y = ops.aggregate_tiled_raw(s, sv.ell, 0, t, nrm.dis, nrm.dis, b)
+                    else:
+                        y = ops.aggregate_raw(s.rowptr_dst, s.col_dst, nrm.coef_dst, nrm.selfc, None, b, t,
+                                              band=sv.band[0])
                 if training and slab is None:
                     slab = torch.empty(rows, 2 * hid, dtype=torch.float64, device=dev)
                     srows = rows
@@ -186,7 +198,11 @@ class GcnWideEncode(torch.autograd.Function):
                         ops.linear_bwd_weight_raw(dy, sv.p0, dw, 0)
                     grads[0:4] = [dw, db, dgamma, dbeta]
                     break
-                dt = ops.aggregate_tiled_raw(s, sv.ell, ops.AGG_TRANSPOSED, dy, nrm.dis, nrm.dis, None)
+                if sv.tiled:
+                    dt = ops.aggregate_tiled_raw(s, sv.ell, ops.AGG_TRANSPOSED, dy, nrm.dis, nrm.dis, None)
+                else:
+                    dt = ops.aggregate_raw(s.rowptr_src, s.col_src, nrm.coef_src, nrm.selfc, None, None, dy,
+                                           band=sv.band[1])
                 dw = torch.empty_like(w)
                 ops.linear_bwd_weight_raw(dt, x, dw, 0)
                 grads[4 * li:4 * li + 4] = [dw, db, dgamma, dbeta]

@@ -240,9 +240,14 @@ class _ConnectomeModel(nn.Module):
             from . import gcn_half_path
             gcn_half_path.dense_operators(s)
             return
-        if self._try_fused(batch, s) or s.tiled_ok(self.convs[-1].linear.weight.shape[0]):
+        hid = self.convs[-1].linear.weight.shape[0]
+        if s.tiled_ok(hid):
             # GCN's ELL carries the self-loop (weight 1), GraphSAGE's does not (weight 0)
             s.fused_meta(_TILE_ROWS, _grid(), 1.0 if self._relu_after_bn else 0.0)
+        elif hasattr(s, "band_ops"):
+            # large graphs: the dense fragments of the operator as matrix-core operands (band_aggregate.hip)
+            s.band_ops("gcn" if self._relu_after_bn else "sage", self._norm(s))
+        self._try_fused(batch, s)
 
     def _try_fused(self, batch, structure) -> bool:
         return False
@@ -255,7 +260,8 @@ class _ConnectomeModel(nn.Module):
         from .structure import BatchStructure
         if not isinstance(structure, BatchStructure) or self.impl == "layered" or self.storage == "fp16" \
                 or any(isinstance(bn, nn.SyncBatchNorm) for bn in self.batch_norms) \
-                or not self._try_fused(batch, structure):
+                or not self._try_fused(batch, structure) \
+                or not structure.tiled_ok(self.convs[-1].linear.weight.shape[0]):
             return
         twin = structure.degree_ordered_twin()
         twin.fused_meta(_TILE_ROWS, _grid(), 1.0 if self._relu_after_bn else 0.0)

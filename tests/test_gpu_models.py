@@ -301,8 +301,8 @@ def test_fused_headline_shape_properties():
 
 
 def test_edge_cases_empty_graphs_and_fallbacks():
-    """Zero-node / zero-edge graphs inside a batch, a graph larger than the LDS tile (layered
-    fallback), and hidden != 64 (layered) all agree with the oracle."""
+    """Zero-node / zero-edge graphs inside a batch, a graph larger than the LDS tile (the wide encoder
+    over the CSR gather aggregate), and hidden 32 (op-by-op path) all agree with the oracle."""
     import connectome_gnn_amd as C
     g_ok = C.generate_connectome(30, 4, seed=1)
     empty = C.ConnectomeGraph(torch.zeros(0, 5), torch.zeros(2, 0, dtype=torch.long), torch.zeros(0),
@@ -310,10 +310,11 @@ def test_edge_cases_empty_graphs_and_fallbacks():
     lonely = C.ConnectomeGraph(torch.randn(3, 5), torch.zeros(2, 0, dtype=torch.long), torch.zeros(0),
                                torch.tensor(0))
     big = C.generate_connectome(400, 6, seed=2)
-    for graphs, want_impl in (([g_ok, empty, lonely, g_ok], "fused"), ([g_ok, big], "layered")):
+    for graphs, hidden, want_impl in (([g_ok, empty, lonely, g_ok], 64, "fused"), ([g_ok, big], 64, "fused"),
+                                      ([g_ok, big], 32, "layered")):
         b = C.collate_graphs(graphs)
         torch.manual_seed(2)
-        m = C.GCNConnectome(5, 64, dropout=0.0)
+        m = C.GCNConnectome(5, hidden, dropout=0.0)
         st = O.require_grad({k: v.clone() for k, v in m.state_dict().items()})
         ob = O.OBatch(b.node_features, b.edge_index, b.edge_weight, b.batch, b.labels, b.ptr)
         lo = O.gcn_forward(st, ob, 0.0, True)
@@ -321,6 +322,7 @@ def test_edge_cases_empty_graphs_and_fallbacks():
         m = m.to(DEV).train()
         lg = m(b.to(DEV))
         assert m.impl_used == want_impl
+        assert want_impl == "layered" or m._fused_kind == ("wide" if any(g is big for g in graphs) else "tile")
         lg.sum().backward()
         torch.testing.assert_close(lg.cpu(), lo, **TOL)
         for k, p in m.named_parameters():
