@@ -113,6 +113,7 @@ PROTOTYPES = {
     "cgnn_gcn_norm": (c_int, [P, P, I64, I64, P, P, P, P, P, P, P, P, P]),
     "cgnn_sage_norm": (c_int, [P, P, I64, I64, P, P, P, P, P, P, P, P]),
     "cgnn_aggregate_f32": (c_int, [P, P, P, P, P, P, P, I64, P, I64, I64, I32, P]),
+    "cgnn_aggregate_acc_f32": (c_int, [P, P, P, P, P, P, P, I64, P, I64, I64, I32, P]),
     "cgnn_aggregate_tiled_f16": (c_int, [TP, I32, P, I64, I32, P, P, P, P, I64, P]),
     "cgnn_head_supported": (c_int, [I32, I32, I32]),
     "cgnn_head_grid": (c_int, [I32, I32, I32, I32]),

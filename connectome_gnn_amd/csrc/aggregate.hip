@@ -28,8 +28,10 @@ __device__ __forceinline__ void fma_vec(float (&acc)[VEC], float c,
   for (int i = 0; i < VEC; ++i) acc[i] = fmaf(c, p[i], acc[i]);
 }
 
-// F == 64*VEC.  Block = 4 waves = 4 rows.
-template <int VEC>
+// F == 64*VEC.  Block = 4 waves = 4 rows.  ACC: the row's sum is added onto what Y holds (the dense
+// fragments' part, written by band_aggregate.hip just before); that read is issued with the row's
+// first gathers, so it costs one more line among the ~16 in flight.
+template <int VEC, bool ACC = false>
 __global__ void __launch_bounds__(256) k_agg_wave_row(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const float* __restrict__ coef, const float* __restrict__ selfc,
@@ -53,6 +55,8 @@ __global__ void __launch_bounds__(256) k_agg_wave_row(
     float acc[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+    V yold;
+    if (ACC) yold = *reinterpret_cast<const V*>(Y + r * ldy + lane * VEC);
     for (int base = beg; base < end; base += 64) {
       const int cnt = min(64, end - base);
       int mycol = 0;
@@ -102,7 +106,7 @@ __global__ void __launch_bounds__(256) k_agg_wave_row(
     V o;
     float* po = reinterpret_cast<float*>(&o);
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) po[i] = acc[i];
+    for (int i = 0; i < VEC; ++i) po[i] = ACC ? reinterpret_cast<const float*>(&yold)[i] + acc[i] : acc[i];
     *reinterpret_cast<V*>(Y + r * ldy + lane * VEC) = o;
   }
 }
@@ -145,26 +149,37 @@ __global__ void __launch_bounds__(256) k_agg_elem(
 
 }  // namespace
 
-extern "C" int cgnn_aggregate_f32(const int32_t* rowptr, const int32_t* col, const float* coef,
-                                  const float* selfc, const float* rowdiv, const float* bias,
-                                  const float* X, int64_t ldx, float* Y, int64_t ldy,
-                                  int64_t num_rows, int32_t F, void* stream) {
+static bool agg_vec_ok(const float* X, int64_t ldx, const float* Y, int64_t ldy, int F) {
+  return (F % 64 == 0) && (F / 64 == 1 || F / 64 == 2 || F / 64 == 4) && (ldx % (F / 64) == 0) &&
+         (ldy % (F / 64) == 0) && (reinterpret_cast<uintptr_t>(X) % (4 * (F / 64)) == 0) &&
+         (reinterpret_cast<uintptr_t>(Y) % (4 * (F / 64)) == 0);
+}
+
+template <bool ACC>
+static void agg_wave_row_launch(const int32_t* rowptr, const int32_t* col, const float* coef, const float* selfc,
+                                const float* rowdiv, const float* bias, const float* X, int64_t ldx, float* Y,
+                                int64_t ldy, int64_t num_rows, int F, hipStream_t st) {
+  const int64_t per = ((num_rows + 3) / 4 + 7) / 8;          // 4-row blocks per XCD
+  unsigned grid = (unsigned)(8 * (per < 2048 ? per : 2048)); // a multiple of 8; the rest grid-strides
+  switch (F / 64) {
+    case 1: k_agg_wave_row<1, ACC><<<grid, 256, 0, st>>>(rowptr, col, coef, selfc, rowdiv, bias, X, ldx, Y, ldy, num_rows); break;
+    case 2: k_agg_wave_row<2, ACC><<<grid, 256, 0, st>>>(rowptr, col, coef, selfc, rowdiv, bias, X, ldx, Y, ldy, num_rows); break;
+    default: k_agg_wave_row<4, ACC><<<grid, 256, 0, st>>>(rowptr, col, coef, selfc, rowdiv, bias, X, ldx, Y, ldy, num_rows); break;
+  }
+}
+
+extern "C" {
+
+int cgnn_aggregate_f32(const int32_t* rowptr, const int32_t* col, const float* coef,
+                       const float* selfc, const float* rowdiv, const float* bias,
+                       const float* X, int64_t ldx, float* Y, int64_t ldy,
+                       int64_t num_rows, int32_t F, void* stream) {
   if (num_rows < 0 || F <= 0 || ldx < F || ldy < F) return CGNN_EINVAL;
   if (num_rows == 0) return CGNN_OK;
   if (!rowptr || !X || !Y) return CGNN_EINVAL;
   hipStream_t st = cgnn_stream(stream);
-  const bool vec_ok = (F % 64 == 0) && (F / 64 == 1 || F / 64 == 2 || F / 64 == 4) &&
-                      (ldx % (F / 64) == 0) && (ldy % (F / 64) == 0) &&
-                      (reinterpret_cast<uintptr_t>(X) % (4 * (F / 64)) == 0) &&
-                      (reinterpret_cast<uintptr_t>(Y) % (4 * (F / 64)) == 0);
-  if (vec_ok) {
-    const int64_t per = ((num_rows + 3) / 4 + 7) / 8;          // 4-row blocks per XCD
-    unsigned grid = (unsigned)(8 * (per < 2048 ? per : 2048)); // a multiple of 8; the rest grid-strides
-    switch (F / 64) {
-      case 1: k_agg_wave_row<1><<<grid, 256, 0, st>>>(rowptr, col, coef, selfc, rowdiv, bias, X, ldx, Y, ldy, num_rows); break;
-      case 2: k_agg_wave_row<2><<<grid, 256, 0, st>>>(rowptr, col, coef, selfc, rowdiv, bias, X, ldx, Y, ldy, num_rows); break;
-      default: k_agg_wave_row<4><<<grid, 256, 0, st>>>(rowptr, col, coef, selfc, rowdiv, bias, X, ldx, Y, ldy, num_rows); break;
-    }
+  if (agg_vec_ok(X, ldx, Y, ldy, F)) {
+    agg_wave_row_launch<false>(rowptr, col, coef, selfc, rowdiv, bias, X, ldx, Y, ldy, num_rows, F, st);
   } else {
     int64_t total = num_rows * F;
     unsigned grid = (unsigned)((total + 255) / 256);
@@ -174,3 +189,18 @@ extern "C" int cgnn_aggregate_f32(const int32_t* rowptr, const int32_t* col, con
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }
+
+int cgnn_aggregate_acc_f32(const int32_t* rowptr, const int32_t* col, const float* coef,
+                           const float* selfc, const float* rowdiv, const float* bias,
+                           const float* X, int64_t ldx, float* Y, int64_t ldy,
+                           int64_t num_rows, int32_t F, void* stream) {
+  if (num_rows < 0 || F <= 0 || ldx < F || ldy < F) return CGNN_EINVAL;
+  if (!agg_vec_ok(X, ldx, Y, ldy, F)) return CGNN_EUNSUPPORTED;
+  if (num_rows == 0) return CGNN_OK;
+  if (!rowptr || !X || !Y || X == Y) return CGNN_EINVAL;
+  agg_wave_row_launch<true>(rowptr, col, coef, selfc, rowdiv, bias, X, ldx, Y, ldy, num_rows, F, cgnn_stream(stream));
+  CGNN_CHECK_LAUNCH();
+  return CGNN_OK;
+}
+
+}  // extern "C"

@@ -1,7 +1,7 @@
 // band_aggregate.hip -- the dense part of the aggregation operator of LARGE graphs in fp32, on the bf16
 // matrix pipe with exactly split operands (gfx950).
 //
-//   Y[r,:] += ( sum over the edges of row r that fall into DENSE fragments  c_e * X[col_e,:] ) (/ rowdiv[r])
+//   Y[r,:] = ( sum over the edges of row r that fall into DENSE fragments  c_e * X[col_e,:] ) (/ rowdiv[r])
 //
 // Replaces, for graphs of more than 384 nodes (BASELINE config 5's 1000-ROI parcellation in the
 // reference's own arithmetic), most of the gather -> mul -> scatter_add_ of models.py:112-114 / :146-149
@@ -11,16 +11,16 @@
 // fragments on the lattice band are nearly full and hold ~90 % of the edges.  Those fragments are
 // applied as matrix products here -- fp32 exact to rounding: both operands are cut into three bf16
 // pieces by truncation (split_bf16.h) and the six partial products of order <= 2 are accumulated in fp32
-// by v_mfma_f32_32x32x16_bf16 -- and the gather kernel keeps the ~10 % of edges outside them (a CSR
-// filtered by the caller), the self-loop term, the row division and the bias.
+// by v_mfma_f32_32x32x16_bf16 -- and the gather kernel (cgnn_aggregate_acc_f32, launched next) adds the
+// ~15 % of edges outside them (a CSR filtered by the caller), the self-loop term and the bias.
 //
 //   cgnn_band_pack_f32       the dense fragments of one CSR ordering as MFMA A operands, already split:
 //                            bfrag[item][piece h|m|l][lane][8 bf16] (3 KB per fragment), bstep[item] = its
 //                            k-step; items of a (graph, row block) are contiguous (boff).  Static per batch.
 //   cgnn_band_aggregate_f32  one wave per (graph, 32-row block, 64-column panel): streams the block's
 //                            fragments (A pieces: three 16-byte loads per lane; B: the 16 source rows'
-//                            64 columns straight from X, split in registers), twelve MFMAs each, and adds
-//                            the [32 x 64] result into Y.  No LDS: the operands are register-shaped as
+//                            64 columns straight from X, split in registers), twelve MFMAs each, and
+//                            writes the [32 x 64] result to Y.  No LDS: the operands are register-shaped as
 //                            they arrive, and the four waves of a workgroup (four panels of one row
 //                            block) share the A pieces through L1.
 #include "common.h"
@@ -89,7 +89,9 @@ struct BdItem { uint4 ah, am, al; float2 x[8]; };   // one fragment's operands a
 // cut into eight contiguous runs -- a graph's feature rows and fragments stay in ONE L2.
 // (Measured and not kept: the remaining edges walked by the same wave on the same accumulators, Y
 // written once -- 202 us against 66 + 58 us for the two launches: the walk is 160 dependent-latency
-// 8-byte gathers per wave where the gather kernel issues 16-byte loads, a whole row per wave.)
+// 8-byte gathers per wave where the gather kernel issues 16-byte loads, a whole row per wave.  And this
+// kernel adding onto the gather kernel's Y: its read-modify-write epilogue was 16 of 57 us, exposed at
+// the end of every wave; the gather kernel hides the same read among its row's gathers.)
 __global__ void __launch_bounds__(256) k_band_agg(
     const uint4* __restrict__ bfrag, const int32_t* __restrict__ bstep, const int32_t* __restrict__ boff,
     int P, const int32_t* __restrict__ gptr, int B, const float* __restrict__ X, int64_t ldx, int F,
@@ -107,44 +109,48 @@ __global__ void __launch_bounds__(256) k_band_agg(
     const int base = gptr[g], n = gptr[g + 1] - base;
     if (panel >= panels || 32 * rb >= n) continue;          // (wave-uniform)
     const int d0 = boff[row], nd = boff[row + 1] - d0;
-    if (nd <= 0) continue;
     const int c0 = 64 * panel + 2 * j;
     const bool colok = c0 < F;                              // F is even: 2j+1 is inside with 2j
     const float* xcol = X + (colok ? c0 : 0);
+    // the k-steps of the row block's fragments: one load up front (a row block has at most P/16 <= 64),
+    // so the source-row addresses of a fragment do not wait on a load of their own
+    const int steps_v = lane < nd ? bstep[d0 + lane] : 0;
     auto fetch = [&](BdItem& it, int item) __attribute__((always_inline)) {
       const uint4* ap = bfrag + (int64_t)(d0 + item) * 192 + lane;
       it.ah = ap[0];
       it.am = ap[64];
       it.al = ap[128];
-      const int k0 = 16 * bstep[d0 + item] + 8 * h;         // B[k = 8 h + e][col]
+      const int k0 = 16 * __builtin_amdgcn_readlane(steps_v, item) + 8 * h;   // B[k = 8 h + e][col]
 #pragma unroll
       for (int e = 0; e < 8; ++e)
         it.x[e] = (k0 + e < n && colok) ? *reinterpret_cast<const float2*>(xcol + (int64_t)(base + k0 + e) * ldx)
                                         : make_float2(0.f, 0.f);
     };
     f32x16 acc0 = {0}, acc1 = {0};
-    BdItem cur, nxt;
-    fetch(cur, 0);
-    nxt = cur;
-    for (int item = 0; item < nd; ++item) {
-      if (item + 1 < nd) fetch(nxt, item + 1);
-      const Split8 b0 = split8(make_float4(cur.x[0].x, cur.x[1].x, cur.x[2].x, cur.x[3].x),
-                               make_float4(cur.x[4].x, cur.x[5].x, cur.x[6].x, cur.x[7].x));
-      const Split8 b1 = split8(make_float4(cur.x[0].y, cur.x[1].y, cur.x[2].y, cur.x[3].y),
-                               make_float4(cur.x[4].y, cur.x[5].y, cur.x[6].y, cur.x[7].y));
-      acc0 = bd_mfma(cur.al, b0.h, acc0);                   // smallest terms first
-      acc1 = bd_mfma(cur.al, b1.h, acc1);
-      acc0 = bd_mfma(cur.ah, b0.l, acc0);
-      acc1 = bd_mfma(cur.ah, b1.l, acc1);
-      acc0 = bd_mfma(cur.am, b0.m, acc0);
-      acc1 = bd_mfma(cur.am, b1.m, acc1);
-      acc0 = bd_mfma(cur.am, b0.h, acc0);
-      acc1 = bd_mfma(cur.am, b1.h, acc1);
-      acc0 = bd_mfma(cur.ah, b0.m, acc0);
-      acc1 = bd_mfma(cur.ah, b1.m, acc1);
-      acc0 = bd_mfma(cur.ah, b0.h, acc0);
-      acc1 = bd_mfma(cur.ah, b1.h, acc1);
-      cur = nxt;
+    if (nd > 0) {
+      BdItem cur, nxt;
+      fetch(cur, 0);
+      nxt = cur;
+      for (int item = 0; item < nd; ++item) {
+        if (item + 1 < nd) fetch(nxt, item + 1);
+        const Split8 b0 = split8(make_float4(cur.x[0].x, cur.x[1].x, cur.x[2].x, cur.x[3].x),
+                                 make_float4(cur.x[4].x, cur.x[5].x, cur.x[6].x, cur.x[7].x));
+        const Split8 b1 = split8(make_float4(cur.x[0].y, cur.x[1].y, cur.x[2].y, cur.x[3].y),
+                                 make_float4(cur.x[4].y, cur.x[5].y, cur.x[6].y, cur.x[7].y));
+        acc0 = bd_mfma(cur.al, b0.h, acc0);                 // smallest terms first
+        acc1 = bd_mfma(cur.al, b1.h, acc1);
+        acc0 = bd_mfma(cur.ah, b0.l, acc0);
+        acc1 = bd_mfma(cur.ah, b1.l, acc1);
+        acc0 = bd_mfma(cur.am, b0.m, acc0);
+        acc1 = bd_mfma(cur.am, b1.m, acc1);
+        acc0 = bd_mfma(cur.am, b0.h, acc0);
+        acc1 = bd_mfma(cur.am, b1.h, acc1);
+        acc0 = bd_mfma(cur.ah, b0.m, acc0);
+        acc1 = bd_mfma(cur.ah, b1.m, acc1);
+        acc0 = bd_mfma(cur.ah, b0.h, acc0);
+        acc1 = bd_mfma(cur.ah, b1.h, acc1);
+        cur = nxt;
+      }
     }
     if (!colok) continue;
 #pragma unroll
@@ -157,11 +163,7 @@ __global__ void __launch_bounds__(256) k_band_agg(
           v0 = v0 / d;
           v1 = v1 / d;
         }
-        float2* yp = reinterpret_cast<float2*>(Y + (int64_t)(base + orow) * ldy + c0);
-        float2 y = *yp;
-        y.x += v0;
-        y.y += v1;
-        *yp = y;
+        *reinterpret_cast<float2*>(Y + (int64_t)(base + orow) * ldy + c0) = make_float2(v0, v1);
       }
     }
   }

@@ -112,6 +112,12 @@ int cgnn_aggregate_f32(const int32_t* rowptr, const int32_t* col, const float* c
                        const float* selfc, const float* rowdiv, const float* bias,
                        const float* X, int64_t ldx, float* Y, int64_t ldy,
                        int64_t num_rows, int32_t F, void* stream);
+/* Y[r, :] += the same sum (F = 64, 128 or 256; else CGNN_EUNSUPPORTED): the edges outside the dense
+ * fragments that cgnn_band_aggregate_f32 has just written to Y (below). */
+int cgnn_aggregate_acc_f32(const int32_t* rowptr, const int32_t* col, const float* coef,
+                           const float* selfc, const float* rowdiv, const float* bias,
+                           const float* X, int64_t ldx, float* Y, int64_t ldy,
+                           int64_t num_rows, int32_t F, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Feature projection on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32),
@@ -417,12 +423,12 @@ int cgnn_dense_aggregate_c16_bnbwd(const void* dfrag, const int32_t* dstep, cons
  *     [num_graphs * P/32 * P/16] = position of a fragment in the dense list or 0xFFFFFFFF) the listed
  *     fragments as MFMA A operands cut into three bf16 pieces: bfrag [items][3][64 lanes][8 bf16]
  *     (3 KB per fragment), bstep [items] = k-step.  Duplicate edges add up in fp32.  Static per batch.
- *   cgnn_band_aggregate_f32: Y[r,:] += (sum over the listed fragments of row block r/32) (/ rowdiv[r]);
- *     boff [num_graphs * P/32 + 1] = item ranges of the (graph, row block)s; F % 32 == 0, ldx / ldy even,
- *     X / Y 8-byte aligned, Y != X.  The caller runs cgnn_aggregate_f32 on the CSR of the edges OUTSIDE the
- *     listed fragments first (it also carries the self-loop term, the row division and the bias) and
- *     this on top: together the full operator, each matrix product exact to 2^-24 relative, the sums in
- *     another order than the reference's. */
+ *   cgnn_band_aggregate_f32: Y[r,:] = (sum over the listed fragments of row block r/32) (/ rowdiv[r]) for
+ *     every row (0 where the row block lists nothing); boff [num_graphs * P/32 + 1] = item ranges of the
+ *     (graph, row block)s; F % 32 == 0, ldx / ldy even, X / Y 8-byte aligned, Y != X.  The caller then
+ *     runs cgnn_aggregate_acc_f32 on the CSR of the edges OUTSIDE the listed fragments (it also carries
+ *     the self-loop term, the row division and the bias) on top: together the full operator, each matrix
+ *     product exact to 2^-24 relative, the sums in another order than the reference's. */
 int cgnn_band_pack_f32(const int32_t* rowptr, const int32_t* col, const float* coef, const int32_t* gptr,
                        int32_t num_graphs, int32_t P, const uint32_t* fpos, void* bfrag, int32_t* bstep,
                        void* stream);
