@@ -117,7 +117,8 @@ PMC_FILES = {
     "cfg5-gcn-64x1000-h256-fp16": (("r03_cfg5_fp16_pmc_traffic.json", "r02_cfg5_fp16_pmc_traffic.json"), 64,
                                    ("k_dense_agg",)),
     "shard512-gcn-512x360-h64": (("r03_shard512_pmc_traffic.json",), 512, ("k_gcn_bwd<",)),
-    "cfg5-gcn-64x1000-h256-fp32": (("r03_cfg5_fp32_pmc_traffic.json",), 64, ("k_agg_wave_row",)),
+    # one aggregation = two launches (dense fragments on the matrix cores, then the remaining edges): SUMMED
+    "cfg5-gcn-64x1000-h256-fp32": (("r03_cfg5_fp32_pmc_traffic.json",), 64, (("k_band_agg",), ("k_agg_wave_row",))),
 }
 
 
@@ -125,8 +126,8 @@ def pmc_traffic(workload: str, bsz: int):
     """(HBM bytes per launch of the dominant kernel, HBM bytes per step, source) from the committed
     offline PMC passes, or (None, None, None).  A file that exists for this workload but holds
     no kernel matching the prefixes is an ERROR (stale key), not a silent null."""
-    if workload not in PMC_FILES:
-        return None, None, None
+    if workload not in PMC_FILES or os.environ.get("CGNN_BENCH_COLLECTING_PMC"):
+        return None, None, None          # (the counter passes themselves run this script: tools/measure_all.sh)
     files, pmc_bsz, prefixes = PMC_FILES[workload]
     if bsz != pmc_bsz:
         return None, None, None
@@ -135,11 +136,13 @@ def pmc_traffic(workload: str, bsz: int):
         if not os.path.exists(path):
             continue
         doc = json.load(open(path))
-        hits = [v for k, v in doc["kernels"].items() if any(k.startswith(pf) for pf in prefixes)]
-        if not hits:
-            raise RuntimeError(f"profiles/{fname}: no kernel starts with any of {prefixes} -- stale PMC_FILES key")
-        launches = sum(h["launches"] for h in hits)
-        per_launch = sum(h["hbm_bytes_per_launch"] * h["launches"] for h in hits) / launches
+        per_launch = 0.0
+        for group in (prefixes if isinstance(prefixes[0], tuple) else (prefixes,)):   # groups add up
+            hits = [v for k, v in doc["kernels"].items() if any(k.startswith(pf) for pf in group)]
+            if not hits:
+                raise RuntimeError(f"profiles/{fname}: no kernel starts with any of {group} -- stale PMC_FILES key")
+            launches = sum(h["launches"] for h in hits)
+            per_launch += sum(h["hbm_bytes_per_launch"] * h["launches"] for h in hits) / launches
         return per_launch, doc.get("hbm_bytes_per_step_library_kernels"), \
             f"profiles/{fname} (offline rocprofv3 --pmc passes, not this run)"
     return None, None, None
@@ -421,6 +424,9 @@ def run_workload(args, name: str, rank: int, world: int, dev, *, launch: str, ba
         "cgnn_gcn_fused_bwd": lambda nn_, ee: nn_ * 4.0 * (5 * hidden + hidden + 2 * hidden) + 8.0 * ee,
         f"cgnn_aggregate_tiled_f32[F={hidden}]": agg_bytes,     # LDS-tiled aggregate (wide layers)
         f"cgnn_aggregate_f32[F={hidden}]": agg_bytes,           # gather form (graphs > 384 nodes)
+        # ... with the operator's dense fragments on the matrix cores: two launches per aggregation, timed
+        # and priced as ONE (the sparse operator's bytes; the fragments' stored operands are not "algorithmic")
+        f"cgnn_band_aggregate_f32+cgnn_aggregate_acc_f32[F={hidden}]": agg_bytes,
         # fp16 storage: the dense per-graph aggregate, priced at the SPARSE operator's bytes (s = 2)
         f"cgnn_dense_aggregate_f16[F={hidden}]": lambda nn_, ee: 2.0 * nn_ * hidden * 2 + 8.0 * ee + 4.0 * (nn_ + 1),
         f"cgnn_dense_aggregate_c16[F={hidden}]": lambda nn_, ee: 2.0 * nn_ * hidden * 2 + 8.0 * ee + 4.0 * (nn_ + 1),
@@ -434,6 +440,8 @@ def run_workload(args, name: str, rank: int, world: int, dev, *, launch: str, ba
         dom = "cgnn_gcn_fused_bwd"
     elif batches[0].structure().tiled_ok(hidden):
         dom = f"cgnn_aggregate_tiled_f32[F={hidden}]"
+    elif any(v[0] is not None for v in batches[0].structure().__dict__.get("_band_ops", {}).values()):
+        dom = f"cgnn_band_aggregate_f32+cgnn_aggregate_acc_f32[F={hidden}]"
     else:
         dom = f"cgnn_aggregate_f32[F={hidden}]"
     dom_bytes_fn = candidates[dom]

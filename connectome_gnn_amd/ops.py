@@ -97,17 +97,16 @@ def band_aggregate_raw(structure, band: BandOp, selfc, rowdiv, bias, x, out=None
     lib = _lib.load()
     n, f = x.shape
     y = torch.empty_like(x) if out is None else out
-    with _lib.device_guard(x.device):
+    # (one timed region: the two launches are one aggregation -- bench.py prices them together)
+    with _lib.device_guard(x.device), _lib.timed("cgnn_band_aggregate_f32+cgnn_aggregate_acc_f32", f"F={f}"):
         sp = _lib.stream_ptr()
-        with _lib.timed("cgnn_band_aggregate_f32", f"F={f}"):
-            _lib.check(lib.cgnn_band_aggregate_f32(
-                _lib.ptr(band.bfrag), _lib.ptr(band.bstep), _lib.ptr(band.boff), band.pitch, _lib.ptr(structure.gptr),
-                structure.num_graphs, _lib.ptr(x), x.stride(0), f, _lib.ptr(rowdiv), _lib.ptr(y), y.stride(0), sp),
-                "cgnn_band_aggregate_f32")
-        with _lib.timed("cgnn_aggregate_acc_f32", f"F={f}"):
-            _lib.check(lib.cgnn_aggregate_acc_f32(
-                _lib.ptr(band.rowptr), _lib.ptr(band.col), _lib.ptr(band.coef), _lib.ptr(selfc), _lib.ptr(rowdiv),
-                _lib.ptr(bias), _lib.ptr(x), x.stride(0), _lib.ptr(y), y.stride(0), n, f, sp), "cgnn_aggregate_acc_f32")
+        _lib.check(lib.cgnn_band_aggregate_f32(
+            _lib.ptr(band.bfrag), _lib.ptr(band.bstep), _lib.ptr(band.boff), band.pitch, _lib.ptr(structure.gptr),
+            structure.num_graphs, _lib.ptr(x), x.stride(0), f, _lib.ptr(rowdiv), _lib.ptr(y), y.stride(0), sp),
+            "cgnn_band_aggregate_f32")
+        _lib.check(lib.cgnn_aggregate_acc_f32(
+            _lib.ptr(band.rowptr), _lib.ptr(band.col), _lib.ptr(band.coef), _lib.ptr(selfc), _lib.ptr(rowdiv),
+            _lib.ptr(bias), _lib.ptr(x), x.stride(0), _lib.ptr(y), y.stride(0), n, f, sp), "cgnn_aggregate_acc_f32")
     return y
 
 
