@@ -126,7 +126,7 @@ PROTOTYPES = {
     "cgnn_dense_pack_fill": (c_int, [P, P, P, P, P, I32, I32, P, P, P, P, P, P]),
     "cgnn_dense_aggregate_c16": (c_int, [P, P, P, P, P, P, I32, P, I32, P, I64, I32, P, P, I64, P, P]),
     "cgnn_band_pack_f32": (c_int, [P, P, P, P, I32, I32, P, P, P, P]),
-    "cgnn_band_aggregate_f32": (c_int, [P, P, P, I32, P, I32, P, I64, I32, P, P, I64, P]),
+    "cgnn_band_aggregate_f32": (c_int, [P, P, P, I32, P, I32, P, I64, I32, P, P, I64, P, I64, P]),
     "cgnn_dense_aggregate_c16_bnbwd": (c_int, [P, P, P, P, P, P, I32, P, I32, P, I64, P, P, I64, P, P, P, I32, F32, I32, P,
                                                I64, P, P]),
     "cgnn_linear_fwd_f32": (c_int, [P, I64, I32, P, I64, I32, P, P, I32, P, I64, I64, I32, P]),

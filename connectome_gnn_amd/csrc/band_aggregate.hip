@@ -95,7 +95,8 @@ struct BdItem { uint4 ah, am, al; float2 x[8]; };   // one fragment's operands a
 __global__ void __launch_bounds__(256) k_band_agg(
     const uint4* __restrict__ bfrag, const int32_t* __restrict__ bstep, const int32_t* __restrict__ boff,
     int P, const int32_t* __restrict__ gptr, int B, const float* __restrict__ X, int64_t ldx, int F,
-    const float* __restrict__ rowdiv, float* __restrict__ Y, int64_t ldy) {
+    const float* __restrict__ rowdiv, const float* __restrict__ Yadd, int64_t ldadd, float* __restrict__ Y,
+    int64_t ldy) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
   const int NRB = P >> 5;
   const int panels = (F + 63) >> 6, pgroups = (panels + 3) >> 2;   // workgroups per (graph, row block)
@@ -163,6 +164,11 @@ __global__ void __launch_bounds__(256) k_band_agg(
           v0 = v0 / d;
           v1 = v1 / d;
         }
+        if (Yadd) {                                         // GraphSAGE backward: dX = dX1 + A^T (dA / den)
+          const float2 ya = *reinterpret_cast<const float2*>(Yadd + (int64_t)(base + orow) * ldadd + c0);
+          v0 += ya.x;
+          v1 += ya.y;
+        }
         *reinterpret_cast<float2*>(Y + (int64_t)(base + orow) * ldy + c0) = make_float2(v0, v1);
       }
     }
@@ -196,17 +202,18 @@ int cgnn_band_pack_f32(const int32_t* rowptr, const int32_t* col, const float* c
 
 int cgnn_band_aggregate_f32(const void* bfrag, const int32_t* bstep, const int32_t* boff, int32_t P,
                             const int32_t* gptr, int32_t num_graphs, const float* X, int64_t ldx, int32_t F,
-                            const float* rowdiv, float* Y, int64_t ldy, void* stream) {
-  if (num_graphs < 0 || P <= 0 || F <= 0 || ldx < F || ldy < F) return CGNN_EINVAL;
+                            const float* rowdiv, const float* Yadd, int64_t ldadd, float* Y, int64_t ldy,
+                            void* stream) {
+  if (num_graphs < 0 || P <= 0 || F <= 0 || ldx < F || ldy < F || (Yadd && ldadd < F)) return CGNN_EINVAL;
   if (P > BD_MAXP || P % 64 || F % 32 || ldx % 2 || ldy % 2 || (reinterpret_cast<uintptr_t>(X) & 7) ||
-      (reinterpret_cast<uintptr_t>(Y) & 7))
+      (reinterpret_cast<uintptr_t>(Y) & 7) || (Yadd && (ldadd % 2 || (reinterpret_cast<uintptr_t>(Yadd) & 7))))
     return CGNN_EUNSUPPORTED;                               // (8-byte accesses of column pairs)
   if (num_graphs == 0) return CGNN_OK;
   if (!bfrag || !bstep || !boff || !gptr || !X || !Y || X == Y) return CGNN_EINVAL;
   const int64_t tasks = (int64_t)num_graphs * (P >> 5) * (((F + 63) / 64 + 3) / 4);
   const unsigned grid = (unsigned)(((tasks < 65536 ? tasks : 65536) + 7) / 8 * 8);
   k_band_agg<<<grid, 256, 0, cgnn_stream(stream)>>>(static_cast<const uint4*>(bfrag), bstep, boff, P, gptr, num_graphs,
-                                                    X, ldx, F, rowdiv, Y, ldy);
+                                                    X, ldx, F, rowdiv, Yadd, ldadd, Y, ldy);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }

@@ -91,8 +91,8 @@ def band_operator_f32(structure, rowptr, col, coef) -> Optional[BandOp]:
     return op
 
 
-def band_aggregate_raw(structure, band: BandOp, selfc, rowdiv, bias, x, out=None) -> torch.Tensor:
-    """The operator of ``band`` applied to x with the epilogue of aggregate_raw: the dense fragments'
+def band_aggregate_raw(structure, band: BandOp, selfc, rowdiv, bias, x, out=None, yadd=None) -> torch.Tensor:
+    """The operator of ``band`` applied to x with the epilogue of aggregate_raw (+ yadd): the dense fragments'
     part written by cgnn_band_aggregate_f32, the remaining edges added by cgnn_aggregate_acc_f32."""
     lib = _lib.load()
     n, f = x.shape
@@ -102,21 +102,36 @@ def band_aggregate_raw(structure, band: BandOp, selfc, rowdiv, bias, x, out=None
         sp = _lib.stream_ptr()
         _lib.check(lib.cgnn_band_aggregate_f32(
             _lib.ptr(band.bfrag), _lib.ptr(band.bstep), _lib.ptr(band.boff), band.pitch, _lib.ptr(structure.gptr),
-            structure.num_graphs, _lib.ptr(x), x.stride(0), f, _lib.ptr(rowdiv), _lib.ptr(y), y.stride(0), sp),
-            "cgnn_band_aggregate_f32")
+            structure.num_graphs, _lib.ptr(x), x.stride(0), f, _lib.ptr(rowdiv), _lib.ptr(yadd),
+            0 if yadd is None else yadd.stride(0), _lib.ptr(y), y.stride(0), sp), "cgnn_band_aggregate_f32")
         _lib.check(lib.cgnn_aggregate_acc_f32(
             _lib.ptr(band.rowptr), _lib.ptr(band.col), _lib.ptr(band.coef), _lib.ptr(selfc), _lib.ptr(rowdiv),
             _lib.ptr(bias), _lib.ptr(x), x.stride(0), _lib.ptr(y), y.stride(0), n, f, sp), "cgnn_aggregate_acc_f32")
     return y
 
 
-def aggregate_raw(rowptr, col, coef, selfc, rowdiv, bias, x, out=None, band=None) -> torch.Tensor:
+def aggregate_raw(rowptr, col, coef, selfc, rowdiv, bias, x, out=None, band=None, yadd=None) -> torch.Tensor:
     """out: optional [n, f] destination (may be a column slice of a wider row-major buffer).
     band = (structure, BandOp): the operator's dense fragments go to the matrix cores
-    (band_aggregate.hip) and only the remaining edges through the gather kernel (widths 64, 128, 256)."""
-    if band is not None and x.shape[1] in (64, 128, 256) and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and (
-            out is None or (out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0)):
-        return band_aggregate_raw(band[0], band[1], selfc, rowdiv, bias, x, out)
+    (band_aggregate.hip) and only the remaining edges through the gather kernel (widths 64, 128, 256).
+    yadd: [n, f] added to the result (GraphSAGE's dX = dX1 + A^T(dA / den)); widths 64, 128, 256."""
+    f = x.shape[1]
+    wide = f in (64, 128, 256) and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and (
+        out is None or (out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0))
+    if band is not None and wide and (yadd is None or (yadd.stride(0) % 2 == 0 and yadd.data_ptr() % 8 == 0)):
+        return band_aggregate_raw(band[0], band[1], selfc, rowdiv, bias, x, out, yadd)
+    if yadd is not None:
+        if not wide:
+            raise ValueError("aggregate_raw(yadd=...) takes widths 64, 128, 256 (16-byte aligned rows)")
+        lib = _lib.load()
+        y = torch.empty_like(x) if out is None else out
+        y.copy_(yadd)                                  # the sum lands on top (cgnn_aggregate_acc_f32)
+        with _lib.device_guard(x.device), _lib.timed("cgnn_aggregate_acc_f32", f"F={f}"):
+            _lib.check(lib.cgnn_aggregate_acc_f32(
+                _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(coef), _lib.ptr(selfc), _lib.ptr(rowdiv), _lib.ptr(bias),
+                _lib.ptr(x), x.stride(0), _lib.ptr(y), y.stride(0), x.shape[0], f, _lib.stream_ptr()),
+                "cgnn_aggregate_acc_f32")
+        return y
     lib = _lib.load()
     n, f = x.shape
     y = torch.empty_like(x) if out is None else out

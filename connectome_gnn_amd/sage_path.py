@@ -34,8 +34,8 @@ def eligible(model, batch, structure: BatchStructure) -> Optional[str]:
     hid = model.convs[0].linear.weight.shape[0]
     if hid % 64 or not bool(_lib.load().cgnn_bn_act_width_ok(hid)):
         return "hidden_dim is not 64, 128, 256, ..."
-    if not structure.tiled_ok(hid):
-        return "graphs do not fit an LDS tile (or edges cross graph boundaries)"
+    if not structure.tiled_ok(hid) and not isinstance(structure, BatchStructure):
+        return "graphs do not fit an LDS tile and the structure has no CSR form"
     if batch.node_features.requires_grad:
         return "node_features require grad"
     if not bn_modules_ok(model):
@@ -45,7 +45,7 @@ def eligible(model, batch, structure: BatchStructure) -> Optional[str]:
 
 class _Saved:
     __slots__ = ("s", "ell", "norm", "xs", "aggs", "zs", "coefs", "masks", "p", "training", "ws", "xa0",
-                 "sync_group", "count_block", "fsum")
+                 "sync_group", "count_block", "fsum", "tiled", "band")
 
 
 PAD_K = 32          # layer 0: [x0 | agg(x0) | 0] packed to one 32-wide panel
@@ -68,13 +68,13 @@ def _agg_narrow_tiled(s, ell, norm, x, out=None):
     return out
 
 
-def _agg_fwd(s: BatchStructure, ell, norm, x):
+def _agg_fwd(s: BatchStructure, ell, norm, x, band=None):
     """weighted mean of in-neighbours, models.py:146-149"""
-    if s.tiled_ok(x.shape[1]):
+    if ell is not None and s.tiled_ok(x.shape[1]):
         return ops.aggregate_tiled_raw(s, ell, ops.AGG_POST_DIV, x, None, norm.den, None)
     if getattr(s, "cached_subjects", False):
         return _agg_narrow_tiled(s, ell, norm, x)
-    return ops.aggregate_raw(s.rowptr_dst, s.col_dst, norm.w_dst, None, norm.den, None, x)
+    return ops.aggregate_raw(s.rowptr_dst, s.col_dst, norm.w_dst, None, norm.den, None, x, band=band)
 
 
 def sync_group_of(model):
@@ -190,8 +190,12 @@ class SageEncode(torch.autograd.Function):
         sv = _Saved()
         sv.s, sv.p, sv.training = s, p, training
         grid = int(lib.cgnn_fused_grid())
-        sv.ell = s.fused_meta(TILE_ROWS, grid, 0.0)
-        sv.norm = s.sage_norm(backward_coef=False)
+        # graphs of <= 384 nodes: LDS tiles over the blocked-ELL; larger ones: the CSR gather kernel, its dense
+        # fragments on the matrix cores where the batch has them (the transposed pass then needs w / den per edge)
+        sv.tiled = s.tiled_ok(params[0].shape[0])
+        sv.ell = s.fused_meta(TILE_ROWS, grid, 0.0) if sv.tiled else None
+        sv.norm = s.sage_norm(backward_coef=not sv.tiled)
+        sv.band = (None, None) if sv.tiled else s.band_ops("sage", sv.norm)
         sv.xs, sv.aggs, sv.zs, sv.coefs, sv.masks, sv.ws = [], [], [], [], [], []
         sv.xa0 = None
         sv.sync_group, sv.count_block = cfg.get("sync_group"), None
@@ -208,7 +212,7 @@ class SageEncode(torch.autograd.Function):
                 if pending is not None:
                     pz, pcoef, pseed, prw, pmask = pending
                     x = torch.empty_like(pz)
-                    if s.tiled_ok(pz.shape[1]):
+                    if sv.tiled and s.tiled_ok(pz.shape[1]):
                         # X' = drop(BatchNorm(Z)) formed while the aggregate stages its tiles (and
                         # written out for the projection): no apply pass
                         agg = ops.aggregate_tiled_bn_raw(s, sv.ell, ops.AGG_POST_DIV, pz, None, sv.norm.den, None,
@@ -236,7 +240,7 @@ class SageEncode(torch.autograd.Function):
                     gemm_in = (xa, None, wp)
                 else:
                     if agg is None:
-                        agg = _agg_fwd(s, sv.ell, sv.norm, x)
+                        agg = _agg_fwd(s, sv.ell, sv.norm, x, sv.band[0])
                     gemm_in = (x, agg, w)
                 z = None
                 if training:
@@ -334,8 +338,12 @@ class SageEncode(torch.autograd.Function):
                     break
                 # ---- [dX1 | dA] = dPre W, then dX = dX1 + A_w^T (dA / den)
                 dcat = ops.linear_bwd_input_raw(dpre, w, 0, 2 * fin)
-                dx = ops.aggregate_tiled_raw(s, sv.ell, ops.AGG_TRANSPOSED | ops.AGG_PRE_DIV,
-                                             dcat[:, fin:], sv.norm.den, None, None, yadd=dcat[:, :fin])
+                if sv.tiled:
+                    dx = ops.aggregate_tiled_raw(s, sv.ell, ops.AGG_TRANSPOSED | ops.AGG_PRE_DIV,
+                                                 dcat[:, fin:], sv.norm.den, None, None, yadd=dcat[:, :fin])
+                else:
+                    dx = ops.aggregate_raw(s.rowptr_src, s.col_src, sv.norm.coef_src_bwd, None, None, None,
+                                           dcat[:, fin:], band=sv.band[1], yadd=dcat[:, :fin])
             deferred.flush(st())
         ctx.sv = None
         return (None, None, *grads)

@@ -424,7 +424,8 @@ int cgnn_dense_aggregate_c16_bnbwd(const void* dfrag, const int32_t* dstep, cons
  *     fragments as MFMA A operands cut into three bf16 pieces: bfrag [items][3][64 lanes][8 bf16]
  *     (3 KB per fragment), bstep [items] = k-step.  Duplicate edges add up in fp32.  Static per batch.
  *   cgnn_band_aggregate_f32: Y[r,:] = (sum over the listed fragments of row block r/32) (/ rowdiv[r]) for
- *     every row (0 where the row block lists nothing); boff [num_graphs * P/32 + 1] = item ranges of the
+ *     every row (0 where the row block lists nothing), + Yadd[r,:] when Yadd is not NULL (GraphSAGE's
+ *     dX = dX1 + A^T(dA / den), models.py:146-152 backward; Yadd may not alias Y); boff [num_graphs * P/32 + 1] = item ranges of the
  *     (graph, row block)s; F % 32 == 0, ldx / ldy even, X / Y 8-byte aligned, Y != X.  The caller then
  *     runs cgnn_aggregate_acc_f32 on the CSR of the edges OUTSIDE the listed fragments (it also carries
  *     the self-loop term, the row division and the bias) on top: together the full operator, each matrix
@@ -434,7 +435,8 @@ int cgnn_band_pack_f32(const int32_t* rowptr, const int32_t* col, const float* c
                        void* stream);
 int cgnn_band_aggregate_f32(const void* bfrag, const int32_t* bstep, const int32_t* boff, int32_t P,
                             const int32_t* gptr, int32_t num_graphs, const float* X, int64_t ldx, int32_t F,
-                            const float* rowdiv, float* Y, int64_t ldy, void* stream);
+                            const float* rowdiv, const float* Yadd, int64_t ldadd, float* Y, int64_t ldy,
+                            void* stream);
 
 
 /* Layer 0 forward.  X0 [Nn,F0] (F0 <= 16), W0 [64,F0], bias [64] -> Y [Nn,64];

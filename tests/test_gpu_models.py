@@ -335,7 +335,8 @@ def test_edge_cases_empty_graphs_and_fallbacks():
 
 def test_sage_edge_cases_empty_graphs_and_fallbacks():
     """GraphSAGE: zero-node / zero-edge graphs inside a batch on the one-node encoder, a graph
-    larger than the LDS tile and hidden 32 on the op-by-op path -- all against the oracle."""
+    larger than the LDS tile (same encoder over the CSR gather aggregate) and hidden 32 on the
+    op-by-op path -- all against the oracle."""
     import connectome_gnn_amd as C
     g_ok = C.generate_connectome(30, 4, seed=1)
     empty = C.ConnectomeGraph(torch.zeros(0, 5), torch.zeros(2, 0, dtype=torch.long), torch.zeros(0),
@@ -344,7 +345,7 @@ def test_sage_edge_cases_empty_graphs_and_fallbacks():
                                torch.tensor(0))
     big = C.generate_connectome(400, 6, seed=2)
     for graphs, hidden, want_impl in (([g_ok, empty, lonely, g_ok], 64, "fused"),
-                                      ([g_ok, big], 64, "layered"), ([g_ok, lonely], 32, "layered")):
+                                      ([g_ok, big], 64, "fused"), ([g_ok, lonely], 32, "layered")):
         b = C.collate_graphs(graphs)
         torch.manual_seed(2)
         m = C.GraphSAGEConnectome(5, hidden, dropout=0.0)
@@ -699,6 +700,44 @@ def test_cfg5_shape_gcn_1000roi_h256_vs_oracle(dropout):
     floor = P.NoiseFloor("gcn", sd0, b, dropout, masks)
     for k_, p in m.named_parameters():
         P.assert_grad(k_, p.grad, g32[k_], g64[k_], f"cfg5-p{dropout}", floor)
+    sd = m.state_dict()
+    for k_ in sd:
+        if "running" in k_:
+            torch.testing.assert_close(sd[k_].cpu(), st32[k_], **TOL)
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.3])
+def test_sage_1000roi_h128_band_aggregate_vs_oracle(dropout):
+    """GraphSAGE on 1000-ROI graphs at 10 % density (BASELINE config 5's graphs), hidden 128: the one-node
+    encoder over the large-graph aggregate -- dense fragments of A_w / den as split-bf16 matrix products
+    (band_aggregate.hip, with the row division and, in the backward, the dX1 addend), the other edges
+    through the gather kernel -- against the fp32 oracle, dropout masks replayed."""
+    import connectome_gnn_amd as C
+    from connectome_gnn_amd.resident import assemble_batch
+    from connectome_gnn_amd.synthetic import generate_packed
+    ds = generate_packed(3, 1000, 100, seed=11)
+    b = assemble_batch(ds, torch.arange(3))
+    torch.manual_seed(4)
+    m = _model("sage", 5, 128, dropout=dropout)
+    sd0 = {k_: v.clone() for k_, v in m.state_dict().items()}
+    m = m.to(DEV).train()
+    m.record_dropout = True
+    bd = b.to(DEV)
+    lg = m(bd)
+    assert m.impl_used == "fused"
+    s = bd.structure()
+    bf, bb = s.band_ops("sage", s.sage_norm())
+    assert bf is not None and bb is not None and bf[1].covered > 0.5
+    loss_g = torch.nn.functional.cross_entropy(lg, bd.labels)
+    loss_g.backward()
+    masks = P.recorded_masks(m, b.num_nodes, b.num_graphs) if dropout > 0 else None
+    lo, loss_o, g32, st32 = P.oracle_run("sage", sd0, b, dropout, True, masks)
+    _, _, g64, _ = P.oracle_run("sage", sd0, b, dropout, True, masks, dtype=torch.float64)
+    torch.testing.assert_close(lg.detach().cpu(), lo, **TOL)
+    torch.testing.assert_close(loss_g.detach().cpu(), loss_o, **TOL)
+    floor = P.NoiseFloor("sage", sd0, b, dropout, masks)
+    for k_, p in m.named_parameters():
+        P.assert_grad(k_, p.grad, g32[k_], g64[k_], f"sage1000-p{dropout}", floor)
     sd = m.state_dict()
     for k_ in sd:
         if "running" in k_:
