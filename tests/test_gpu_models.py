@@ -706,6 +706,33 @@ def test_cfg5_shape_gcn_1000roi_h256_vs_oracle(dropout):
             torch.testing.assert_close(sd[k_].cpu(), st32[k_], **TOL)
 
 
+@pytest.mark.parametrize("kind", ["gcn", "sage"])
+def test_graphs_beyond_the_band_builder_take_the_gather_aggregate(kind):
+    """A 1100-node graph (more than the 1024 the dense-fragment builder takes) next to a small one and an
+    empty one: the one-node encoders run over the plain CSR gather aggregate, against the oracle."""
+    import connectome_gnn_amd as C
+    graphs = [C.generate_connectome(1100, 40, seed=3), C.generate_connectome(50, 6, seed=4),
+              C.ConnectomeGraph(torch.zeros(0, 5), torch.zeros(2, 0, dtype=torch.long), torch.zeros(0), torch.tensor(1))]
+    b = C.collate_graphs(graphs)
+    torch.manual_seed(5)
+    m = _model(kind, 5, 64, dropout=0.0)
+    sd0 = {k_: v.clone() for k_, v in m.state_dict().items()}
+    m = m.to(DEV).train()
+    bd = b.to(DEV)
+    lg = m(bd)
+    assert m.impl_used == "fused"
+    s = bd.structure()
+    assert s.band_ops(kind, s.gcn_norm() if kind == "gcn" else s.sage_norm()) == (None, None)
+    loss_g = torch.nn.functional.cross_entropy(lg, bd.labels)
+    loss_g.backward()
+    lo, loss_o, g32, st32 = P.oracle_run(kind, sd0, b, 0.0, True, None)
+    _, _, g64, _ = P.oracle_run(kind, sd0, b, 0.0, True, None, dtype=torch.float64)
+    torch.testing.assert_close(lg.detach().cpu(), lo, **TOL)
+    floor = P.NoiseFloor(kind, sd0, b, 0.0, None)
+    for k_, p in m.named_parameters():
+        P.assert_grad(k_, p.grad, g32[k_], g64[k_], f"big1100-{kind}", floor)
+
+
 @pytest.mark.parametrize("dropout", [0.0, 0.3])
 def test_sage_1000roi_h128_band_aggregate_vs_oracle(dropout):
     """GraphSAGE on 1000-ROI graphs at 10 % density (BASELINE config 5's graphs), hidden 128: the one-node
