@@ -368,7 +368,7 @@ def run_workload(args, name: str, rank: int, world: int, dev, *, launch: str, ba
             sync.zero_grad()                 # grads are views of the flat all-reduce buffer
         else:
             opt.zero_grad(set_to_none=True)
-        loss = loss_fn(model(b), b.labels)
+        loss = cops.model_loss(model, loss_fn, b)       # (= loss_fn(model(b), b.labels), as Trainer.train_step)
         cops.backward_unit(loss)
         if sync is not None:
             sync(local_graphs=local_graphs)

@@ -392,6 +392,225 @@ __global__ void __launch_bounds__(CETHR) k_ce_fwd(const float* __restrict__ logi
   }
 }
 
+// ------------------------------------------------ head forward + cross-entropy + head backward
+// One launch for the whole classifier step when the loss is the batch-mean cross-entropy and its
+// upstream gradient is the unit (the Trainer's step, reference train.py:46-51): a workgroup takes
+// 16-row chunks through k_head_fwd's arithmetic (z, relu', dropout hash, logits), k_ce_fwd's per-row
+// log-sum-exp and gradient -- the divisor V (labels that are not -100) is counted by every workgroup
+// from the label array itself, so no workgroup waits on another -- and k_head_bwd_t's backward, and
+// leaves its parameter-gradient partials AND its share of the loss (sum of its rows' losses / V) in
+// its slab row: the slab fold that produces the gradients also produces the loss.  Three launches
+// (7.5 + 4.8 + 7.0 us at 512 graphs) become one.
+// Slab row: dW1 [H2*H] | db1 [H2] | dW2 [C*H2] | db2 [C] | loss share [1].
+template <int H, int H2, int C>
+__global__ void __launch_bounds__(256) k_head_loss_t(
+    const float* __restrict__ P, int B, const float* __restrict__ W1, const float* __restrict__ b1,
+    const float* __restrict__ W2, const float* __restrict__ b2, const int64_t* __restrict__ labels,
+    HeadDrop drop, int use_drop, float* __restrict__ H1, float* __restrict__ fac,
+    float* __restrict__ logits, float* __restrict__ dP, float* __restrict__ slab) {
+  constexpr int KT = H / 16, JT = H2 / 16;
+  constexpr int HBR = H > 128 ? 8 : HB_R;
+  constexpr int TPR = 256 / HBR;
+  constexpr int NSM = H2 + C * H2 + C;
+  constexpr int LDW = H + 4;                          // padded weight rows: lanes j -> banks 4j + k
+  static_assert(H % 16 == 0 && H2 % 16 == 0 && KT % 2 == 0 && NSM <= 512, "head shape");
+  __shared__ __attribute__((aligned(16))) float w1[H2 * LDW];
+  __shared__ float w2[C * H2];
+  __shared__ __attribute__((aligned(16))) float pl[HBR * H];
+  __shared__ float dh[HBR * H2], hl[HBR * H2], fl[HBR * H2], dl[HBR * C], lg[HBR * C];
+  __shared__ int cnt[256];
+  __shared__ double lred[HBR];
+  const int t = threadIdx.x;
+  if (drop.dev_key) drop.key1 ^= drop.dev_key[0];
+  if ((reinterpret_cast<uintptr_t>(W1) & 15) == 0) {     // 16-byte loads, eight in flight
+    constexpr int N4 = H2 * H / 4;
+    for (int i0 = t; i0 < N4; i0 += 8 * 256) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        v[u] = i0 + u * 256 < N4 ? reinterpret_cast<const float4*>(W1)[i0 + u * 256] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = 4 * (i0 + u * 256);
+        if (i < H2 * H) *reinterpret_cast<float4*>(w1 + (i / H) * LDW + i % H) = v[u];
+      }
+    }
+  } else {
+    for (int i = t; i < H2 * H; i += 256) w1[(i / H) * LDW + i % H] = W1[i];
+  }
+  for (int i = t; i < C * H2; i += 256) w2[i] = W2[i];
+  // V = number of rows that count (k_ce_fwd), bit 30 = a label outside [0, C) other than -100
+  {
+    int valid = 0, bad = 0;
+    for (int i = t; i < B; i += 256) {
+      const int64_t lab = labels[i];
+      if (lab == CE_IGNORE) continue;
+      if (lab < 0 || lab >= C) bad = 1; else ++valid;
+    }
+    cnt[t] = valid | (bad << 30);
+    __syncthreads();
+    for (int sft = 128; sft > 0; sft >>= 1) {
+      if (t < sft) {
+        const int a = cnt[t], b = cnt[t + sft];
+        cnt[t] = ((a & 0x3FFFFFFF) + (b & 0x3FFFFFFF)) | ((a | b) & (1 << 30));
+      }
+      __syncthreads();
+    }
+  }
+  const int total = cnt[0] & 0x3FFFFFFF;
+  const bool any_bad = (cnt[0] >> 30) & 1;
+  const float nanv = __int_as_float(0x7FC00000);
+  const float invv = 1.0f / (float)total;
+  double lacc = 0.0;                                   // thread rl < HBR: loss of its rows
+
+  const int tj = t >> 4, tk = t & 15;                 // dW1 patch: rows JT*tj.., columns KT*tk..
+  float gw1[JT][KT];
+#pragma unroll
+  for (int a = 0; a < JT; ++a)
+#pragma unroll
+    for (int b = 0; b < KT; ++b) gw1[a][b] = 0.f;
+  float gsm[2] = {0.f, 0.f};                           // elements t and t + 256 of db1 | dW2 | db2
+  for (int r0 = blockIdx.x * HBR; r0 < B; r0 += gridDim.x * HBR) {
+    __syncthreads();
+    for (int i = t; i < HBR * H / 4; i += 256) {
+      const int r = r0 + i / (H / 4);
+      *reinterpret_cast<float4*>(pl + 4 * i) =
+          r < B ? *reinterpret_cast<const float4*>(P + (int64_t)r0 * H + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    // ---- forward: h = drop(relu(P W1^T + b1))   (k_head_fwd: the same fmaf chain over k, the same hash)
+    for (int i = t; i < HBR * H2; i += 256) {
+      const int rl = i / H2, j = i % H2, r = r0 + rl;
+      float z = b1[j];
+      const float* wr = w1 + j * LDW;
+      const float* pr = pl + rl * H;
+#pragma unroll 4
+      for (int k = 0; k < H; k += 4) {
+        const float4 pv = *reinterpret_cast<const float4*>(pr + k);
+        const float4 wv = *reinterpret_cast<const float4*>(wr + k);
+        z = fmaf(pv.x, wv.x, z); z = fmaf(pv.y, wv.y, z); z = fmaf(pv.z, wv.z, z); z = fmaf(pv.w, wv.w, z);
+      }
+      float f = z > 0.f ? 1.f : 0.f;
+      if (use_drop) {
+        const uint32_t e = (uint32_t)r * (uint32_t)H2 + (uint32_t)j;
+        const uint32_t hsh = hmix32(hmix32(e ^ drop.key0) + drop.key1);
+        f = ((hsh & 0xFFFFu) >= drop.thr16) ? f * drop.scale : 0.f;
+      }
+      const float hv = r < B ? z * f : 0.f;
+      hl[i] = hv;
+      fl[i] = r < B ? f : 0.f;
+      if (r < B) {
+        H1[(int64_t)r * H2 + j] = hv;
+        fac[(int64_t)r * H2 + j] = f;
+      }
+    }
+    __syncthreads();
+    // ---- logits = h W2^T + b2
+    if (t < HBR * C) {
+      const int rl = t / C, c = t % C, row = r0 + rl;
+      float acc = b2[c];
+      for (int k = 0; k < H2; ++k) acc = fmaf(hl[rl * H2 + k], w2[c * H2 + k], acc);
+      lg[t] = acc;
+      if (row < B) logits[(int64_t)row * C + c] = acc;
+    }
+    __syncthreads();
+    // ---- cross-entropy of the chunk's rows and its gradient (k_ce_fwd's formulas)
+    if (t < HBR) {
+      const int row = r0 + t;
+      float* drow = dl + t * C;
+#pragma unroll
+      for (int c = 0; c < C; ++c) drow[c] = 0.f;
+      if (row < B) {
+        const int64_t lab = labels[row];
+        const float* lr = lg + t * C;
+        if (lab == CE_IGNORE) {
+        } else if (lab < 0 || lab >= C) {
+#pragma unroll
+          for (int c = 0; c < C; ++c) drow[c] = nanv;
+        } else {
+          float m = lr[0];
+#pragma unroll
+          for (int c = 1; c < C; ++c) m = fmaxf(m, lr[c]);
+          float se = 0.f;
+#pragma unroll
+          for (int c = 0; c < C; ++c) se += expf(lr[c] - m);
+          const float lse = m + logf(se);
+          lacc += (double)(lse - lr[lab]);
+#pragma unroll
+          for (int c = 0; c < C; ++c) drow[c] = (expf(lr[c] - lse) - (c == (int)lab ? 1.f : 0.f)) * invv;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- backward (k_head_bwd_t)
+    for (int i = t; i < HBR * H2; i += 256) {
+      const int rl = i / H2, j = i % H2;
+      float d = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) d = fmaf(dl[rl * C + c], w2[c * H2 + j], d);
+      dh[i] = d * fl[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pc = 0; pc < (H / 4 + TPR - 1) / TPR; ++pc) {
+      const int rl = t / TPR, k4 = (t % TPR) + TPR * pc;
+      if (r0 + rl < B && k4 < H / 4) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+        for (int j = 0; j < H2; ++j) {
+          const float d = dh[rl * H2 + j];
+          const float4 w = *reinterpret_cast<const float4*>(w1 + j * LDW + 4 * k4);
+          a.x = fmaf(d, w.x, a.x); a.y = fmaf(d, w.y, a.y); a.z = fmaf(d, w.z, a.z); a.w = fmaf(d, w.w, a.w);
+        }
+        *reinterpret_cast<float4*>(dP + (int64_t)(r0 + rl) * H + 4 * k4) = a;
+      }
+    }
+#pragma unroll 4
+    for (int rl = 0; rl < HBR; ++rl) {
+      float dv[JT], pv[KT];
+#pragma unroll
+      for (int a = 0; a < JT; ++a) dv[a] = dh[rl * H2 + JT * tj + a];
+#pragma unroll
+      for (int b = 0; b < KT; b += 2) {
+        const float2 p2 = *reinterpret_cast<const float2*>(pl + rl * H + KT * tk + b);
+        pv[b] = p2.x; pv[b + 1] = p2.y;
+      }
+#pragma unroll
+      for (int a = 0; a < JT; ++a)
+#pragma unroll
+        for (int b = 0; b < KT; ++b) gw1[a][b] = fmaf(dv[a], pv[b], gw1[a][b]);
+    }
+#pragma unroll
+    for (int u = 0; u < (NSM + 255) / 256; ++u) {
+      const int e = t + 256 * u;
+      if (e < H2) {
+        for (int rl = 0; rl < HBR; ++rl) gsm[u] += dh[rl * H2 + e];
+      } else if (e < H2 + C * H2) {
+        const int q = e - H2, c = q / H2, j = q % H2;
+        for (int rl = 0; rl < HBR; ++rl) gsm[u] = fmaf(dl[rl * C + c], hl[rl * H2 + j], gsm[u]);
+      } else if (e < NSM) {
+        const int c = e - H2 - C * H2;
+        for (int rl = 0; rl < HBR; ++rl) gsm[u] += dl[rl * C + c];
+      }
+    }
+  }
+  if (t < HBR) lred[t] = lacc;
+  __syncthreads();
+  float* out = slab + (int64_t)blockIdx.x * (H2 * H + NSM + 1);
+#pragma unroll
+  for (int a = 0; a < JT; ++a)
+#pragma unroll
+    for (int b = 0; b < KT; ++b) out[(JT * tj + a) * H + KT * tk + b] = gw1[a][b];
+#pragma unroll
+  for (int u = 0; u < (NSM + 255) / 256; ++u)
+    if (t + 256 * u < NSM) out[H2 * H + t + 256 * u] = gsm[u];
+  if (t == 0) {
+    double sum = 0.0;
+    for (int i = 0; i < HBR; ++i) sum += lred[i];
+    out[H2 * H + NSM] = any_bad ? nanv : (float)(sum / (double)total);
+  }
+}
+
 constexpr size_t HEAD_LDS_MAX = 160 * 1024;
 size_t head_fwd_lds(int H, int H2) {
   const int RB = HTHR / H2;
@@ -492,6 +711,32 @@ int cgnn_head_bwd_f32(const float* dlogits, const float* P, const float* H1, con
   if (lds > 64 * 1024 && !head_allow_lds()) return CGNN_ELAUNCH;
   k_head_bwd<<<head_grid(B, H2), HTHR, lds, cgnn_stream(stream)>>>(dlogits, P, H1, fac, B, H, H2, C, W1,
                                                                  W2, dP, slab);
+  CGNN_CHECK_LAUNCH();
+  return CGNN_OK;
+}
+
+int cgnn_head_loss_f32(const float* P, int32_t B, int32_t H, int32_t H2, int32_t C, const float* W1,
+                       const float* b1, const float* W2, const float* b2, const int64_t* labels,
+                       float p_drop, uint64_t seed, const uint32_t* seed_dev, float* H1, float* fac,
+                       float* logits, float* dP, float* slab, void* stream) {
+  if (B <= 0 || p_drop < 0.f || p_drop >= 1.f) return CGNN_EINVAL;
+  if (!head_ok(H, H2, C) || !head_tiled(H, H2, C)) return CGNN_EUNSUPPORTED;
+  if (!P || !W1 || !b1 || !W2 || !b2 || !labels || !H1 || !fac || !logits || !dP || !slab) return CGNN_EINVAL;
+  HeadDrop d;
+  double thr = (double)p_drop * 65536.0 + 0.5;
+  if (thr > 65535.0) thr = 65535.0;
+  d.thr16 = (uint32_t)thr;
+  d.scale = p_drop > 0.f ? (float)(1.0 / (1.0 - (double)p_drop)) : 1.0f;
+  d.key0 = (uint32_t)(seed & 0xFFFFFFFFu) * 0x9E3779B9u + 0x7F4A7C15u;
+  d.key1 = (uint32_t)(seed >> 32) ^ 0x94D049BBu;
+  d.dev_key = seed_dev;
+  const int use = p_drop > 0.f ? 1 : 0;
+  const int tg = head_bwd_grid(B, H, H2, C);
+  hipStream_t st = cgnn_stream(stream);
+  if (H == 64) k_head_loss_t<64, 32, 2><<<tg, 256, 0, st>>>(P, B, W1, b1, W2, b2, labels, d, use, H1, fac, logits, dP, slab);
+  else if (H == 128) k_head_loss_t<128, 64, 2><<<tg, 256, 0, st>>>(P, B, W1, b1, W2, b2, labels, d, use, H1, fac, logits, dP, slab);
+  else if (H == 256) k_head_loss_t<256, 128, 2><<<tg, 256, 0, st>>>(P, B, W1, b1, W2, b2, labels, d, use, H1, fac, logits, dP, slab);
+  else k_head_loss_t<32, 16, 2><<<tg, 256, 0, st>>>(P, B, W1, b1, W2, b2, labels, d, use, H1, fac, logits, dP, slab);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }

@@ -126,7 +126,7 @@ class GraphedTrainStep:
     def _fwd_bwd(self) -> torch.Tensor:
         self._zero()
         batch = self.batch if self.make_batch is None else self.make_batch()
-        loss = self.loss_fn(self.model(batch), batch.labels)
+        loss = ops.model_loss(self.model, self.loss_fn, batch)
         ops.backward_unit(loss)
         return loss.detach()
 

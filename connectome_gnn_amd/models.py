@@ -206,6 +206,19 @@ class _ConnectomeModel(nn.Module):
                 x = F.dropout(x, p=self.dropout, training=self.training)
         return ops.pool_mean(x, s.gptr, batch.num_graphs)
 
+    def forward_loss(self, batch: ConnectomeBatch):
+        """(logits, mean cross-entropy against batch.labels) with the classifier, the loss and their
+        backward in ONE launch (ops.head_loss) -- the Trainer's step, reference train.py:48-50 -- or None
+        when the head is not one of that kernel's shapes or the model is not training on a GPU batch."""
+        if not (self.training and batch.node_features.is_cuda and batch.labels is not None
+                and ops.head_loss_supported(self.classifier)):
+            return None
+        pooled = self.encode(batch)
+        rng = getattr(self, "rng_device_state", None)
+        word = None if rng is None else rng.data_ptr() + 4 * len(self.convs)
+        rec = self.last_dropout if self.record_dropout else None
+        return ops.head_loss(self.classifier, pooled, batch.labels, True, word, rec)
+
     def forward(self, batch: ConnectomeBatch) -> torch.Tensor:
         """Class logits [B, num_classes]."""
         pooled = self.encode(batch)

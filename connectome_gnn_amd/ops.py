@@ -716,6 +716,105 @@ class _Head(torch.autograd.Function):
                 None, None, None, None)
 
 
+class _HeadLoss(torch.autograd.Function):
+    """(logits, loss) = the classifier and the batch-mean cross-entropy, with the whole backward of both
+    done in the same launch (cgnn_head_loss_f32): the loss's upstream gradient in a training step is the
+    unit, so dP and the parameter gradients are known when the forward ends.  backward() hands them out
+    (scaled when the upstream gradient is not the unit); a gradient arriving through `logits` as well goes
+    through cgnn_head_bwd_f32 on top."""
+
+    @staticmethod
+    def forward(ctx, p, w1, b1, w2, b2, labels, p_drop, training, rng_word, record=None):
+        lib = _lib.load()
+        p, w1, b1, w2, b2 = (_prep(t, "head tensor") for t in (p, w1, b1, w2, b2))
+        _require_device(labels, "labels")
+        if labels.dtype != torch.int64:
+            raise TypeError(f"labels must be int64, got {labels.dtype}")
+        bsz, h = p.shape
+        h2, c = w1.shape[0], w2.shape[0]
+        dev = p.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        p_eff = float(p_drop) if training else 0.0
+        seed = _lib.next_seed(dev) if p_eff > 0 else 0
+        wd = h2 * h + h2 + c * h2 + c
+        h1, fac = torch.empty(bsz, h2, **f32), torch.empty(bsz, h2, **f32)
+        logits, dp = torch.empty(bsz, c, **f32), torch.empty_like(p)
+        flat = torch.empty(wd + 1, **f32)
+        with _lib.device_guard(dev):
+            rows = int(lib.cgnn_head_grid(bsz, h, h2, c))
+            slab = torch.empty(rows, wd + 1, **f32)
+            sp = _lib.stream_ptr()
+            _lib.check(lib.cgnn_head_loss_f32(_lib.ptr(p), bsz, h, h2, c, _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2),
+                                              _lib.ptr(b2), _lib.ptr(labels.contiguous()), p_eff, seed,
+                                              rng_word if p_eff > 0 else None, _lib.ptr(h1), _lib.ptr(fac),
+                                              _lib.ptr(logits), _lib.ptr(dp), _lib.ptr(slab), sp), "cgnn_head_loss_f32")
+            _lib.check(lib.cgnn_slab_reduce_f32(_lib.ptr(slab), rows, 1, wd + 1, wd + 1, _lib.ptr(flat), wd + 1, sp),
+                       "cgnn_slab_reduce_f32")
+        if record is not None:
+            record["head_factor"] = fac
+        ctx.save_for_backward(p, w1, w2, h1, fac, dp, flat)
+        ctx.set_materialize_grads(False)
+        return logits, flat[wd]
+
+    @staticmethod
+    def backward(ctx, dlogits, g):
+        p, w1, w2, h1, fac, dp, flat = ctx.saved_tensors
+        bsz, h = p.shape
+        h2, c = w1.shape[0], w2.shape[0]
+        o1, o2, o3 = h2 * h, h2 * h + h2, h2 * h + h2 + c * h2
+        wd = o3 + c
+        outs = None
+        if g is not None:
+            if not _is_unit_grad(g):
+                dp, flat = dp * g, flat * g
+            outs = [dp, flat[:o1].view(h2, h), flat[o1:o2], flat[o2:o3].view(c, h2), flat[o3:wd]]
+        if dlogits is not None:                   # a second consumer of the logits: the ordinary backward on top
+            lib = _lib.load()
+            dl = _prep(dlogits, "grad")
+            with _lib.device_guard(p.device):
+                rows = int(lib.cgnn_head_grid(bsz, h, h2, c))
+                slab = torch.empty(rows, wd, dtype=torch.float32, device=p.device)
+                dp2 = torch.empty_like(p)
+                fl2 = torch.empty(wd, dtype=torch.float32, device=p.device)
+                _lib.check(lib.cgnn_head_bwd_f32(_lib.ptr(dl), _lib.ptr(p), _lib.ptr(h1), _lib.ptr(fac), bsz, h, h2, c,
+                                                 _lib.ptr(w1), _lib.ptr(w2), _lib.ptr(dp2), _lib.ptr(slab),
+                                                 _lib.stream_ptr()), "cgnn_head_bwd_f32")
+                _lib.check(lib.cgnn_slab_reduce_f32(_lib.ptr(slab), rows, 1, wd, wd, _lib.ptr(fl2), wd,
+                                                    _lib.stream_ptr()), "cgnn_slab_reduce_f32")
+            extra = [dp2, fl2[:o1].view(h2, h), fl2[o1:o2], fl2[o2:o3].view(c, h2), fl2[o3:]]
+            outs = extra if outs is None else [a + b for a, b in zip(outs, extra)]
+        if outs is None:
+            outs = [None] * 5
+        return (*outs, None, None, None, None, None)
+
+
+def head_loss_supported(classifier) -> bool:
+    """head_supported and one of the register-tiled shapes of cgnn_head_loss_f32 (two classes,
+    hidden = 2 x the classifier's inner width in {32, 64, 128, 256}) -- the reference's default head."""
+    if not head_supported(classifier):
+        return False
+    l1, l2 = classifier[0], classifier[3]
+    return l2.out_features == 2 and l1.in_features == 2 * l1.out_features and l1.in_features in (32, 64, 128, 256)
+
+
+def head_loss(classifier, pooled, labels, training: bool, rng_word=None, record=None):
+    """(logits, mean cross-entropy) of head_loss_supported classifiers in one launch each way."""
+    l1, _, drop, l2 = classifier
+    return _HeadLoss.apply(pooled, l1.weight, l1.bias, l2.weight, l2.bias, labels, drop.p, training, rng_word, record)
+
+
+def model_loss(model, loss_fn, batch) -> torch.Tensor:
+    """loss_fn(model(batch), batch.labels) -- the training step's loss, reference train.py:48-49 -- through
+    the model's fused classifier + loss launch when loss_fn is this package's CrossEntropyLoss (mean
+    reduction, torch's defaults) and the model offers it for this batch."""
+    fused = getattr(model, "forward_loss", None)
+    if fused is not None and type(loss_fn) is CrossEntropyLoss:
+        out = fused(batch)
+        if out is not None:
+            return out[1]
+    return loss_fn(model(batch), batch.labels)
+
+
 def head_supported(classifier) -> bool:
     """The reference's head layout: Sequential(Linear, ReLU, Dropout, Linear) at a covered width."""
     import torch.nn as nn

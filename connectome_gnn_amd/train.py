@@ -201,7 +201,7 @@ class Trainer:
             self.grad_sync.zero_grad()       # keeps .grad as views of the all-reduce buffer
         else:
             self.optimizer.zero_grad()
-        loss = self.loss_fn(self.model(batch), batch.labels)
+        loss = ops.model_loss(self.model, self.loss_fn, batch)
         ops.backward_unit(loss)
         if isinstance(self.grad_sync, cdist.GradSync):
             self.grad_sync(local_graphs=batch.num_graphs)     # exact with unequal shards

@@ -691,6 +691,66 @@ def _csr_apply_f64(rowptr, col, coef, selfc, rowdiv, bias, x):
     return y
 
 
+@pytest.mark.parametrize("h,bsz,p", [(64, 512, 0.3), (64, 37, 0.0), (128, 300, 0.3), (256, 64, 0.3), (32, 1, 0.0),
+                                     (64, 4096, 0.3)])
+def test_head_loss_one_launch_equals_head_then_cross_entropy(h, bsz, p):
+    """cgnn_head_loss_f32 (classifier forward + mean cross-entropy + the backward of both in one launch)
+    against ops.head followed by ops.cross_entropy: logits, dP and the recorded dropout factors bit for
+    bit (the same arithmetic row by row, the same hash), the loss to fp32 rounding of a different fold, the
+    parameter gradients to the rounding of another chunking of the row sums; ignore_index rows and an
+    out-of-range label behave as in cgnn_cross_entropy_f32; a second consumer of the logits adds up."""
+    from connectome_gnn_amd import ops
+    g = torch.Generator().manual_seed(h + bsz)
+    clf = torch.nn.Sequential(torch.nn.Linear(h, h // 2), torch.nn.ReLU(), torch.nn.Dropout(p),
+                              torch.nn.Linear(h // 2, 2)).to(DEV)
+    assert ops.head_loss_supported(clf)
+    pooled = torch.randn(bsz, h, generator=g).to(DEV).requires_grad_(True)
+    labels = torch.randint(0, 2, (bsz,), generator=g).to(DEV)
+    if bsz > 8:
+        labels[3] = -100
+    word = torch.tensor([0x1234], dtype=torch.int32, device=DEV)
+    from connectome_gnn_amd import _lib
+
+    def run(fused, extra=False):
+        for q in clf.parameters():
+            q.grad = None
+        pooled.grad = None
+        rec = {}
+        if fused:
+            logits, loss = ops.head_loss(clf, pooled, labels, True, word.data_ptr(), rec)
+        else:
+            logits = ops.head(clf, pooled, True, word.data_ptr(), rec)
+            loss = ops.cross_entropy(logits, labels)
+        tot = loss + (logits * logits).sum() * 0.01 if extra else loss
+        if extra:
+            tot.backward()
+        else:
+            ops.backward_unit(loss)
+        return logits.detach(), loss.detach(), pooled.grad.clone(), [q.grad.clone() for q in clf.parameters()], rec
+
+    orig = _lib.next_seed
+    try:
+        _lib.next_seed = lambda dev: 0x5EED5EED12345678          # the same dropout words for both forms
+        a = run(False)
+        b = run(True)
+        c = run(False, extra=True)
+        d = run(True, extra=True)
+    finally:
+        _lib.next_seed = orig
+    assert torch.equal(a[0], b[0]) and torch.equal(a[4]["head_factor"], b[4]["head_factor"])
+    assert torch.equal(a[2], b[2])                       # dP: row-local, the same chain
+    torch.testing.assert_close(b[1], a[1], rtol=2e-6, atol=1e-7)
+    for x, y in zip(a[3], b[3]):
+        torch.testing.assert_close(y, x, rtol=2e-5, atol=2e-7)
+    torch.testing.assert_close(d[2], c[2], rtol=2e-5, atol=1e-7)
+    for x, y in zip(c[3], d[3]):
+        torch.testing.assert_close(y, x, rtol=2e-5, atol=2e-6)
+    if bsz > 8:
+        assert float(b[2][3].abs().max()) == 0.0         # ignored row: no gradient
+        labels[5] = 7                                    # torch raises; the kernels turn the loss into NaN
+        assert torch.isnan(run(True)[1]) and torch.isnan(run(False)[1])
+
+
 @pytest.mark.parametrize("p", [0.0, 0.3])
 def test_aggregate_tiled_with_bn_prologue_equals_two_passes(p):
     """cgnn_aggregate_tiled_bn_f32 (BatchNorm + dropout of the input applied while the tiles are
