@@ -168,8 +168,11 @@ class GraphedResidentStep(GraphedTrainStep):
         self._b, self._lib = b, _lib
         self.order_buf = torch.zeros(max(int(cache.dataset.num_subjects), b), dtype=torch.long, device=dev)
         self.order_buf[:b].copy_(first_batch._ids)
-        self.cursor = torch.zeros(1, dtype=torch.long, device=dev)
-        self.tally = torch.zeros(1, dtype=torch.float32, device=dev)       # sum of loss x graphs since take_tally()
+        # cursor (int64) and tally (fp32: sum of loss x graphs since take_tally()) share one 16-byte block, so
+        # an epoch resets both with one fill
+        self._state = torch.zeros(2, dtype=torch.long, device=dev)
+        self.cursor = self._state[:1]
+        self.tally = self._state[1:].view(torch.float32)[:1]
         self.ids_buf = self.order_buf[:b]                                   # (the window at cursor 0)
         cache.static(b)                                    # batch-size constants exist before capture
         super().__init__(model, optimizer, first_batch, loss_fn,
@@ -198,14 +201,14 @@ class GraphedResidentStep(GraphedTrainStep):
         n = steps * self._b
         if int(ids.numel()) != n or n > int(self.order_buf.numel()):
             raise ValueError("run_epoch: ids must hold steps x batch_size subject ids (at most the dataset's size)")
-        self.order_buf[:n].copy_(ids, non_blocking=True)
-        self.cursor.zero_()
-        self.tally.zero_()              # (single-batch calls in between also fed it: their losses were read directly)
+        self.order_buf[:n].copy_(ids, non_blocking=True)      # (ids may be pinned host memory: one upload per epoch)
+        self._state.zero_()             # cursor and tally (single-batch calls in between also fed the tally:
+                                        # their losses were read directly)
         for _ in range(steps):
             super().__call__()
 
     def take_tally(self) -> torch.Tensor:
         """Sum of loss x graphs over the replays since the last call (device scalar); resets it."""
-        out = self.tally.clone()
+        out = self.tally.clone()        # (run_epoch resets the tally itself; a second take reads zero only after that)
         self.tally.zero_()
         return out.reshape(())

@@ -89,8 +89,9 @@ class ResidentDataLoader:
         dev = self.dataset.x.device
         if dev.type == "cuda":
             # (from pinned memory, asynchronously: a pageable upload would make the host wait for every
-            # step already queued on this stream -- one pipeline bubble per epoch)
-            order = order.pin_memory().to(dev, non_blocking=True)
+            # step already queued on this stream -- one pipeline bubble per epoch.  Two pinned staging
+            # buffers used in turn, each guarded by the event of its last upload: no allocation per epoch)
+            order = self._upload(order, dev)
         for lo in range(0, n, self.batch_size):
             hi = min(n, lo + self.batch_size)
             if self.world_size > 1:
@@ -99,6 +100,21 @@ class ResidentDataLoader:
                 run = shard_slice(range(lo, hi), self.rank, self.world_size)   # a contiguous run
                 lo, hi = run.start, run.stop
             yield order[lo:hi]
+
+    def _upload(self, order: torch.Tensor, dev) -> torch.Tensor:
+        ring = self.__dict__.setdefault("_pinned", [])
+        if len(ring) < 2 or ring[0][0].numel() != order.numel():
+            ring[:] = [[torch.empty(order.numel(), dtype=order.dtype).pin_memory(), None] for _ in range(2)]
+            self._pin_turn = 0
+        slot = ring[self._pin_turn]
+        self._pin_turn ^= 1
+        if slot[1] is not None:
+            slot[1].synchronize()                  # the upload that last read this buffer (two epochs ago)
+        slot[0].copy_(order)
+        out = slot[0].to(dev, non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record(torch.cuda.current_stream(dev))
+        return out
 
     def __iter__(self):
         if self.structure_cache is not None and not self.cache_batches:

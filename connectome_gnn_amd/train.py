@@ -30,6 +30,19 @@ from . import dist as cdist
 from . import ops
 
 
+def _joined(run) -> torch.Tensor:
+    """The ids of consecutive chunks as one tensor: a view when they are adjacent slices of one array (what an
+    unsharded loader yields), else a concatenation."""
+    first = run[0]
+    end = first.storage_offset() + first.numel()
+    for c in run[1:]:
+        if c.untyped_storage().data_ptr() != first.untyped_storage().data_ptr() or c.storage_offset() != end \
+                or not c.is_contiguous():
+            return torch.cat(run)
+        end += c.numel()
+    return torch.as_strided(first, (end - first.storage_offset(),), (1,))
+
+
 class _DeviceTally:
     """Sum of per-batch quantities weighted by graphs per batch, kept on the device."""
 
@@ -118,6 +131,10 @@ class Trainer:
         """Per-epoch sums as host floats + the graph count, identical on every rank: summed over
         ranks when the loader hands each rank its own shard, rank 0's values otherwise."""
         vals = [t.total if t.total is not None else torch.zeros((), device=self.device) for t in tallies]
+        if not self._data_parallel():                        # nothing to agree on: one read-back, no staging
+            if len(vals) == 1:
+                return [float(vals[0])], tallies[0].graphs
+            return torch.stack([v.detach().double().reshape(()) for v in vals]).tolist(), tallies[0].graphs
         vec = torch.stack([v.detach().double().reshape(()) for v in vals]
                           + [torch.tensor(float(tallies[0].graphs), dtype=torch.float64, device=vals[0].device)])
         if self._data_parallel():
@@ -237,7 +254,7 @@ class Trainer:
                     tally.add_scaled(self.train_step(ResidentBatch(cache, c), _borrow=True), size)
             else:
                 run = chunks[i:j]
-                ids = run[0] if len(run) == 1 else torch.cat(run)
+                ids = run[0] if len(run) == 1 else _joined(run)
                 step.run_epoch(ids.to(step.order_buf.device), len(run))
                 tally.add(step.take_tally(), size * len(run))
             i = j
