@@ -119,6 +119,7 @@ PROTOTYPES = {
     "cgnn_head_grid": (c_int, [I32, I32, I32, I32]),
     "cgnn_head_fwd_f32": (c_int, [P, I32, I32, I32, I32, P, P, P, P, F32, U64, P, P, P, P, P]),
     "cgnn_head_bwd_f32": (c_int, [P, P, P, P, I32, I32, I32, I32, P, P, P, P, P]),
+    "cgnn_head_loss_grid": (c_int, [I32, I32, I32, I32]),
     "cgnn_head_loss_f32": (c_int, [P, I32, I32, I32, I32, P, P, P, P, P, F32, U64, P, P, P, P, P, P, P]),
     "cgnn_cross_entropy_f32": (c_int, [P, P, I32, I32, P, P, P]),
     "cgnn_dense_adj_f16": (c_int, [P, P, P, P, P, I32, I32, P, P]),

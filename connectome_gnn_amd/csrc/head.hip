@@ -402,14 +402,13 @@ __global__ void __launch_bounds__(CETHR) k_ce_fwd(const float* __restrict__ logi
 // its slab row: the slab fold that produces the gradients also produces the loss.  Three launches
 // (7.5 + 4.8 + 7.0 us at 512 graphs) become one.
 // Slab row: dW1 [H2*H] | db1 [H2] | dW2 [C*H2] | db2 [C] | loss share [1].
-template <int H, int H2, int C>
+template <int H, int H2, int C, int HBR>
 __global__ void __launch_bounds__(256) k_head_loss_t(
     const float* __restrict__ P, int B, const float* __restrict__ W1, const float* __restrict__ b1,
     const float* __restrict__ W2, const float* __restrict__ b2, const int64_t* __restrict__ labels,
     HeadDrop drop, int use_drop, float* __restrict__ H1, float* __restrict__ fac,
     float* __restrict__ logits, float* __restrict__ dP, float* __restrict__ slab) {
   constexpr int KT = H / 16, JT = H2 / 16;
-  constexpr int HBR = H > 128 ? 8 : HB_R;
   constexpr int TPR = 256 / HBR;
   constexpr int NSM = H2 + C * H2 + C;
   constexpr int LDW = H + 4;                          // padded weight rows: lanes j -> banks 4j + k
@@ -639,6 +638,15 @@ bool head_allow_lds() {
   return true;
 }
 
+// rows per chunk of k_head_loss_t: H = 256 keeps the whole 128 KB weight in LDS, so few rows fit beside it;
+// small batches take 2-row chunks so that a 64-graph batch spreads over 32 workgroups instead of 8
+int head_loss_rows(int B, int H) { return H > 128 ? (B <= 128 ? 2 : 8) : HB_R; }
+int head_loss_grid(int B, int H) {
+  const int rows = head_loss_rows(B, H);
+  const int g = (B + rows - 1) / rows;
+  return g < 1 ? 1 : (g > HB_MAX_GRID ? HB_MAX_GRID : g);
+}
+
 int head_grid(int B, int H2) {
   const int RB = HTHR / H2;
   int g = (B + RB - 1) / RB;
@@ -715,6 +723,11 @@ int cgnn_head_bwd_f32(const float* dlogits, const float* P, const float* H1, con
   return CGNN_OK;
 }
 
+int cgnn_head_loss_grid(int32_t B, int32_t H, int32_t H2, int32_t C) {
+  if (B < 0 || !head_ok(H, H2, C) || !head_tiled(H, H2, C)) return CGNN_EINVAL;
+  return head_loss_grid(B, H);
+}
+
 int cgnn_head_loss_f32(const float* P, int32_t B, int32_t H, int32_t H2, int32_t C, const float* W1,
                        const float* b1, const float* W2, const float* b2, const int64_t* labels,
                        float p_drop, uint64_t seed, const uint32_t* seed_dev, float* H1, float* fac,
@@ -731,12 +744,16 @@ int cgnn_head_loss_f32(const float* P, int32_t B, int32_t H, int32_t H2, int32_t
   d.key1 = (uint32_t)(seed >> 32) ^ 0x94D049BBu;
   d.dev_key = seed_dev;
   const int use = p_drop > 0.f ? 1 : 0;
-  const int tg = head_bwd_grid(B, H, H2, C);
+  const int rows = head_loss_rows(B, H);
+  const int tg = head_loss_grid(B, H);
   hipStream_t st = cgnn_stream(stream);
-  if (H == 64) k_head_loss_t<64, 32, 2><<<tg, 256, 0, st>>>(P, B, W1, b1, W2, b2, labels, d, use, H1, fac, logits, dP, slab);
-  else if (H == 128) k_head_loss_t<128, 64, 2><<<tg, 256, 0, st>>>(P, B, W1, b1, W2, b2, labels, d, use, H1, fac, logits, dP, slab);
-  else if (H == 256) k_head_loss_t<256, 128, 2><<<tg, 256, 0, st>>>(P, B, W1, b1, W2, b2, labels, d, use, H1, fac, logits, dP, slab);
-  else k_head_loss_t<32, 16, 2><<<tg, 256, 0, st>>>(P, B, W1, b1, W2, b2, labels, d, use, H1, fac, logits, dP, slab);
+#define CGNN_HL(HH, R) k_head_loss_t<HH, HH / 2, 2, R><<<tg, 256, 0, st>>>(P, B, W1, b1, W2, b2, labels, d, use, H1, fac, logits, dP, slab)
+  if (H == 64) CGNN_HL(64, 16);
+  else if (H == 128) CGNN_HL(128, 16);
+  else if (H == 256 && rows == 2) CGNN_HL(256, 2);
+  else if (H == 256) CGNN_HL(256, 8);
+  else CGNN_HL(32, 16);
+#undef CGNN_HL
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }

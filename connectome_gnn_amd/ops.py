@@ -741,7 +741,7 @@ class _HeadLoss(torch.autograd.Function):
         logits, dp = torch.empty(bsz, c, **f32), torch.empty_like(p)
         flat = torch.empty(wd + 1, **f32)
         with _lib.device_guard(dev):
-            rows = int(lib.cgnn_head_grid(bsz, h, h2, c))
+            rows = int(lib.cgnn_head_loss_grid(bsz, h, h2, c))
             slab = torch.empty(rows, wd + 1, **f32)
             sp = _lib.stream_ptr()
             _lib.check(lib.cgnn_head_loss_f32(_lib.ptr(p), bsz, h, h2, c, _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2),

@@ -737,10 +737,11 @@ int cgnn_cross_entropy_f32(const float* logits, const int64_t* labels, int32_t B
  * cgnn_head_bwd_f32 (models.py:196-201,213-216 and train.py:46-50 with the loss's unit upstream gradient),
  * the same arithmetic row by row -- for the register-tiled head shapes (C = 2, H = 2 * H2 in {32, 64, 128,
  * 256}; else CGNN_EUNSUPPORTED).  Outputs: H1, fac, logits as the forward; dP [B,H]; slab
- * [cgnn_head_grid(B,H,H2,C)][WD + 1]: the backward's row layout plus one column holding the workgroup's share
+ * [cgnn_head_loss_grid(B,H,H2,C)][WD + 1]: the backward's row layout plus one column holding the workgroup's share
  * of the loss (sum of its rows' losses / V), so cgnn_slab_reduce_f32(slab, rows, 1, WD + 1, WD + 1, out,
  * WD + 1) yields the parameter gradients and out[WD] = the mean loss.  V is counted from `labels` by every
  * workgroup (no cross-workgroup wait); label rules as cgnn_cross_entropy_f32. */
+int cgnn_head_loss_grid(int32_t B, int32_t H, int32_t H2, int32_t C);   /* rows of cgnn_head_loss_f32's slab */
 int cgnn_head_loss_f32(const float* P, int32_t B, int32_t H, int32_t H2, int32_t C, const float* W1,
                        const float* b1, const float* W2, const float* b2, const int64_t* labels,
                        float p_drop, uint64_t seed, const uint32_t* seed_dev, float* H1, float* fac,
