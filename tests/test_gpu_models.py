@@ -707,6 +707,39 @@ def test_cfg5_shape_gcn_1000roi_h256_vs_oracle(dropout):
 
 
 @pytest.mark.parametrize("kind", ["gcn", "sage"])
+def test_ragged_large_graphs_on_the_band_aggregate_vs_oracle(kind):
+    """Graphs of 1000, 333 and 610 nodes at band-like density plus an edgeless and an empty one in one
+    batch (pitch 1024, ragged row blocks, a graph that would fit an LDS tile riding along): the one-node
+    encoders over dense fragments + gather remainder against the oracle, dropout masks replayed."""
+    import connectome_gnn_amd as C
+    graphs = [C.generate_connectome(1000, 80, seed=5), C.generate_connectome(333, 60, seed=6),
+              C.ConnectomeGraph(torch.randn(7, 5), torch.zeros(2, 0, dtype=torch.long), torch.zeros(0), torch.tensor(0)),
+              C.generate_connectome(610, 90, seed=7),
+              C.ConnectomeGraph(torch.zeros(0, 5), torch.zeros(2, 0, dtype=torch.long), torch.zeros(0), torch.tensor(1))]
+    b = C.collate_graphs(graphs)
+    torch.manual_seed(6)
+    m = _model(kind, 5, 128, dropout=0.3)
+    sd0 = {k_: v.clone() for k_, v in m.state_dict().items()}
+    m = m.to(DEV).train()
+    m.record_dropout = True
+    bd = b.to(DEV)
+    lg = m(bd)
+    assert m.impl_used == "fused"
+    s = bd.structure()
+    bf, bb = s.band_ops(kind, s.gcn_norm() if kind == "gcn" else s.sage_norm())
+    assert bf is not None and bb is not None and 0.5 < bf[1].covered < 1.0
+    loss_g = torch.nn.functional.cross_entropy(lg, bd.labels)
+    loss_g.backward()
+    masks = P.recorded_masks(m, b.num_nodes, b.num_graphs)
+    lo, loss_o, g32, st32 = P.oracle_run(kind, sd0, b, 0.3, True, masks)
+    _, _, g64, _ = P.oracle_run(kind, sd0, b, 0.3, True, masks, dtype=torch.float64)
+    torch.testing.assert_close(lg.detach().cpu(), lo, **TOL)
+    floor = P.NoiseFloor(kind, sd0, b, 0.3, masks)
+    for k_, p in m.named_parameters():
+        P.assert_grad(k_, p.grad, g32[k_], g64[k_], f"ragged-band-{kind}", floor)
+
+
+@pytest.mark.parametrize("kind", ["gcn", "sage"])
 def test_graphs_beyond_the_band_builder_take_the_gather_aggregate(kind):
     """A 1100-node graph (more than the 1024 the dense-fragment builder takes) next to a small one and an
     empty one: the one-node encoders run over the plain CSR gather aggregate, against the oracle."""
