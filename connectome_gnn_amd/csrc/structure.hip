@@ -112,9 +112,68 @@ __global__ void k_fill(const int64_t* __restrict__ src, const int64_t* __restric
   eid_src[rowptr_src[s] + atomicAdd(&cur_src[s], 1)] = (int32_t)e;
 }
 
-// One thread per row: restore COO order inside the row (the atomic fill order is arbitrary),
-// then emit the neighbour id of every slot.  Rows are short (in-degree ~k of the
-// Watts-Strogatz graphs), so an insertion sort in place is the cheapest stable choice.
+// One WAVE per row: restore COO order inside the row (the atomic fill order is arbitrary), then emit the
+// neighbour id of every slot.  Edge ids are distinct, so an entry's place is the number of smaller ids in
+// its row: the row's ids go to LDS, every lane ranks its entries against all of them (broadcast reads) and
+// writes them straight to their slots.  One thread per row with an in-place insertion sort (below, kept
+// for rows longer than SR_MAX) took 1.5 ms per ordering on 64 x 1000-ROI graphs at 100 edges per row.
+constexpr int SR_MAX = 1024;
+__global__ void __launch_bounds__(256) k_sort_rows_wave(const int32_t* __restrict__ rowptr, int32_t* eid,
+                                                        const int64_t* __restrict__ other_end,
+                                                        int32_t* __restrict__ col, int64_t nn, int32_t* max_deg) {
+  __shared__ __attribute__((aligned(16))) int32_t keys[4][SR_MAX];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int dmax = 0;
+  for (int64_t r0 = (int64_t)blockIdx.x * 4; r0 < nn; r0 += (int64_t)gridDim.x * 4) {   // (uniform trip count)
+    const int64_t r = r0 + w;
+    int b = 0, deg = 0;
+    if (r < nn) {
+      b = rowptr[r];
+      deg = rowptr[r + 1] - b;
+    }
+    dmax = max(dmax, deg);
+    const bool in_lds = deg <= SR_MAX;
+    const int deg8 = (deg + 7) & ~7;                      // padded with INT_MAX: never smaller than a key
+    if (in_lds)
+      for (int i = lane; i < deg8; i += 64) keys[w][i] = i < deg ? eid[b + i] : 0x7FFFFFFF;
+    __syncthreads();
+    if (in_lds) {
+      for (int i = lane; i < deg; i += 64) {
+        const int key = keys[w][i];
+        int rank = 0;
+        for (int j = 0; j < deg8; j += 8) {               // two broadcast 16-byte reads per step
+          const int4 a = *reinterpret_cast<const int4*>(&keys[w][j]);
+          const int4 c = *reinterpret_cast<const int4*>(&keys[w][j + 4]);
+          rank += (a.x < key) + (a.y < key) + (a.z < key) + (a.w < key) + (c.x < key) + (c.y < key) + (c.z < key) +
+                  (c.w < key);
+        }
+        eid[b + rank] = key;
+        col[b + rank] = (int32_t)other_end[key];
+      }
+    } else {
+      if (lane == 0) {
+        for (int i = b + 1; i < b + deg; ++i) {
+          const int key = eid[i];
+          int j = i - 1;
+          while (j >= b && eid[j] > key) {
+            eid[j + 1] = eid[j];
+            --j;
+          }
+          eid[j + 1] = key;
+        }
+      }
+      __threadfence();                                 // lane 0's stores before the wave's reads of them
+      for (int i = lane; i < deg; i += 64) col[b + i] = (int32_t)other_end[eid[b + i]];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) dmax = max(dmax, __shfl_xor(dmax, o, 64));
+  if (lane == 0 && dmax > 0) atomicMax(max_deg, dmax);
+}
+
+// One thread per row, insertion sort in place: for short rows (in-degree ~k <= 16 of the 84- / 360-ROI
+// Watts-Strogatz graphs) the cheapest stable choice.
 __global__ void k_sort_rows(const int32_t* __restrict__ rowptr, int32_t* eid,
                             const int64_t* __restrict__ other_end, int32_t* col, int64_t nn,
                             int32_t* max_deg) {
@@ -523,10 +582,16 @@ int cgnn_csr_build(const int64_t* edge_index, const int64_t* node_graph, int64_t
                                                 cur_src, eid_dst, eid_src);
     CGNN_CHECK_LAUNCH();
     if (nn > 0) {
-      k_sort_rows<<<blocks_for(nn, 256), 256, 0, st>>>(rowptr_dst, eid_dst, src, col_dst, nn,
-                                                       flags + 2);
-      k_sort_rows<<<blocks_for(nn, 256), 256, 0, st>>>(rowptr_src, eid_src, dst, col_src, nn,
-                                                       flags + 3);
+      if (ne > 24 * nn) {                                  // long rows: a wave per row
+        const unsigned wg = (unsigned)((nn + 3) / 4 < 16384 ? (nn + 3) / 4 : 16384);
+        k_sort_rows_wave<<<wg, 256, 0, st>>>(rowptr_dst, eid_dst, src, col_dst, nn, flags + 2);
+        k_sort_rows_wave<<<wg, 256, 0, st>>>(rowptr_src, eid_src, dst, col_src, nn, flags + 3);
+      } else {
+        k_sort_rows<<<blocks_for(nn, 256), 256, 0, st>>>(rowptr_dst, eid_dst, src, col_dst, nn,
+                                                         flags + 2);
+        k_sort_rows<<<blocks_for(nn, 256), 256, 0, st>>>(rowptr_src, eid_src, dst, col_src, nn,
+                                                         flags + 3);
+      }
       CGNN_CHECK_LAUNCH();
     }
   }

@@ -50,8 +50,27 @@ def _csr_ref(ei, nn_, by):
     return np.cumsum(rowptr), order, ei[1 - by].numpy()[order]
 
 
+def test_csr_build_long_rows_bit_exact():
+    """Rows of ~60 and of > 1024 entries (the wave-per-row rank ordering and its serial tail for rows that
+    do not fit its LDS keys) against numpy's stable argsort, both orderings, generic builder."""
+    from connectome_gnn_amd.structure import BatchStructure
+    ei, w, ptr, bid, nn_ = _rand_graph_batch([1600, 300], 60, 4)
+    hub = torch.stack([torch.arange(1, 1600), torch.zeros(1599, dtype=torch.long)])     # 1599 edges into node 0
+    perm = torch.randperm(ei.shape[1] + 2 * 1599, generator=torch.Generator().manual_seed(9))
+    ei = torch.cat([ei, hub, hub.flip(0)], 1)[:, perm]                                   # ... and out of it
+    w = torch.rand(ei.shape[1], generator=torch.Generator().manual_seed(10)) + 0.05
+    b = _batch(ei, w, ptr, bid, nn_, 4).to(DEV)
+    s = BatchStructure.build(b, force_generic=True)
+    assert ei.shape[1] > 24 * nn_ and s.max_in_degree > 1024 and s.max_out_degree > 1024
+    for by, (rp, eid, col) in ((1, (s.rowptr_dst, s.eid_dst, s.col_dst)), (0, (s.rowptr_src, s.eid_src, s.col_src))):
+        rrp, reid, rcol = _csr_ref(ei, nn_, by)
+        assert np.array_equal(rp.cpu().numpy(), rrp)
+        assert np.array_equal(eid.cpu().numpy(), reid)
+        assert np.array_equal(col.cpu().numpy(), rcol)
+
+
 @pytest.mark.parametrize("sizes,deg", [([20] * 8, 4), ([5, 1, 33, 84, 2], 6), ([360, 360], 14),
-                                       ([1], 0), ([700], 3)])
+                                       ([1], 0), ([700], 3), ([300, 40], 60)])
 def test_csr_build_bit_exact(sizes, deg):
     ei, w, ptr, bid, nn_ = _rand_graph_batch(sizes, max(deg, 1), 1)
     if deg == 0:
