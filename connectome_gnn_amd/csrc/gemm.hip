@@ -374,14 +374,34 @@ int cgnn_linear_bwd_input_f32(const float* dY, int64_t lddy, const float* W, int
   return CGNN_OK;
 }
 
-int64_t cgnn_linear_bwd_weight_workspace_bytes(int64_t M, int32_t N, int32_t K) {
-  if (M < 0 || N <= 0 || K <= 0) return CGNN_EINVAL;
+// fp32 words one cgnn_linear_bwd_weight_f32(M, N, K) call writes into its slab: the generic kernel's row
+// chunks, or the weight-stationary kernel's one partial per workgroup -- for N = 256 two halves of 128
+// rows, one at a time
+static int64_t bwd_weight_slab_words(int64_t M, int32_t N, int32_t K) {
   int64_t nchunks = (M + WCHUNK - 1) / WCHUNK;
   if (nchunks == 0) nchunks = 1;
-  int64_t ws = cgnn_ws_bwd_weight_partials(M, N, K);
-  if (N == 256) ws = (cgnn_ws_bwd_weight_partials(M, 128, K) + 1) / 2;   // halves run one at a time
-  if (ws > nchunks) nchunks = ws;
-  return cgnn_align_up(nchunks * (int64_t)N * K * (int64_t)sizeof(float), 256);
+  int64_t words = nchunks * (int64_t)N * K;
+  const int64_t ws = cgnn_ws_bwd_weight_partials(M, N, K) * (int64_t)N * K;
+  if (ws > words) words = ws;
+  if (N == 256) {
+    const int64_t half = cgnn_ws_bwd_weight_partials(M, 128, K) * (int64_t)128 * K;
+    if (half > words) words = half;
+  }
+  return words;
+}
+
+int64_t cgnn_linear_bwd_weight_workspace_bytes(int64_t M, int32_t N, int32_t K) {
+  if (M < 0 || N <= 0 || K <= 0) return CGNN_EINVAL;
+  int64_t words = bwd_weight_slab_words(M, N, K);
+  // cgnn_linear_bwd_weight2_f32 with two equal panels (K = 2 * K1) falls back to one call per panel when
+  // the joint shape is outside the weight-stationary kernel: each of those may take ITS weight-stationary
+  // form (256 partials of [N x K/2] -- far more than the generic chunks of [N x K]).  GraphSAGE hidden
+  // 256 on >= 4096 nodes wrote 33 MB into a 1 MB slab before this line existed.
+  if (K % 2 == 0) {
+    const int64_t panel = bwd_weight_slab_words(M, N, K / 2);
+    if (panel > words) words = panel;
+  }
+  return cgnn_align_up(words * (int64_t)sizeof(float), 256);
 }
 
 int cgnn_linear_bwd_weight_f32(const float* dY, int64_t lddy, const float* X, int64_t ldx,

@@ -95,7 +95,7 @@ class GcnWideEncode(torch.autograd.Function):
                 slab, srows, y = None, rows, None
                 if li == 0:
                     # narrow input: aggregate first (A_hat (X W^T) == (A_hat X) W^T, models.py:111-114)
-                    pad = fin <= PAD_K and hid in (64, 128) and n_nodes >= PAD_MIN_ROWS
+                    pad = fin <= PAD_K and hid in (64, 128, 256) and n_nodes >= PAD_MIN_ROWS
                     width = PAD_K if pad else fin
                     p0 = torch.zeros(n_nodes, width, dtype=torch.float32, device=dev) if pad \
                         else _f32(dev, n_nodes, fin)

@@ -225,7 +225,7 @@ class SageEncode(torch.autograd.Function):
                 fin = x.shape[1]
                 slab = None
                 srows = rows
-                if li == 0 and 2 * fin <= PAD_K and hid in (64, 128) and n_nodes >= PAD_MIN_ROWS:
+                if li == 0 and 2 * fin <= PAD_K and hid in (64, 128, 256) and n_nodes >= PAD_MIN_ROWS:
                     # narrow input layer: pack [x0 | agg(x0) | 0] and the zero-padded weight into
                     # 32-wide panels so that the tall weight-stationary GEMMs apply (K = 10 would
                     # otherwise run the per-tile kernels at a few % of the matrix-core rate)

@@ -672,17 +672,18 @@ def test_dropout_masks_are_reproducible_under_manual_seed():
 
 
 # ------------------------------------------------------- config 5's model shape against the oracle
-@pytest.mark.parametrize("dropout", [0.0, 0.3])
-def test_cfg5_shape_gcn_1000roi_h256_vs_oracle(dropout):
+@pytest.mark.parametrize("dropout,ngraphs", [(0.0, 3), (0.3, 3), (0.3, 5)])
+def test_cfg5_shape_gcn_1000roi_h256_vs_oracle(dropout, ngraphs):
     """BASELINE config 5's model: 1000-ROI graphs at 10 % density (k = 100), hidden 256, 3 layers;
     graphs > 384 nodes take the large-graph path.  fp32 against the fp32 oracle (the fp16-storage
-    path is validated against this same oracle at fp16 resolution in test_gpu_kernels)."""
+    path is validated against this same oracle at fp16 resolution in test_gpu_kernels).  Five graphs =
+    5000 rows: layer 0 then runs through the packed 32-wide panel of the weight-stationary GEMMs."""
     import connectome_gnn_amd as C
     from connectome_gnn_amd.resident import assemble_batch
     from connectome_gnn_amd.synthetic import generate_packed
-    ds = generate_packed(3, 1000, 100, seed=9)
-    b = assemble_batch(ds, torch.arange(3))
-    assert b.num_nodes == 3000 and b.edge_index.shape[1] == 300_000
+    ds = generate_packed(ngraphs, 1000, 100, seed=9)
+    b = assemble_batch(ds, torch.arange(ngraphs))
+    assert b.num_nodes == 1000 * ngraphs and b.edge_index.shape[1] == 100_000 * ngraphs
     torch.manual_seed(3)
     m = _model("gcn", 5, 256, dropout=dropout)
     sd0 = {k_: v.clone() for k_, v in m.state_dict().items()}
@@ -766,8 +767,8 @@ def test_graphs_beyond_the_band_builder_take_the_gather_aggregate(kind):
         P.assert_grad(k_, p.grad, g32[k_], g64[k_], f"big1100-{kind}", floor)
 
 
-@pytest.mark.parametrize("dropout", [0.0, 0.3])
-def test_sage_1000roi_h128_band_aggregate_vs_oracle(dropout):
+@pytest.mark.parametrize("dropout,hidden,ngraphs", [(0.0, 128, 3), (0.3, 128, 3), (0.3, 256, 5)])
+def test_sage_1000roi_h128_band_aggregate_vs_oracle(dropout, hidden, ngraphs):
     """GraphSAGE on 1000-ROI graphs at 10 % density (BASELINE config 5's graphs), hidden 128: the one-node
     encoder over the large-graph aggregate -- dense fragments of A_w / den as split-bf16 matrix products
     (band_aggregate.hip, with the row division and, in the backward, the dX1 addend), the other edges
@@ -775,10 +776,10 @@ def test_sage_1000roi_h128_band_aggregate_vs_oracle(dropout):
     import connectome_gnn_amd as C
     from connectome_gnn_amd.resident import assemble_batch
     from connectome_gnn_amd.synthetic import generate_packed
-    ds = generate_packed(3, 1000, 100, seed=11)
-    b = assemble_batch(ds, torch.arange(3))
+    ds = generate_packed(ngraphs, 1000, 100, seed=11)
+    b = assemble_batch(ds, torch.arange(ngraphs))
     torch.manual_seed(4)
-    m = _model("sage", 5, 128, dropout=dropout)
+    m = _model("sage", 5, hidden, dropout=dropout)
     sd0 = {k_: v.clone() for k_, v in m.state_dict().items()}
     m = m.to(DEV).train()
     m.record_dropout = True
