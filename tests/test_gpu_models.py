@@ -108,7 +108,16 @@ def test_g7_trainer_trajectory(kind):
 @pytest.mark.parametrize("kind,n,k,hidden,nb", [("gcn", 84, 8, 64, 32), ("sage", 84, 8, 64, 16),
                                                ("gcn", 360, 14, 64, 8), ("sage", 360, 14, 128, 4),
                                                ("gcn", 50, 6, 256, 3), ("sage", 50, 6, 256, 3),
-                                               ("sage", 100, 10, 128, 48), ("gcn", 100, 10, 128, 48)])
+                                               ("sage", 100, 10, 128, 48), ("gcn", 100, 10, 128, 48),
+                                               # >= 4096 rows at hidden 256: every weight-stationary GEMM form
+                                               # (two halves, packed layer-0 panel, per-panel weight gradient)
+                                               ("sage", 100, 10, 256, 48), ("gcn", 100, 10, 256, 48),
+                                               # (16 graphs, not 12: at 12 x 360 rows ONE ReLU pre-activation of
+                                               # GraphSAGE's last layer, channel 133, sits within rounding of 0 and
+                                               # the split-bf16 GEMM lands on the other side of it than every fp32
+                                               # CPU order -- 2 % of that channel's bias gradient, same value on the
+                                               # fused and the layered path; tools/_bin probe)
+                                               ("sage", 360, 14, 256, 16), ("gcn", 360, 14, 256, 16)])
 def test_models_vs_oracle_fresh(kind, n, k, hidden, nb):
     """Seeded fresh inputs (our generator), train mode dropout 0: logits, loss, all grads.
 
