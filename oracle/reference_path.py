@@ -108,14 +108,26 @@ def gcn_layer(x, edge_index, edge_weight, weight, bias):
     return scatter_sum(msg, d, n) + bias                        # :113-114
 
 
-def sage_layer(x, edge_index, edge_weight, weight, bias):
+# ReLU decisions (test hook).  None: F.relu.  Else a callable (site, pre) -> {0,1} mask or None: the
+# parity tests use it to LIST the pre-activations that sit within rounding of zero and to re-evaluate the
+# path with such a tie decided the other way (tests/parity.py: a fp32 evaluation may land on either side
+# of a tie, and one decision carries ~1/N of a gradient) -- the arithmetic is untouched.
+RELU_HOOK = None
+
+
+def _relu(pre, site: str):
+    mask = RELU_HOOK(site, pre) if RELU_HOOK is not None else None
+    return F.relu(pre) if mask is None else pre * mask.to(pre.dtype)
+
+
+def sage_layer(x, edge_index, edge_weight, weight, bias, site: str = "sage"):
     """models.py:136-152.  Weighted mean over in-edges, concat, linear, ReLU."""
     n = x.shape[0]
     s, d = edge_index[0], edge_index[1]
     msg = x[s] * edge_weight.unsqueeze(1)                       # :146
     wsum = torch.zeros(n, 1).scatter_add_(0, d.unsqueeze(1), edge_weight.unsqueeze(1))  # :147-148
     agg = scatter_sum(msg, d, n) / (wsum + 1e-8)                # :149
-    return F.relu(F.linear(torch.cat([x, agg], 1), weight, bias))  # :151-152
+    return _relu(F.linear(torch.cat([x, agg], 1), weight, bias), site)  # :151-152
 
 
 def _bn(x, state: State, i: int, training: bool):
@@ -151,7 +163,7 @@ def _keep(masks: Optional[dict], key: str, i: Optional[int] = None):
 
 
 def _classifier(h, state: State, p: float, training: bool, keep=None):
-    h = F.relu(F.linear(h, state["classifier.0.weight"], state["classifier.0.bias"]))
+    h = _relu(F.linear(h, state["classifier.0.weight"], state["classifier.0.bias"]), "head")
     h = _dropout(h, p, training, keep)
     return F.linear(h, state["classifier.3.weight"], state["classifier.3.bias"])  # :196-201
 
@@ -164,7 +176,7 @@ def gcn_encode(state: State, b: OBatch, dropout: float = 0.3, training: bool = F
         x = gcn_layer(x, b.edge_index, b.edge_weight,
                       state[f"convs.{i}.linear.weight"], state[f"convs.{i}.bias"])
         x = _bn(x, state, i, training)
-        x = F.relu(x)
+        x = _relu(x, f"layer{i}")
         x = _dropout(x, dropout, training, _keep(masks, "layers", i))
     return graph_mean_pool(x, b.batch, b.num_graphs)            # :211
 
@@ -180,7 +192,7 @@ def sage_encode(state: State, b: OBatch, dropout: float = 0.3, training: bool = 
     x = b.node_features
     for i in range(_num_layers(state)):                         # :258-261 (no ReLU after BN)
         x = sage_layer(x, b.edge_index, b.edge_weight,
-                       state[f"convs.{i}.linear.weight"], state[f"convs.{i}.linear.bias"])
+                       state[f"convs.{i}.linear.weight"], state[f"convs.{i}.linear.bias"], f"layer{i}")
         x = _bn(x, state, i, training)
         x = _dropout(x, dropout, training, _keep(masks, "layers", i))
     return graph_mean_pool(x, b.batch, b.num_graphs)            # :262

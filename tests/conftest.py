@@ -39,3 +39,5 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
             f"{P.ARBITER['fp64']} (of which by the fp32 noise floor: {P.ARBITER['floor']})")
         for line in P.ARBITER["names"]:
             terminalreporter.write_line(f"   arbiter: {line}")
+        for line in P.ARBITER.get("relu_ties", []):
+            terminalreporter.write_line(f"   relu tie: {line}")

@@ -717,6 +717,61 @@ def test_cfg5_shape_gcn_1000roi_h256_vs_oracle(dropout, ngraphs):
 
 
 @pytest.mark.parametrize("kind", ["gcn", "sage"])
+@pytest.mark.parametrize("in_ch,hidden,n,nb", [(1, 64, 84, 8), (8, 64, 84, 60), (9, 64, 84, 60), (16, 64, 360, 12),
+                                               (17, 64, 360, 12), (32, 128, 100, 48), (40, 64, 100, 48),
+                                               (64, 128, 100, 48), (3, 256, 360, 16), (20, 256, 100, 48),
+                                               (128, 128, 50, 10), (7, 192, 100, 48), (12, 32, 84, 60)])
+def test_shape_sweep_vs_oracle(kind, in_ch, hidden, n, nb):
+    """Input widths 1 .. 128 x hidden 32 .. 256 x row counts below and above the 4096 from which the
+    weight-stationary GEMMs and the packed layer-0 panels apply: whatever path the dispatcher picks
+    (per-tile, wide, GraphSAGE encoder, op by op), logits and every gradient against the oracle."""
+    import connectome_gnn_amd as C
+    gs = C.generate_dataset(nb, n, k=8, seed=31 + in_ch)
+    g = torch.Generator().manual_seed(in_ch * 1000 + hidden)
+    gs = [C.ConnectomeGraph(torch.randn(x.num_nodes, in_ch, generator=g), x.edge_index, x.edge_weight, x.label) for x in gs]
+    b = C.collate_graphs(gs)
+    torch.manual_seed(11)
+    m = _model(kind, in_ch, hidden, dropout=0.0)
+    sd0 = {k_: v.clone() for k_, v in m.state_dict().items()}
+    lo, loss_o, g32, _ = P.oracle_run(kind, sd0, b)
+    _, _, g64, _ = P.oracle_run(kind, sd0, b, dtype=torch.float64)
+    m = m.to(DEV).train()
+    bd = b.to(DEV)
+    lg = m(bd)
+    loss_g = torch.nn.functional.cross_entropy(lg, bd.labels)
+    loss_g.backward()
+    torch.testing.assert_close(lg.cpu(), lo, **TOL)
+    P.assert_grads({k_: p.grad for k_, p in m.named_parameters()}, kind, sd0, b,
+                   f"sweep-{kind}-f{in_ch}-h{hidden}-{n}x{nb}", g32=g32, g64=g64)
+
+
+def test_a_relu_tie_is_found_and_resolved():
+    """GraphSAGE hidden 256 on 12 x 360-ROI graphs: ONE of 1.1 M last-layer pre-activations is +5.4e-8 in
+    float64 (channel median 0.5) and the split-bf16 GEMM rounds it to 0 -- 2 % of that channel's bias
+    gradient.  Rules (1)-(3) fail; rule (4) lists the tie and passes with it decided the
+    other way -- and only with it."""
+    import connectome_gnn_amd as C
+    b = C.collate_graphs(C.generate_dataset(12, 360, 14, seed=123))
+    torch.manual_seed(7)
+    m = _model("sage", 5, 256, dropout=0.0)
+    sd0 = {k_: v.clone() for k_, v in m.state_dict().items()}
+    ties = P.relu_ties("sage", sd0, b)
+    assert ("layer2", 931, 133) in ties and len(ties) <= P.RELU_TIE_LIST
+    _, _, g32, _ = P.oracle_run("sage", sd0, b)
+    _, _, g64, _ = P.oracle_run("sage", sd0, b, dtype=torch.float64)
+    m = m.to(DEV).train()
+    lg = m(b.to(DEV))
+    torch.nn.functional.cross_entropy(lg, b.labels.to(DEV)).backward()
+    grads = {k_: p.grad for k_, p in m.named_parameters()}
+    with pytest.raises(AssertionError):
+        for k_, g in grads.items():
+            P.assert_grad(k_, g, g32[k_], g64[k_], "tie-demo", P.NoiseFloor("sage", sd0, b))
+    before = len(P.ARBITER["relu_ties"])
+    P.assert_grads(grads, "sage", sd0, b, "tie-demo", g32=g32, g64=g64)
+    assert len(P.ARBITER["relu_ties"]) == before + 1 and "[('layer2', 931, 133)] decided" in P.ARBITER["relu_ties"][-1]
+
+
+@pytest.mark.parametrize("kind", ["gcn", "sage"])
 def test_ragged_large_graphs_on_the_band_aggregate_vs_oracle(kind):
     """Graphs of 1000, 333 and 610 nodes at band-like density plus an edgeless and an empty one in one
     batch (pitch 1024, ragged row blocks, a graph that would fit an LDS tile riding along): the one-node
