@@ -743,6 +743,17 @@ def test_shape_sweep_vs_oracle(kind, in_ch, hidden, n, nb):
     torch.testing.assert_close(lg.cpu(), lo, **TOL)
     P.assert_grads({k_: p.grad for k_, p in m.named_parameters()}, kind, sd0, b,
                    f"sweep-{kind}-f{in_ch}-h{hidden}-{n}x{nb}", g32=g32, g64=g64)
+    # ... and the eval-mode forward on the running statistics that step left behind (each side its own)
+    _, _, _, st32 = P.oracle_run(kind, sd0, b)
+    sd = m.state_dict()
+    for k_ in sd:
+        if "running" in k_:
+            torch.testing.assert_close(sd[k_].cpu(), st32[k_], **TOL)
+    le_o, _, _, _ = P.oracle_run(kind, st32, b, 0.0, training=False)
+    m.eval()
+    with torch.no_grad():
+        le = m(bd)
+    torch.testing.assert_close(le.cpu(), le_o, rtol=1e-4, atol=1e-5)
 
 
 def test_a_relu_tie_is_found_and_resolved():
