@@ -440,7 +440,7 @@ def run_workload(args, name: str, rank: int, world: int, dev, *, launch: str, ba
         dom = "cgnn_gcn_fused_bwd"
     elif batches[0].structure().tiled_ok(hidden):
         dom = f"cgnn_aggregate_tiled_f32[F={hidden}]"
-    elif any(v[0] is not None for v in batches[0].structure().__dict__.get("_band_ops", {}).values()):
+    elif any(v is not None for v in batches[0].structure().__dict__.get("_band_ops", {}).values()):
         dom = f"cgnn_band_aggregate_f32+cgnn_aggregate_acc_f32[F={hidden}]"
     else:
         dom = f"cgnn_aggregate_f32[F={hidden}]"

@@ -228,8 +228,10 @@ class BatchStructure:
             else:
                 f = ops.band_operator_f32(self, self.rowptr_dst, self.col_dst, norm.w_dst)
                 b = ops.band_operator_f32(self, self.rowptr_src, self.col_src, norm.coef_src_bwd) if f is not None else None
-            hit[kind] = ((self, f), (self, b)) if (f is not None and b is not None) else (None, None)
-        return hit[kind]
+            hit[kind] = (f, b) if (f is not None and b is not None) else None
+        # (the pairs are made per call: a cached tuple holding `self` would be a reference cycle, and a
+        # structure with its device arrays would then wait for the cycle collector instead of its refcount)
+        return (None, None) if hit[kind] is None else ((self, hit[kind][0]), (self, hit[kind][1]))
 
     # -- normalisations: layer independent, recomputed once per forward pass ----------------
     def gcn_norm(self) -> GcnNorm:

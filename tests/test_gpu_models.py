@@ -815,6 +815,33 @@ def test_ragged_large_graphs_on_the_band_aggregate_vs_oracle(kind):
         P.assert_grad(k_, p.grad, g32[k_], g64[k_], f"ragged-band-{kind}", floor)
 
 
+def test_structures_are_released_by_reference_count():
+    """A batch's structure -- CSR, blocked-ELL, the dense fragments of large graphs, the degree-ordered twin --
+    holds hundreds of MB at the benchmark sizes: it must die with the batch, not wait for the cycle collector
+    (a cycle through such a cache once cost ~100 ms collector stalls per epoch)."""
+    import gc
+    import weakref
+    import connectome_gnn_amd as C
+    gc.collect()
+    gc.disable()
+    try:
+        for graphs, hidden in (([C.generate_connectome(600, 80, seed=1), C.generate_connectome(450, 70, seed=2)], 128),
+                               (C.generate_dataset(6, 100, 8, seed=3), 64)):
+            b = C.collate_graphs(graphs).to(DEV)
+            m = C.GCNConnectome(5, hidden, dropout=0.0).to(DEV).train()
+            m.prepare_batch(b, reuse=True)
+            m(b).sum().backward()
+            s = b.structure()
+            refs = [weakref.ref(s)]
+            twin = s.__dict__.get("_degree_twin")
+            if twin is not None:
+                refs.append(weakref.ref(twin))
+            del s, twin, b, m
+            assert all(r() is None for r in refs), "a structure survived its batch without the cycle collector"
+    finally:
+        gc.enable()
+
+
 @pytest.mark.parametrize("kind", ["gcn", "sage"])
 def test_graphs_beyond_the_band_builder_take_the_gather_aggregate(kind):
     """A 1100-node graph (more than the 1024 the dense-fragment builder takes) next to a small one and an
