@@ -63,7 +63,18 @@ def _l0_center(lib, s, x0: torch.Tensor, tiles_ref, stream) -> torch.Tensor:
     """The centring constants of the factored layer 0 (cgnn_gcn_l0_center): column means of X0 and
     the mean row sum of the normalised operator over the batch's first tile.  It is a conditioning hint, not part of the arithmetic (any value
     gives the same result up to rounding), so it is computed once per (batch, feature tensor)
-    and cached on the structure -- one tiny launch at a batch's first use."""
+    and cached on the structure -- one tiny launch at a batch's first use -- or once per DATASET for
+    batches assembled from a per-subject structure cache."""
+    cache = getattr(s, "cache", None)
+    if cache is not None and torch.cuda.is_current_stream_capturing():
+        # a captured step that assembles another batch of a per-subject structure cache on every replay:
+        # ONE set of constants per dataset -- those of the batch the step's eager warm-up ran on, stored
+        # below -- instead of a launch per replay (6.4 us of a 0.2 ms step at 512 x 84-ROI).  Any value is
+        # correct; eager steps keep their per-batch constants (and with them bit-identity to the
+        # per-batch build of the same subjects).
+        const = cache.__dict__.get("_l0_center")
+        if const is not None and const[0] == int(x0.shape[1]):
+            return const[1]
     key = (x0.data_ptr(), x0._version, tuple(x0.shape))
     hit = s.__dict__.get("_l0_center")
     if hit is None or hit[0] != key:
@@ -72,6 +83,8 @@ def _l0_center(lib, s, x0: torch.Tensor, tiles_ref, stream) -> torch.Tensor:
                    "cgnn_gcn_l0_center")
         hit = (key, center)
         s.__dict__["_l0_center"] = hit
+        if cache is not None and not torch.cuda.is_current_stream_capturing() and cache.__dict__.get("_l0_center") is None:
+            cache.__dict__["_l0_center"] = (int(x0.shape[1]), center)
     return hit[1]
 
 

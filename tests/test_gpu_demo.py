@@ -226,6 +226,11 @@ def _trainer_replay_equals_eager(ds, masks=True, cls="gcn"):
             assert all(isinstance(s, GraphedResidentStep) for s in tr._graphs.values())
     torch.testing.assert_close(torch.tensor(hist["graph"]), torch.tensor(hist["eager"]), rtol=2e-5, atol=1e-6)
     for k, v in finals["eager"].items():
+        # (GCN's bias ahead of BatchNorm has a zero true gradient -- Adam moves it by +-lr per step on the SIGN
+        # of rounding noise -- and the layer's running mean contains it; the replayed step uses one set of
+        # layer-0 centring constants per dataset, the eager one per batch: equal functions, different rounding)
+        if cls == "gcn" and (k.startswith("convs.") and k.endswith(".bias") or "running_mean" in k):
+            continue
         if v.is_floating_point() and not (k.startswith("convs.") and k.endswith(".bias")):
             torch.testing.assert_close(finals["graph"][k], v, rtol=1e-4, atol=1e-5, msg=lambda s: f"{k}: {s}")
     if not masks:
