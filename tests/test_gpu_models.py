@@ -756,6 +756,34 @@ def test_shape_sweep_vs_oracle(kind, in_ch, hidden, n, nb):
     torch.testing.assert_close(le.cpu(), le_o, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("kind,hidden,n,k,nb", [("gcn", 64, 360, 14, 6), ("sage", 128, 84, 8, 20), ("gcn", 256, 1000, 100, 3),
+                                                ("gcn", 32, 84, 8, 9)])
+def test_training_step_loss_through_the_one_launch_classifier_vs_oracle(kind, hidden, n, k, nb):
+    """The Trainer's way of taking a step -- ops.model_loss (model.forward_loss: classifier + cross-entropy +
+    their backward in one launch, cgnn_head_loss_f32) and the unit upstream gradient -- with dropout 0.3 on every
+    path it meets (per-tile GCN, GraphSAGE encoder, large graphs, hidden 32 = the three-launch form): loss and
+    every gradient against the oracle with the kernels' own keep decisions replayed."""
+    import connectome_gnn_amd as C
+    from connectome_gnn_amd import ops
+    from connectome_gnn_amd.resident import assemble_batch
+    from connectome_gnn_amd.synthetic import generate_packed
+    b = assemble_batch(generate_packed(nb, n, k, seed=21), torch.arange(nb))
+    torch.manual_seed(8)
+    m = _model(kind, 5, hidden, dropout=0.3)
+    sd0 = {k_: v.clone() for k_, v in m.state_dict().items()}
+    m = m.to(DEV).train()
+    m.record_dropout = True
+    bd = b.to(DEV)
+    loss = ops.model_loss(m, ops.CrossEntropyLoss(), bd)
+    ops.backward_unit(loss)
+    masks = P.recorded_masks(m, b.num_nodes, b.num_graphs)
+    _, loss_o, g32, _ = P.oracle_run(kind, sd0, b, 0.3, True, masks)
+    _, _, g64, _ = P.oracle_run(kind, sd0, b, 0.3, True, masks, dtype=torch.float64)
+    torch.testing.assert_close(loss.detach().cpu(), loss_o, **TOL)
+    P.assert_grads({k_: p.grad for k_, p in m.named_parameters()}, kind, sd0, b, f"step-{kind}-h{hidden}-{n}",
+                   dropout=0.3, masks=masks, g32=g32, g64=g64)
+
+
 def test_a_relu_tie_is_found_and_resolved():
     """GraphSAGE hidden 256 on 12 x 360-ROI graphs: ONE of 1.1 M last-layer pre-activations is +5.4e-8 in
     float64 (channel median 0.5) and the split-bf16 GEMM rounds it to 0 -- 2 % of that channel's bias
