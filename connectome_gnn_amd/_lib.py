@@ -175,6 +175,7 @@ PROTOTYPES = {
     "cgnn_epoch_advance": (c_int, [P, I64, P, F32, P, P]),
     "cgnn_gcn_dis": (c_int, [P, P, I64, P, P]),
     "cgnn_fused_grid": (c_int, []),
+    "cgnn_set_fused_grid": (c_int, [I32]),
     "cgnn_gcn_fused_fwd_first": (c_int, [TP, P, I32, P, P, P, P, P]),
     "cgnn_rng_advance": (c_int, [P, I32, P]),
     "cgnn_gcn_fused_fwd": (c_int, [TP, P, LP, P, F32, U64, P, P, P, P, P, P, P]),

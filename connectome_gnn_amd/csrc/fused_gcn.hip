@@ -1402,8 +1402,10 @@ __global__ void __launch_bounds__(RD_C * RD_G) k_dw_db_reduce_multi(cgnn_dw_jobs
 }
 
 int g_grid_cache[CGNN_MAX_DEVICES] = {};
+int g_grid_override = 0;   // cgnn_set_fused_grid (test hook): > 0 replaces the CU count
 
 int fused_grid() {
+  if (g_grid_override > 0) return g_grid_override;
   const int dev = cgnn_device_ordinal();
   if (g_grid_cache[dev] == 0) {
     int cus = 0;
@@ -1460,6 +1462,12 @@ int cgnn_debug_stamps(unsigned long long* out_host) {
 #endif
 
 int cgnn_fused_grid(void) { return fused_grid(); }
+
+int cgnn_set_fused_grid(int32_t workgroups) {
+  if (workgroups < 0 || workgroups > 65535) return CGNN_EINVAL;
+  g_grid_override = workgroups;
+  return CGNN_OK;
+}
 
 int cgnn_gcn_fused_fwd_first(const cgnn_tiles* t, const float* X0, int32_t F0, const float* W0,
                              const float* bias, float* Y, double* stat_slab, void* stream) {

@@ -318,6 +318,11 @@ typedef struct cgnn_l0src {
 
 /* Number of persistent workgroups every fused kernel launches (= rows of every slab). */
 int cgnn_fused_grid(void);
+/* TEST HOOK: make every persistent kernel launch `workgroups` workgroups instead of one per CU
+ * (0 restores the device's CU count), so that small parity batches put several tiles / row blocks
+ * on one workgroup -- the regime the benchmarks run in.  Process-wide; slabs sized with the old
+ * value must not be reused across a change.  Not for production callers. */
+int cgnn_set_fused_grid(int32_t workgroups);
 
 /* Tiled edge-weighted aggregation for wide features (F % 64 == 0), the LDS-staged form of
  * cgnn_aggregate_f32 (models.py:112-114, :146-149 and their autograd transposes):
