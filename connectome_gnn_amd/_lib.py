@@ -15,7 +15,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint6
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CGNN_LIB selects another build of the same ABI (diagnostic builds only, e.g. the stamped one)
 LIB_PATH = os.environ.get("CGNN_LIB") or os.path.join(_HERE, "libcgnn_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 CGNN_OK, CGNN_EINVAL, CGNN_ELAUNCH, CGNN_EUNSUPPORTED = 0, -1, -2, -3
 _ERR = {CGNN_EINVAL: "CGNN_EINVAL (bad argument)", CGNN_ELAUNCH: "CGNN_ELAUNCH (kernel launch failed)",
@@ -108,7 +108,7 @@ PROTOTYPES = {
     "cgnn_abi_version": (c_int, []),
     "cgnn_build_target": (c_char_p, []),
     "cgnn_csr_workspace_bytes": (I64, [I64, I64]),
-    "cgnn_csr_build": (c_int, [P, P, I64, I64, P, P, P, P, P, P, P, P, P]),
+    "cgnn_csr_build": (c_int, [P, P, I64, I64, P, P, P, P, P, P, P, P, I64, P]),
     "cgnn_csr_build_grouped": (c_int, [P, P, P, I32, I64, I64, I32, I32, P, P, P, P, P, P, P, P]),
     "cgnn_gcn_norm": (c_int, [P, P, I64, I64, P, P, P, P, P, P, P, P, P]),
     "cgnn_sage_norm": (c_int, [P, P, I64, I64, P, P, P, P, P, P, P, P]),
@@ -118,54 +118,54 @@ PROTOTYPES = {
     "cgnn_head_supported": (c_int, [I32, I32, I32]),
     "cgnn_head_grid": (c_int, [I32, I32, I32, I32]),
     "cgnn_head_fwd_f32": (c_int, [P, I32, I32, I32, I32, P, P, P, P, F32, U64, P, P, P, P, P]),
-    "cgnn_head_bwd_f32": (c_int, [P, P, P, P, I32, I32, I32, I32, P, P, P, P, P]),
+    "cgnn_head_bwd_f32": (c_int, [P, P, P, P, I32, I32, I32, I32, P, P, P, P, I64, P]),
     "cgnn_head_loss_grid": (c_int, [I32, I32, I32, I32]),
-    "cgnn_head_loss_f32": (c_int, [P, I32, I32, I32, I32, P, P, P, P, P, F32, U64, P, P, P, P, P, P, P]),
+    "cgnn_head_loss_f32": (c_int, [P, I32, I32, I32, I32, P, P, P, P, P, F32, U64, P, P, P, P, P, P, I64, P]),
     "cgnn_cross_entropy_f32": (c_int, [P, P, I32, I32, P, P, P]),
     "cgnn_dense_adj_f16": (c_int, [P, P, P, P, P, I32, I32, P, P]),
-    "cgnn_dense_aggregate_f16": (c_int, [P, I32, P, I32, P, I64, I32, P, P, I64, P, P]),
+    "cgnn_dense_aggregate_f16": (c_int, [P, I32, P, I32, P, I64, I32, P, P, I64, P, I64, P]),
     "cgnn_dense_pack_count": (c_int, [P, P, P, P, P, I32, I32, P, P]),
     "cgnn_dense_pack_fill": (c_int, [P, P, P, P, P, I32, I32, P, P, P, P, P, P]),
-    "cgnn_dense_aggregate_c16": (c_int, [P, P, P, P, P, P, I32, P, I32, P, I64, I32, P, P, I64, P, P]),
+    "cgnn_dense_aggregate_c16": (c_int, [P, P, P, P, P, P, I32, P, I32, P, I64, I32, P, P, I64, P, I64, P]),
     "cgnn_band_pack_f32": (c_int, [P, P, P, P, I32, I32, P, P, P, P]),
     "cgnn_band_aggregate_f32": (c_int, [P, P, P, I32, P, I32, P, I64, I32, P, P, I64, P, I64, P]),
-    "cgnn_dense_aggregate_c16_bnbwd": (c_int, [P, P, P, P, P, P, I32, P, I32, P, I64, P, P, I64, P, P, P, I32, F32, I32, P,
-                                               I64, P, P]),
+    "cgnn_dense_aggregate_c16_bnbwd": (c_int, [P, P, P, P, P, P, I32, P, I32, P, I64, P, P, I64, P, P, P, I32, F32, I32, P, I64, P, I64, P]),
     "cgnn_linear_fwd_f32": (c_int, [P, I64, I32, P, I64, I32, P, P, I32, P, I64, I64, I32, P]),
-    "cgnn_linear_fwd_stats_f32": (c_int, [P, I64, I32, P, I64, I32, P, P, I32, P, I64, I64, I32, P, P]),
+    "cgnn_linear_fwd_stats_f32": (c_int, [P, I64, I32, P, I64, I32, P, P, I32, P, I64, I64, I32, P, I64, P]),
     "cgnn_linear_bwd_input_f32": (c_int, [P, I64, P, I32, I32, P, I64, I64, I32, I32, P]),
     "cgnn_linear_bwd_weight_workspace_bytes": (I64, [I64, I32, I32]),
-    "cgnn_linear_bwd_weight_f32": (c_int, [P, I64, P, I64, P, I32, I32, I64, I32, I32, P, P]),
-    "cgnn_linear_bwd_weight2_f32": (c_int, [P, I64, P, I64, I32, P, I64, I32, P, I32, I64, I32, P, P]),
+    "cgnn_linear_bwd_weight2_workspace_bytes": (I64, [I64, I32, I32, I32]),
+    "cgnn_linear_bwd_weight_f32": (c_int, [P, I64, P, I64, P, I32, I32, I64, I32, I32, P, I64, P]),
+    "cgnn_linear_bwd_weight2_f32": (c_int, [P, I64, P, I64, I32, P, I64, I32, P, I32, I64, I32, P, I64, P]),
     "cgnn_linear_fwd_f16": (c_int, [P, I64, I32, P, I32, I32, P, P, I64, I64, I32, P]),
     "cgnn_linear_bwd_input_f16": (c_int, [P, I64, P, I32, P, I64, I64, I32, I32, P]),
-    "cgnn_linear_fwd_stats_f16": (c_int, [P, I64, I32, P, I32, I32, P, P, I64, I64, I32, P, P]),
+    "cgnn_linear_fwd_stats_f16": (c_int, [P, I64, I32, P, I32, I32, P, P, I64, I64, I32, P, I64, P]),
     "cgnn_linear_bwd_weight_f16_workspace_bytes": (I64, [I64, I32, I32]),
-    "cgnn_linear_bwd_weight_f16": (c_int, [P, I64, P, I64, P, I32, I32, I64, I32, I32, P, P]),
+    "cgnn_linear_bwd_weight_f16": (c_int, [P, I64, P, I64, P, I32, I32, I64, I32, I32, P, I64, P]),
     "cgnn_pad_cast_f16": (c_int, [P, I64, I32, P, I32, I64, P]),
     "cgnn_colsum_workspace_bytes": (I64, [I64, I32]),
-    "cgnn_colsum_f32": (c_int, [P, I64, P, I64, I32, P, P]),
+    "cgnn_colsum_f32": (c_int, [P, I64, P, I64, I32, P, I64, P]),
     "cgnn_pool_mean_fwd_f32": (c_int, [P, I64, P, P, I32, I32, P]),
     "cgnn_pool_mean_bwd_f32": (c_int, [P, P, P, I64, I32, I32, P]),
     # BatchNorm + activation + dropout (layered path)
     "cgnn_bn_act_width_ok": (c_int, [I32]),
     "cgnn_bn_act_slab_rows": (I64, [I64]),
-    "cgnn_bn_act_fwd_stats": (c_int, [P, I64, I32, P, P]),
+    "cgnn_bn_act_fwd_stats": (c_int, [P, I64, I32, P, I64, P]),
     "cgnn_bn_act_finalize": (c_int, [P, I32, I32, F64, P, I32, P, P, P, P, F32, F32, P, P, P]),
     "cgnn_bn_act_fwd_apply": (c_int, [P, P, I32, F32, U64, P, P, P, I64, I32, P]),
     "cgnn_bn_act_pool_fwd": (c_int, [P, P, I32, F32, U64, P, P, P, I32, P, I32, P, P]),
     "cgnn_bn_act_pool_bwd_finalize": (c_int, [P, P, P, I32, I32, F64, I32, P, P, P, P]),
-    "cgnn_bn_act_bwd_stats": (c_int, [P, P, P, P, I32, F32, I64, I32, P, P, P, P, P]),
+    "cgnn_bn_act_bwd_stats": (c_int, [P, P, P, P, I32, F32, I64, I32, P, I64, P, P, P, P]),
     "cgnn_bn_act_bwd_finalize": (c_int, [P, I32, I32, F64, P, I32, P, P, P, P]),
     "cgnn_bn_act_apply_blocks": (I64, [I64, I32]),
-    "cgnn_bn_act_bwd_apply": (c_int, [P, P, P, P, P, I32, F32, I32, P, P, I64, I32, P, P, P, P]),
-    "cgnn_bn_act_fwd_stats_f16": (c_int, [P, I64, I32, P, P]),
+    "cgnn_bn_act_bwd_apply": (c_int, [P, P, P, P, P, I32, F32, I32, P, I64, P, I64, I32, P, P, P, P]),
+    "cgnn_bn_act_fwd_stats_f16": (c_int, [P, I64, I32, P, I64, P]),
     "cgnn_bn_act_fwd_apply_f16": (c_int, [P, P, I32, F32, U64, P, P, P, I64, I32, P]),
     "cgnn_bn_act_pool_fwd_f16": (c_int, [P, P, I32, F32, U64, P, P, P, I32, P, I32, P, P]),
-    "cgnn_bn_act_bwd_stats_f16": (c_int, [P, P, P, P, I32, F32, I64, I32, P, P, P, P, P]),
-    "cgnn_bn_act_bwd_apply_f16": (c_int, [P, P, P, P, P, I32, F32, I32, P, P, I64, I32, P, P, P, P]),
+    "cgnn_bn_act_bwd_stats_f16": (c_int, [P, P, P, P, I32, F32, I64, I32, P, I64, P, P, P, P]),
+    "cgnn_bn_act_bwd_apply_f16": (c_int, [P, P, P, P, P, I32, F32, I32, P, I64, P, I64, I32, P, P, P, P]),
     # fused per-tile GCN path
-    "cgnn_bell_plan": (c_int, [P, P, I32, I32, P, P, P, P]),
+    "cgnn_bell_plan": (c_int, [P, P, I32, I32, P, P, P, I64, P]),
     "cgnn_bell_fill": (c_int, [P, P, I32, P, P, P, P, F32, P, P, P]),
     "cgnn_aggregate_tiled_f32": (c_int, [TP, I32, P, I64, I32, P, P, P, P, I64, P, I64, P]),
     "cgnn_aggregate_tiled_bn_f32": (c_int, [TP, I32, P, I64, I32, P, P, P, P, I64, P, I32, F32, U64, P, P, P, I64, P]),
@@ -176,17 +176,17 @@ PROTOTYPES = {
     "cgnn_gcn_dis": (c_int, [P, P, I64, P, P]),
     "cgnn_fused_grid": (c_int, []),
     "cgnn_set_fused_grid": (c_int, [I32]),
-    "cgnn_gcn_fused_fwd_first": (c_int, [TP, P, I32, P, P, P, P, P]),
+    "cgnn_gcn_fused_fwd_first": (c_int, [TP, P, I32, P, P, P, P, I64, P]),
     "cgnn_rng_advance": (c_int, [P, I32, P]),
-    "cgnn_gcn_fused_fwd": (c_int, [TP, P, LP, P, F32, U64, P, P, P, P, P, P, P]),
+    "cgnn_gcn_fused_fwd": (c_int, [TP, P, LP, P, F32, U64, P, P, P, P, P, P, I64, P]),
     "cgnn_bn_reduce": (c_int, [P, I32, I32, P, P]),
     "cgnn_bn_finalize": (c_int, [P, F64, P, P, P, P, P, F32, F32, I32, P, P, P]),
     "cgnn_gcn_fused_pool_fwd": (c_int, [P, P, F32, U64, P, P, P, I32, P, P, P, P]),
-    "cgnn_gcn_fused_pool_bwd_sums": (c_int, [P, P, P, P, I32, P, P]),
-    "cgnn_gcn_fused_pool_bwd": (c_int, [P, P, P, F32, P, P, I32, P, P, P]),
+    "cgnn_gcn_fused_pool_bwd_sums": (c_int, [P, P, P, P, I32, P, I64, P]),
+    "cgnn_gcn_fused_pool_bwd": (c_int, [P, P, P, F32, P, P, I32, P, P, I64, P]),
     "cgnn_bn_bwd_finalize": (c_int, [P, F64, P, I32, P, P, P, P]),
-    "cgnn_gcn_fused_bwd": (c_int, [TP, P, P, P, P, P, LP, P, F32, P, P, P, P, P, P, P, P, P, P, P]),
-    "cgnn_gcn_fused_bwd_first": (c_int, [TP, P, P, P, P, P, I32, P, P, F32, P, P, P, P, P]),
+    "cgnn_gcn_fused_bwd": (c_int, [TP, P, P, P, P, P, LP, P, F32, P, P, P, P, I64, P, I64, P, I64, P, P, P, P, P]),
+    "cgnn_gcn_fused_bwd_first": (c_int, [TP, P, P, P, P, P, I32, P, I64, P, I64, F32, P, P, P, P, P]),
     "cgnn_bn_stats_finalize": (c_int, [P, I32, F64, P, P, P, P, F32, F32, P, P, P]),
     "cgnn_bn_stats_finalize_rng": (c_int, [P, I32, F64, P, P, P, P, F32, F32, P, P, P, I32, P, P]),
     "cgnn_gcn_fused_pool_bwd_finalize": (c_int, [P, P, P, P, I32, F64, I32, P, P, P, P]),
@@ -196,8 +196,8 @@ PROTOTYPES = {
     "cgnn_adam_step": (c_int, [ctypes.POINTER(CgnnAdamJobs), P, P, I32, F64, F64, F64, F64, F64, P]),
     "cgnn_l0_grid": (c_int, [c_int64]),
     "cgnn_gcn_l0_center": (c_int, [TP, P, I32, P, P]),
-    "cgnn_gcn_l0_fwd": (c_int, [TP, P, I32, P, P, P, P, P, P, P, P, P]),
-    "cgnn_gcn_l0_bwd": (c_int, [P, P, LP, P, P, P, I64, P, P, P, P]),
+    "cgnn_gcn_l0_fwd": (c_int, [TP, P, I32, P, P, P, P, P, I64, P, P, P, P]),
+    "cgnn_gcn_l0_bwd": (c_int, [P, P, LP, P, P, P, I64, P, I64, P, I64, P, P]),
     "cgnn_slab_reduce_f32": (c_int, [P, I32, I32, I32, I32, P, I32, P]),
     "cgnn_slab_reduce_f64": (c_int, [P, I32, I32, P, P]),
 }
@@ -242,6 +242,12 @@ def check(rc: int, what: str) -> None:
 def ptr(t) -> int:
     """Device pointer of a tensor (None -> NULL)."""
     return 0 if t is None else t.data_ptr()
+
+
+def nbytes(t) -> int:
+    """Byte count of a tensor handed to the library as a scratch / partial-sum buffer (None -> 0):
+    ABI 2 passes it right after the pointer and the library refuses a buffer that is too short."""
+    return 0 if t is None else t.numel() * t.element_size()
 
 
 class _NullCtx:

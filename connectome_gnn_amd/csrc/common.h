@@ -11,6 +11,13 @@
     if (hipGetLastError() != hipSuccess) return CGNN_ELAUNCH; \
   } while (0)
 
+// ABI 2: every scratch / partial-sum buffer the library writes comes with its byte count; a call whose
+// buffer is shorter than what the path it is about to take writes returns CGNN_EINVAL before any launch.
+#define CGNN_NEED_BYTES(ptr, have, need)                                   \
+  do {                                                                     \
+    if ((ptr) && (int64_t)(have) < (int64_t)(need)) return CGNN_EINVAL;    \
+  } while (0)
+
 static inline hipStream_t cgnn_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 // Per-device lazily-initialised state (function attributes, CU counts) is indexed by the current

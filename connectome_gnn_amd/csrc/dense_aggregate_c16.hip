@@ -483,12 +483,13 @@ int cgnn_dense_aggregate_c16(const void* dfrag, const int32_t* dstep, const uint
                              const uint32_t* sent, const int32_t* sstep, const uint32_t* soff,
                              int32_t P, const int32_t* gptr, int32_t num_graphs, const void* X,
                              int64_t ldx, int32_t F, const float* bias, void* Y, int64_t ldy,
-                             double* stat_slab, void* stream) {
+                             double* stat_slab, int64_t stat_slab_bytes, void* stream) {
   if (num_graphs < 0 || P <= 0 || F <= 0 || ldx < F || ldy < F) return CGNN_EINVAL;
   if (P > C_MAXP || P % 64 || F % 64 || ldx % 8 || c_lds(P, F) > 160 * 1024) return CGNN_EUNSUPPORTED;
   if (reinterpret_cast<uintptr_t>(X) & 15) return CGNN_EUNSUPPORTED;
   if (num_graphs == 0) return CGNN_OK;
   if (!dfrag || !dstep || !doff || !sent || !sstep || !soff || !gptr || !X || !Y) return CGNN_EINVAL;
+  CGNN_NEED_BYTES(stat_slab, stat_slab_bytes, (int64_t)cgnn_fused_grid() * 2 * F * (int64_t)sizeof(double));
   if (!pack_attr()) return CGNN_ELAUNCH;
   const int grid = cgnn_fused_grid();
   int rparts = 1;
@@ -506,7 +507,7 @@ int cgnn_dense_aggregate_c16_bnbwd(const void* dfrag, const int32_t* dstep, cons
                                    int32_t P, const int32_t* gptr, int32_t num_graphs, const void* dX,
                                    int64_t lddx, const float* dP, const void* Yl, int64_t ldyl,
                                    const uint8_t* mask, const float* coef, const float* bwc, int32_t relu,
-                                   float p_drop, int32_t F, void* dT, int64_t lddt, double* cs_slab,
+                                   float p_drop, int32_t F, void* dT, int64_t lddt, double* cs_slab, int64_t cs_slab_bytes,
                                    void* stream) {
   if (num_graphs < 0 || P <= 0 || F <= 0 || ldyl < F || lddt < F || (dX && lddx < F)) return CGNN_EINVAL;
   if ((!dX) == (!dP) || !Yl || !coef || !bwc || !cs_slab || p_drop < 0.f || p_drop >= 1.f || (p_drop > 0.f && !mask))
@@ -515,6 +516,7 @@ int cgnn_dense_aggregate_c16_bnbwd(const void* dfrag, const int32_t* dstep, cons
   if ((reinterpret_cast<uintptr_t>(dX) | reinterpret_cast<uintptr_t>(Yl)) & 15) return CGNN_EUNSUPPORTED;
   if (num_graphs == 0) return CGNN_OK;
   if (!dfrag || !dstep || !doff || !sent || !sstep || !soff || !gptr || !dT) return CGNN_EINVAL;
+  CGNN_NEED_BYTES(cs_slab, cs_slab_bytes, (int64_t)num_graphs * F * (int64_t)sizeof(double));
   if (!pack_attr()) return CGNN_ELAUNCH;
   const int grid = cgnn_fused_grid();
   int rparts = 1;

@@ -236,7 +236,7 @@ int cgnn_dense_adj_f16(const int32_t* rowptr, const int32_t* col, const float* c
 
 int cgnn_dense_aggregate_f16(const void* M, int32_t P, const int32_t* gptr, int32_t num_graphs,
                              const void* X, int64_t ldx, int32_t F, const float* bias, void* Y,
-                             int64_t ldy, double* stat_slab, void* stream) {
+                             int64_t ldy, double* stat_slab, int64_t stat_slab_bytes, void* stream) {
   if (num_graphs < 0 || P <= 0 || F <= 0 || ldx < F || ldy < F) return CGNN_EINVAL;
   if (P > D_MAXP || P % 64 || F % 64 || ldx % 8) return CGNN_EUNSUPPORTED;
   if ((size_t)64 * d_kp(P) * sizeof(__half) + (size_t)(D_NW * 128 + 2 * F) * sizeof(double) > 160 * 1024)
@@ -244,6 +244,7 @@ int cgnn_dense_aggregate_f16(const void* M, int32_t P, const int32_t* gptr, int3
   if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(M)) & 15) return CGNN_EUNSUPPORTED;
   if (num_graphs == 0) return CGNN_OK;
   if (!M || !gptr || !X || !Y) return CGNN_EINVAL;
+  CGNN_NEED_BYTES(stat_slab, stat_slab_bytes, (int64_t)cgnn_fused_grid() * 2 * F * (int64_t)sizeof(double));
   const size_t lds = (size_t)64 * d_kp(P) * sizeof(__half) + (size_t)(D_NW * 128 + 2 * F) * sizeof(double);
   static bool attr_set_dev[CGNN_MAX_DEVICES] = {};
   bool& attr_set = attr_set_dev[cgnn_device_ordinal()];

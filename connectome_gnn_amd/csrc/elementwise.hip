@@ -445,10 +445,11 @@ unsigned apply_blocks(int64_t M, int N, bool colsum = false) {
 namespace {
 
 template <typename T>
-int bn_act_fwd_stats_t(const T* Y, int64_t M, int32_t N, double* slab, void* stream) {
+int bn_act_fwd_stats_t(const T* Y, int64_t M, int32_t N, double* slab, int64_t slab_bytes, void* stream) {
   if (M < 0 || !width_ok(N) || !slab) return width_ok(N) ? CGNN_EINVAL : CGNN_EUNSUPPORTED;
   if (M == 0) return CGNN_OK;
   if (!Y) return CGNN_EINVAL;
+  CGNN_NEED_BYTES(slab, slab_bytes, (int64_t)stat_blocks(M) * 2 * N * (int64_t)sizeof(double));
   DropCfg d{};
   const int rpp = THR / (N >> 2);
   k_colstats<false, T><<<stat_blocks(M), THR, (size_t)rpp * 2 * N * sizeof(double), cgnn_stream(stream)>>>(
@@ -503,11 +504,12 @@ int bn_act_pool_fwd_t(const T* Y, const float* coef, int32_t relu, float p_drop,
 
 template <typename T>
 int bn_act_bwd_stats_t(const T* dX, const T* Y, const uint8_t* mask, const float* coef,
-                       int32_t relu, float p_drop, int64_t M, int32_t N, double* slab,
+                       int32_t relu, float p_drop, int64_t M, int32_t N, double* slab, int64_t slab_bytes,
                        const float* dP, const int32_t* node_graph, const int32_t* gptr,
                        void* stream) {
   if (M < 0 || !width_ok(N) || !slab || p_drop < 0.f || p_drop >= 1.f) return CGNN_EINVAL;
   if (M == 0) return CGNN_OK;
+  CGNN_NEED_BYTES(slab, slab_bytes, (int64_t)stat_blocks(M) * 2 * N * (int64_t)sizeof(double));
   if ((!dX && !dP) || !Y || !coef || (p_drop > 0.f && !mask)) return CGNN_EINVAL;
   if (dP && (!node_graph || !gptr)) return CGNN_EINVAL;
   int use_drop;
@@ -524,10 +526,11 @@ int bn_act_bwd_stats_t(const T* dX, const T* Y, const uint8_t* mask, const float
 template <typename T>
 int bn_act_bwd_apply_t(const T* dX, const T* Y, const uint8_t* mask, const float* coef,
                        const float* bwc, int32_t relu, float p_drop, int32_t relu_in,
-                       double* colsum_slab, T* dY, int64_t M, int32_t N, const float* dP,
+                       double* colsum_slab, int64_t colsum_slab_bytes, T* dY, int64_t M, int32_t N, const float* dP,
                        const int32_t* node_graph, const int32_t* gptr, void* stream) {
   if (M < 0 || !width_ok(N) || p_drop < 0.f || p_drop >= 1.f) return CGNN_EINVAL;
   if (M == 0) return CGNN_OK;
+  CGNN_NEED_BYTES(colsum_slab, colsum_slab_bytes, (int64_t)apply_blocks(M, N, true) * N * (int64_t)sizeof(double));
   if ((!dX && !dP) || !Y || !coef || !bwc || !dY || (p_drop > 0.f && !mask)) return CGNN_EINVAL;
   if (dP && (!node_graph || !gptr)) return CGNN_EINVAL;
   int use_drop;
@@ -578,8 +581,8 @@ int64_t cgnn_bn_act_apply_blocks(int64_t M, int32_t N) {
 
 
 // ---- fp32 storage
-int cgnn_bn_act_fwd_stats(const float* Y, int64_t M, int32_t N, double* slab, void* stream) {
-  return bn_act_fwd_stats_t<float>(Y, M, N, slab, stream);
+int cgnn_bn_act_fwd_stats(const float* Y, int64_t M, int32_t N, double* slab, int64_t slab_bytes, void* stream) {
+  return bn_act_fwd_stats_t<float>(Y, M, N, slab, slab_bytes, stream);
 }
 int cgnn_bn_act_fwd_apply(const float* Y, const float* coef, int32_t relu, float p_drop, uint64_t seed,
                           const uint32_t* seed_dev, uint8_t* mask_out, float* X, int64_t M, int32_t N,
@@ -604,23 +607,23 @@ int cgnn_bn_act_pool_bwd_finalize(const float* dP, const float* Fsum, const int3
   return CGNN_OK;
 }
 int cgnn_bn_act_bwd_stats(const float* dX, const float* Y, const uint8_t* mask, const float* coef,
-                          int32_t relu, float p_drop, int64_t M, int32_t N, double* slab,
+                          int32_t relu, float p_drop, int64_t M, int32_t N, double* slab, int64_t slab_bytes,
                           const float* dP, const int32_t* node_graph, const int32_t* gptr,
                           void* stream) {
-  return bn_act_bwd_stats_t<float>(dX, Y, mask, coef, relu, p_drop, M, N, slab, dP, node_graph, gptr, stream);
+  return bn_act_bwd_stats_t<float>(dX, Y, mask, coef, relu, p_drop, M, N, slab, slab_bytes, dP, node_graph, gptr, stream);
 }
 int cgnn_bn_act_bwd_apply(const float* dX, const float* Y, const uint8_t* mask, const float* coef,
                           const float* bwc, int32_t relu, float p_drop, int32_t relu_in,
-                          double* colsum_slab, float* dY, int64_t M, int32_t N, const float* dP,
+                          double* colsum_slab, int64_t colsum_slab_bytes, float* dY, int64_t M, int32_t N, const float* dP,
                           const int32_t* node_graph, const int32_t* gptr, void* stream) {
-  return bn_act_bwd_apply_t<float>(dX, Y, mask, coef, bwc, relu, p_drop, relu_in, colsum_slab, dY, M, N, dP,
+  return bn_act_bwd_apply_t<float>(dX, Y, mask, coef, bwc, relu, p_drop, relu_in, colsum_slab, colsum_slab_bytes, dY, M, N, dP,
                                    node_graph, gptr, stream);
 }
 
 // ---- fp16 storage (IEEE half arrays, fp32 arithmetic, fp64 statistics): same semantics
 typedef _Float16 cgnn_h;
-int cgnn_bn_act_fwd_stats_f16(const void* Y, int64_t M, int32_t N, double* slab, void* stream) {
-  return bn_act_fwd_stats_t<cgnn_h>(static_cast<const cgnn_h*>(Y), M, N, slab, stream);
+int cgnn_bn_act_fwd_stats_f16(const void* Y, int64_t M, int32_t N, double* slab, int64_t slab_bytes, void* stream) {
+  return bn_act_fwd_stats_t<cgnn_h>(static_cast<const cgnn_h*>(Y), M, N, slab, slab_bytes, stream);
 }
 int cgnn_bn_act_fwd_apply_f16(const void* Y, const float* coef, int32_t relu, float p_drop, uint64_t seed,
                               const uint32_t* seed_dev, uint8_t* mask_out, void* X, int64_t M,
@@ -635,18 +638,18 @@ int cgnn_bn_act_pool_fwd_f16(const void* Y, const float* coef, int32_t relu, flo
                                    gptr, num_graphs, P, N, Fsum, stream);
 }
 int cgnn_bn_act_bwd_stats_f16(const void* dX, const void* Y, const uint8_t* mask, const float* coef,
-                              int32_t relu, float p_drop, int64_t M, int32_t N, double* slab,
+                              int32_t relu, float p_drop, int64_t M, int32_t N, double* slab, int64_t slab_bytes,
                               const float* dP, const int32_t* node_graph, const int32_t* gptr,
                               void* stream) {
   return bn_act_bwd_stats_t<cgnn_h>(static_cast<const cgnn_h*>(dX), static_cast<const cgnn_h*>(Y), mask, coef,
-                                    relu, p_drop, M, N, slab, dP, node_graph, gptr, stream);
+                                    relu, p_drop, M, N, slab, slab_bytes, dP, node_graph, gptr, stream);
 }
 int cgnn_bn_act_bwd_apply_f16(const void* dX, const void* Y, const uint8_t* mask, const float* coef,
                               const float* bwc, int32_t relu, float p_drop, int32_t relu_in,
-                              double* colsum_slab, void* dY, int64_t M, int32_t N, const float* dP,
+                              double* colsum_slab, int64_t colsum_slab_bytes, void* dY, int64_t M, int32_t N, const float* dP,
                               const int32_t* node_graph, const int32_t* gptr, void* stream) {
   return bn_act_bwd_apply_t<cgnn_h>(static_cast<const cgnn_h*>(dX), static_cast<const cgnn_h*>(Y), mask, coef,
-                                    bwc, relu, p_drop, relu_in, colsum_slab, static_cast<cgnn_h*>(dY), M, N,
+                                    bwc, relu, p_drop, relu_in, colsum_slab, colsum_slab_bytes, static_cast<cgnn_h*>(dY), M, N,
                                     dP, node_graph, gptr, stream);
 }
 

@@ -1470,9 +1470,10 @@ int cgnn_set_fused_grid(int32_t workgroups) {
 }
 
 int cgnn_gcn_fused_fwd_first(const cgnn_tiles* t, const float* X0, int32_t F0, const float* W0,
-                             const float* bias, float* Y, double* stat_slab, void* stream) {
+                             const float* bias, float* Y, double* stat_slab, int64_t stat_slab_bytes, void* stream) {
   if (!tiles_ok(t) || F0 <= 0 || F0 > CGNN_FUSED_MAX_F0) return t && t->max_tile_rows > CGNN_FUSED_MAX_ROWS ? CGNN_EUNSUPPORTED : CGNN_EINVAL;
   if (!X0 || !W0 || !bias || !Y) return CGNN_EINVAL;
+  CGNN_NEED_BYTES(stat_slab, stat_slab_bytes, (int64_t)fused_grid() * 128 * (int64_t)sizeof(double));
   DropCfg d{};
   k_gcn_fwd<CGNN_FUSED_MAX_ROWS, true><<<fused_grid(), NTHR, 0, cgnn_stream(stream)>>>(
       *t, X0, F0, nullptr, d, 0, nullptr, W0, bias, Y, stat_slab);
@@ -1490,9 +1491,10 @@ int cgnn_rng_advance(uint32_t* state, int32_t n, void* stream) {
 int cgnn_gcn_fused_fwd(const cgnn_tiles* t, const float* Yprev, const cgnn_l0src* l0,
                        const float* bn_prev, float p_drop, uint64_t seed, const uint32_t* seed_dev,
                        uint8_t* mask_out, const float* W, const float* bias, float* Y,
-                       double* stat_slab, void* stream) {
+                       double* stat_slab, int64_t stat_slab_bytes, void* stream) {
   if (!tiles_ok(t)) return t && t->max_tile_rows > CGNN_FUSED_MAX_ROWS ? CGNN_EUNSUPPORTED : CGNN_EINVAL;
   if ((!Yprev && !l0src_ok(l0)) || !bn_prev || !W || !bias || !Y || p_drop < 0.f || p_drop >= 1.f) return CGNN_EINVAL;
+  CGNN_NEED_BYTES(stat_slab, stat_slab_bytes, (int64_t)fused_grid() * 128 * (int64_t)sizeof(double));
   int use_drop;
   DropCfg d = make_drop(p_drop, seed, &use_drop);
   d.dev_key = seed_dev;
@@ -1542,9 +1544,10 @@ int cgnn_gcn_fused_pool_fwd(const float* Y, const float* bn, float p_drop, uint6
 }
 
 int cgnn_gcn_fused_pool_bwd_sums(const float* dP, const float* F1, const float* F2,
-                                 const int32_t* gptr, int32_t num_graphs, double* s_slab,
+                                 const int32_t* gptr, int32_t num_graphs, double* s_slab, int64_t s_slab_bytes,
                                  void* stream) {
   if (num_graphs < 0 || !dP || !F1 || !F2 || !gptr || !s_slab) return CGNN_EINVAL;
+  CGNN_NEED_BYTES(s_slab, s_slab_bytes, (int64_t)fused_grid() * 128 * (int64_t)sizeof(double));
   // exactly cgnn_fused_grid() workgroups so that the slab has the documented row count
   k_pool_bwd_sums<<<fused_grid(), 128, 0, cgnn_stream(stream)>>>(dP, F1, F2, gptr, num_graphs, s_slab);
   CGNN_CHECK_LAUNCH();
@@ -1553,10 +1556,11 @@ int cgnn_gcn_fused_pool_bwd_sums(const float* dP, const float* F1, const float* 
 
 int cgnn_gcn_fused_pool_bwd(const float* dP, const float* Y, const float* bn, float p_drop,
                             const uint8_t* mask, const int32_t* gptr, int32_t num_graphs,
-                            float* dZ, double* s_slab, void* stream) {
+                            float* dZ, double* s_slab, int64_t s_slab_bytes, void* stream) {
   if (num_graphs < 0 || p_drop < 0.f || p_drop >= 1.f) return CGNN_EINVAL;
   if (!dP || !Y || !bn || !gptr || !s_slab) return CGNN_EINVAL;   /* dZ may be NULL: sums only */
   if (p_drop > 0.f && !mask) return CGNN_EINVAL;
+  CGNN_NEED_BYTES(s_slab, s_slab_bytes, (int64_t)fused_grid() * 128 * (int64_t)sizeof(double));
   int use_drop;
   DropCfg d = make_drop(p_drop, 0, &use_drop);
   // exactly cgnn_fused_grid() workgroups so that the slab has the documented row count
@@ -1577,7 +1581,7 @@ int cgnn_bn_bwd_finalize(const double* sums, double count, const double* count_d
 int cgnn_gcn_fused_bwd(const cgnn_tiles* t, const float* dZ, const float* Y, const float* bn,
                        const float* bwc, const float* Yprev, const cgnn_l0src* l0,
                        const float* bn_prev, float p_drop, const uint8_t* mask_prev, const float* W,
-                       float* dZprev, double* s_slab_prev, float* dW_slab, double* db_slab,
+                       float* dZprev, double* s_slab_prev, int64_t s_slab_prev_bytes, float* dW_slab, int64_t dW_slab_bytes, double* db_slab, int64_t db_slab_bytes,
                        const float* dP, const int32_t* node_graph, const int32_t* gptr,
                        const uint8_t* mask_cur, void* stream) {
   if (!tiles_ok(t)) return t && t->max_tile_rows > CGNN_FUSED_MAX_ROWS ? CGNN_EUNSUPPORTED : CGNN_EINVAL;
@@ -1586,6 +1590,9 @@ int cgnn_gcn_fused_bwd(const cgnn_tiles* t, const float* dZ, const float* Y, con
     return CGNN_EINVAL;
   if (p_drop > 0.f && !mask_prev) return CGNN_EINVAL;
   if (dP ? (!node_graph || !gptr || (p_drop > 0.f && !mask_cur)) : !dZ) return CGNN_EINVAL;
+  CGNN_NEED_BYTES(s_slab_prev, s_slab_prev_bytes, (int64_t)fused_grid() * 128 * (int64_t)sizeof(double));
+  CGNN_NEED_BYTES(dW_slab, dW_slab_bytes, (int64_t)fused_grid() * HID * HID * (int64_t)sizeof(float));
+  CGNN_NEED_BYTES(db_slab, db_slab_bytes, (int64_t)fused_grid() * HID * (int64_t)sizeof(double));
   int use_drop;
   DropCfg d = make_drop(p_drop, 0, &use_drop);
   PoolIn pin{dP, node_graph, gptr, mask_cur};
@@ -1603,13 +1610,15 @@ int cgnn_gcn_fused_bwd(const cgnn_tiles* t, const float* dZ, const float* Y, con
 }
 
 int cgnn_gcn_fused_bwd_first(const cgnn_tiles* t, const float* dZ, const float* Y, const float* bn,
-                             const float* bwc, const float* X0, int32_t F0, float* dW_slab,
-                             double* db_slab, float p_drop, const float* dP,
+                             const float* bwc, const float* X0, int32_t F0, float* dW_slab, int64_t dW_slab_bytes,
+                             double* db_slab, int64_t db_slab_bytes, float p_drop, const float* dP,
                              const int32_t* node_graph, const int32_t* gptr,
                              const uint8_t* mask_cur, void* stream) {
   if (!tiles_ok(t) || F0 <= 0 || F0 > CGNN_FUSED_MAX_F0) return t && t->max_tile_rows > CGNN_FUSED_MAX_ROWS ? CGNN_EUNSUPPORTED : CGNN_EINVAL;
   if (!Y || !bn || !bwc || !X0 || !dW_slab || !db_slab || p_drop < 0.f || p_drop >= 1.f) return CGNN_EINVAL;
   if (dP ? (!node_graph || !gptr || (p_drop > 0.f && !mask_cur)) : !dZ) return CGNN_EINVAL;
+  CGNN_NEED_BYTES(dW_slab, dW_slab_bytes, (int64_t)fused_grid() * HID * 16 * (int64_t)sizeof(float));
+  CGNN_NEED_BYTES(db_slab, db_slab_bytes, (int64_t)fused_grid() * HID * (int64_t)sizeof(double));
   int use_drop;
   DropCfg d = make_drop(dP ? p_drop : 0.f, 0, &use_drop);
   PoolIn pin{dP, node_graph, gptr, mask_cur};

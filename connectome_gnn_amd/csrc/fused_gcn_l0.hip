@@ -450,13 +450,14 @@ int cgnn_gcn_l0_center(const cgnn_tiles* t, const float* X0, int32_t F0, float* 
 }
 
 int cgnn_gcn_l0_fwd(const cgnn_tiles* t, const float* X0, int32_t F0, const float* W0,
-                    const float* bias, float* P0, float* Y, double* stat_slab, const float* center,
+                    const float* bias, float* P0, float* Y, double* stat_slab, int64_t stat_slab_bytes, const float* center,
                     float* w_eff, float* mean_offset, void* stream) {
   if (!t || F0 <= 0 || F0 > FP || t->max_tile_rows > CGNN_FUSED_MAX_ROWS) return t && F0 > FP ? CGNN_EUNSUPPORTED : CGNN_EINVAL;
   if (Y && (center || w_eff || mean_offset)) return CGNN_EINVAL;   // the centred form belongs to the factored layer
   if (center && (!w_eff || !mean_offset || F0 >= FP)) return CGNN_EINVAL;   // column 7 must be spare
   if (!center && (w_eff || mean_offset)) return CGNN_EINVAL;
   if (t->num_tiles == 0) return CGNN_OK;
+  CGNN_NEED_BYTES(stat_slab, stat_slab_bytes, (int64_t)l0_grid(t->num_nodes) * 128 * (int64_t)sizeof(double));
   if (!X0 || !W0 || !bias || !P0 || !t->tile_ptr || !t->tile_blk || !t->blk_off_dst ||
       !t->ent_dst || !t->dis)
     return CGNN_EINVAL;
@@ -471,11 +472,13 @@ int cgnn_gcn_l0_fwd(const cgnn_tiles* t, const float* X0, int32_t F0, const floa
 }
 
 int cgnn_gcn_l0_bwd(const float* dZ, const float* Y, const cgnn_l0src* l0, const float* bn,
-                    const float* bwc, const float* P0, int64_t num_nodes, float* dW_slab,
-                    double* db_slab, const float* center, void* stream) {
+                    const float* bwc, const float* P0, int64_t num_nodes, float* dW_slab, int64_t dW_slab_bytes,
+                    double* db_slab, int64_t db_slab_bytes, const float* center, void* stream) {
   if (num_nodes < 0 || !dZ || !bn || !bwc || !P0 || !dW_slab || !db_slab) return CGNN_EINVAL;
   if (!Y && !(l0 && l0->W0 && l0->b0 && l0->F0 >= 1 && l0->F0 <= FP)) return CGNN_EINVAL;
   if (center && (Y || l0->F0 < 2)) return CGNN_EINVAL;
+  CGNN_NEED_BYTES(dW_slab, dW_slab_bytes, (int64_t)l0_grid(num_nodes) * HID * FP * (int64_t)sizeof(float));
+  CGNN_NEED_BYTES(db_slab, db_slab_bytes, (int64_t)l0_grid(num_nodes) * HID * (int64_t)sizeof(double));
   if (Y)
     k_l0_bwd<false><<<l0_grid(num_nodes), L0BTHR, 0, cgnn_stream(stream)>>>(dZ, Y, cgnn_l0src{}, bn, bwc, P0,
                                                                    num_nodes, dW_slab, db_slab, nullptr);

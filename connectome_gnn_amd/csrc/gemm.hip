@@ -337,10 +337,11 @@ int cgnn_linear_fwd_f32(const float* X1, int64_t ldx1, int32_t K1, const float* 
 int cgnn_linear_fwd_stats_f32(const float* X1, int64_t ldx1, int32_t K1, const float* X2,
                               int64_t ldx2, int32_t K2, const float* W, const float* bias,
                               int32_t relu, float* Y, int64_t ldy, int64_t M, int32_t N,
-                              double* stat_slab, void* stream) {
+                              double* stat_slab, int64_t stat_slab_bytes, void* stream) {
   if (M <= 0 || N <= 0 || K1 <= 0 || K2 < 0 || ldx1 < K1 || ldy < N || !stat_slab) return CGNN_EINVAL;
   if (K2 > 0 && (!X2 || ldx2 < K2)) return CGNN_EINVAL;
   if (!X1 || !W || !Y) return CGNN_EINVAL;
+  CGNN_NEED_BYTES(stat_slab, stat_slab_bytes, (int64_t)cgnn_fused_grid() * 2 * N * (int64_t)sizeof(double));
   if (!cgnn_ws_linear_fwd(X1, ldx1, K1, X2, ldx2, K2, W, bias, relu, Y, ldy, M, N, stat_slab,
                           cgnn_stream(stream)))
     return CGNN_EUNSUPPORTED;      // caller: cgnn_linear_fwd_f32 + cgnn_bn_act_fwd_stats
@@ -392,32 +393,41 @@ static int64_t bwd_weight_slab_words(int64_t M, int32_t N, int32_t K) {
 
 int64_t cgnn_linear_bwd_weight_workspace_bytes(int64_t M, int32_t N, int32_t K) {
   if (M < 0 || N <= 0 || K <= 0) return CGNN_EINVAL;
-  int64_t words = bwd_weight_slab_words(M, N, K);
-  // cgnn_linear_bwd_weight2_f32 with two equal panels (K = 2 * K1) falls back to one call per panel when
-  // the joint shape is outside the weight-stationary kernel: each of those may take ITS weight-stationary
-  // form (256 partials of [N x K/2] -- far more than the generic chunks of [N x K]).  GraphSAGE hidden
-  // 256 on >= 4096 nodes wrote 33 MB into a 1 MB slab before this line existed.
-  if (K % 2 == 0) {
-    const int64_t panel = bwd_weight_slab_words(M, N, K / 2);
-    if (panel > words) words = panel;
-  }
-  return cgnn_align_up(words * (int64_t)sizeof(float), 256);
+  return cgnn_align_up(bwd_weight_slab_words(M, N, K) * (int64_t)sizeof(float), 256);
+}
+
+// both panels in one pass over dY when the joint shape fits the weight-stationary kernel, else one
+// cgnn_linear_bwd_weight_f32 per panel, each of which may take ITS weight-stationary form (one partial of
+// [N x Ki] per workgroup -- GraphSAGE hidden 256 on >= 4096 nodes wrote 33 MB into a slab sized for the
+// joint generic form): the slab must hold the largest of the three
+static int64_t bwd_weight2_slab_words(int64_t M, int32_t N, int32_t K1, int32_t K2) {
+  int64_t words = cgnn_ws_bwd_weight_partials(M, N, K1 + K2) * (int64_t)N * (K1 + K2);
+  const int64_t w1 = bwd_weight_slab_words(M, N, K1), w2 = bwd_weight_slab_words(M, N, K2);
+  if (w1 > words) words = w1;
+  if (w2 > words) words = w2;
+  return words;
+}
+
+int64_t cgnn_linear_bwd_weight2_workspace_bytes(int64_t M, int32_t N, int32_t K1, int32_t K2) {
+  if (M < 0 || N <= 0 || K1 <= 0 || K2 <= 0) return CGNN_EINVAL;
+  return cgnn_align_up(bwd_weight2_slab_words(M, N, K1, K2) * (int64_t)sizeof(float), 256);
 }
 
 int cgnn_linear_bwd_weight_f32(const float* dY, int64_t lddy, const float* X, int64_t ldx,
                                float* dW, int32_t ldw, int32_t k0, int64_t M, int32_t N, int32_t K,
-                               void* slab, void* stream) {
+                               void* slab, int64_t slab_bytes, void* stream) {
   if (M < 0 || N <= 0 || K <= 0 || k0 < 0 || ldw < k0 + K || lddy < N || ldx < K)
     return CGNN_EINVAL;
   if (!dW || !slab) return CGNN_EINVAL;
   if (M > 0 && (!dY || !X)) return CGNN_EINVAL;
+  CGNN_NEED_BYTES(slab, slab_bytes, bwd_weight_slab_words(M, N, K) * (int64_t)sizeof(float));
   hipStream_t st = cgnn_stream(stream);
   if (N == 256 && cgnn_ws_bwd_weight_partials(M, 128, K) > 0 && lddy % 4 == 0) {
     // two halves of 128 output rows of dW through the weight-stationary kernel
-    const int rc = cgnn_linear_bwd_weight_f32(dY, lddy, X, ldx, dW, ldw, k0, M, 128, K, slab, stream);
+    const int rc = cgnn_linear_bwd_weight_f32(dY, lddy, X, ldx, dW, ldw, k0, M, 128, K, slab, slab_bytes, stream);
     if (rc != CGNN_OK) return rc;
     return cgnn_linear_bwd_weight_f32(dY + 128, lddy, X, ldx, dW + (int64_t)128 * ldw, ldw, k0, M, 128, K,
-                                      slab, stream);
+                                      slab, slab_bytes, stream);
   }
   int64_t nchunks = (M + WCHUNK - 1) / WCHUNK;
   const int tiles_n = (N + 63) / 64, tiles_k = (K + 63) / 64;
@@ -439,11 +449,12 @@ int cgnn_linear_bwd_weight_f32(const float* dY, int64_t lddy, const float* X, in
 
 int cgnn_linear_bwd_weight2_f32(const float* dY, int64_t lddy, const float* X1, int64_t ldx1,
                                 int32_t K1, const float* X2, int64_t ldx2, int32_t K2, float* dW,
-                                int32_t ldw, int64_t M, int32_t N, void* slab, void* stream) {
+                                int32_t ldw, int64_t M, int32_t N, void* slab, int64_t slab_bytes, void* stream) {
   if (M < 0 || N <= 0 || K1 <= 0 || K2 <= 0 || ldw < K1 + K2 || lddy < N || ldx1 < K1 || ldx2 < K2)
     return CGNN_EINVAL;
   if (!dW || !slab) return CGNN_EINVAL;
   if (M > 0 && (!dY || !X1 || !X2)) return CGNN_EINVAL;
+  CGNN_NEED_BYTES(slab, slab_bytes, bwd_weight2_slab_words(M, N, K1, K2) * (int64_t)sizeof(float));
   hipStream_t st = cgnn_stream(stream);
   if (cgnn_ws_linear_bwd_weight(dY, lddy, X1, ldx1, K1, X2, ldx2, K2, static_cast<float*>(slab), M, N, st)) {
     CGNN_CHECK_LAUNCH();
@@ -454,9 +465,9 @@ int cgnn_linear_bwd_weight2_f32(const float* dY, int64_t lddy, const float* X1, 
     return CGNN_OK;
   }
   // shapes outside the weight-stationary kernel: one panel at a time
-  const int rc = cgnn_linear_bwd_weight_f32(dY, lddy, X1, ldx1, dW, ldw, 0, M, N, K1, slab, stream);
+  const int rc = cgnn_linear_bwd_weight_f32(dY, lddy, X1, ldx1, dW, ldw, 0, M, N, K1, slab, slab_bytes, stream);
   if (rc != CGNN_OK) return rc;
-  return cgnn_linear_bwd_weight_f32(dY, lddy, X2, ldx2, dW, ldw, K1, M, N, K2, slab, stream);
+  return cgnn_linear_bwd_weight_f32(dY, lddy, X2, ldx2, dW, ldw, K1, M, N, K2, slab, slab_bytes, stream);
 }
 
 int64_t cgnn_colsum_workspace_bytes(int64_t M, int32_t N) {
@@ -466,12 +477,13 @@ int64_t cgnn_colsum_workspace_bytes(int64_t M, int32_t N) {
   return cgnn_align_up(nb * (int64_t)N * (int64_t)sizeof(double), 256);
 }
 
-int cgnn_colsum_f32(const float* A, int64_t lda, float* out, int64_t M, int32_t N, void* slab,
+int cgnn_colsum_f32(const float* A, int64_t lda, float* out, int64_t M, int32_t N, void* slab, int64_t slab_bytes,
                     void* stream) {
   if (M < 0 || N <= 0 || lda < N || !out || !slab) return CGNN_EINVAL;
   if (M > 0 && !A) return CGNN_EINVAL;
   hipStream_t st = cgnn_stream(stream);
   const int64_t nb = (M + CS_ROWS - 1) / CS_ROWS;
+  CGNN_NEED_BYTES(slab, slab_bytes, (nb > 0 ? nb : 1) * (int64_t)N * (int64_t)sizeof(double));
   if (nb > 0) {
     k_colsum_partial<<<(unsigned)nb, 256, 0, st>>>(A, lda, M, N, static_cast<double*>(slab));
     CGNN_CHECK_LAUNCH();

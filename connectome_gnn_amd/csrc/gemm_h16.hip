@@ -458,13 +458,14 @@ int cgnn_linear_fwd_f16(const void* X, int64_t ldx, int32_t K, const float* W, i
 }
 
 int cgnn_linear_fwd_stats_f16(const void* X, int64_t ldx, int32_t K, const float* W, int32_t ldw, int32_t Kw,
-                              const float* bias, void* Y, int64_t ldy, int64_t M, int32_t N, double* stat_slab,
+                              const float* bias, void* Y, int64_t ldy, int64_t M, int32_t N, double* stat_slab, int64_t stat_slab_bytes,
                               void* stream) {
   if (M < 0 || K <= 0 || N <= 0 || Kw <= 0 || Kw > K || ldw < Kw || ldx < K || ldy < N || !stat_slab) return CGNN_EINVAL;
   if (!hg_shape_ok(K, N) || N < 128 || ldx % 8 || ldy % 8 || (reinterpret_cast<uintptr_t>(X) & 15) ||
       (reinterpret_cast<uintptr_t>(Y) & 15) || (reinterpret_cast<uintptr_t>(W) & 15))
     return CGNN_EUNSUPPORTED;
   if (!X || !W || !Y) return CGNN_EINVAL;
+  CGNN_NEED_BYTES(stat_slab, stat_slab_bytes, (int64_t)cgnn_fused_grid() * 2 * N * (int64_t)sizeof(double));
   HgStats hs{};
   hs.slab = stat_slab;
   return hg_launch<false, 1>(static_cast<const __half*>(X), ldx, K, W, ldw, Kw, bias, static_cast<__half*>(Y), ldy, M,
@@ -492,7 +493,7 @@ int64_t cgnn_linear_bwd_weight_f16_workspace_bytes(int64_t M, int32_t N, int32_t
 }
 
 int cgnn_linear_bwd_weight_f16(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW,
-                               int32_t ldw, int32_t Kw, int64_t M, int32_t N, int32_t K, void* slab,
+                               int32_t ldw, int32_t Kw, int64_t M, int32_t N, int32_t K, void* slab, int64_t slab_bytes,
                                void* stream) {
   if (M < 0 || N <= 0 || K <= 0 || Kw <= 0 || Kw > K || ldw < Kw || lddy < N || ldx < K) return CGNN_EINVAL;
   if (N % 64 || K % 64 || N > 256 || K > 256 || lddy % 8 || ldx % 8 || (reinterpret_cast<uintptr_t>(dY) & 15) ||
@@ -504,6 +505,7 @@ int cgnn_linear_bwd_weight_f16(const void* dY, int64_t lddy, const void* X, int6
   int nruns, tnw, tkw;
   int64_t per;
   wg_plan(M, N, K, &tnw, &tkw, &nruns, &per);
+  CGNN_NEED_BYTES(slab, slab_bytes, (int64_t)nruns * N * K * (int64_t)sizeof(float));
   const int grid = nruns * (N / tnw) * (K / tkw);                  // every (run, tile)
   const __half* a = static_cast<const __half*>(dY);
   const __half* b = static_cast<const __half*>(X);

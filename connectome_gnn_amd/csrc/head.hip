@@ -702,11 +702,13 @@ int cgnn_cross_entropy_f32(const float* logits, const int64_t* labels, int32_t B
 
 int cgnn_head_bwd_f32(const float* dlogits, const float* P, const float* H1, const float* fac,
                       int32_t B, int32_t H, int32_t H2, int32_t C, const float* W1, const float* W2,
-                      float* dP, float* slab, void* stream) {
+                      float* dP, float* slab, int64_t slab_bytes, void* stream) {
   if (B <= 0) return CGNN_EINVAL;
   if (!head_ok(H, H2, C)) return CGNN_EUNSUPPORTED;
   if (!dlogits || !P || !H1 || !fac || !W1 || !W2 || !dP || !slab) return CGNN_EINVAL;
   const int tg = head_bwd_grid(B, H, H2, C);
+  const int64_t wd = (int64_t)H2 * H + H2 + (int64_t)C * H2 + C;      // dW1 | db1 | dW2 | db2 per slab row
+  CGNN_NEED_BYTES(slab, slab_bytes, (int64_t)(tg > 0 ? tg : head_grid(B, H2)) * wd * (int64_t)sizeof(float));
   if (tg > 0) {
     if (H == 64) k_head_bwd_t<64, 32, 2><<<tg, 256, 0, cgnn_stream(stream)>>>(dlogits, P, H1, fac, B, W1, W2, dP, slab);
     else if (H == 128) k_head_bwd_t<128, 64, 2><<<tg, 256, 0, cgnn_stream(stream)>>>(dlogits, P, H1, fac, B, W1, W2, dP, slab);
@@ -731,7 +733,7 @@ int cgnn_head_loss_grid(int32_t B, int32_t H, int32_t H2, int32_t C) {
 int cgnn_head_loss_f32(const float* P, int32_t B, int32_t H, int32_t H2, int32_t C, const float* W1,
                        const float* b1, const float* W2, const float* b2, const int64_t* labels,
                        float p_drop, uint64_t seed, const uint32_t* seed_dev, float* H1, float* fac,
-                       float* logits, float* dP, float* slab, void* stream) {
+                       float* logits, float* dP, float* slab, int64_t slab_bytes, void* stream) {
   if (B <= 0 || p_drop < 0.f || p_drop >= 1.f) return CGNN_EINVAL;
   if (!head_ok(H, H2, C) || !head_tiled(H, H2, C)) return CGNN_EUNSUPPORTED;
   if (!P || !W1 || !b1 || !W2 || !b2 || !labels || !H1 || !fac || !logits || !dP || !slab) return CGNN_EINVAL;
@@ -746,6 +748,8 @@ int cgnn_head_loss_f32(const float* P, int32_t B, int32_t H, int32_t H2, int32_t
   const int use = p_drop > 0.f ? 1 : 0;
   const int rows = head_loss_rows(B, H);
   const int tg = head_loss_grid(B, H);
+  CGNN_NEED_BYTES(slab, slab_bytes,
+                  (int64_t)tg * ((int64_t)H2 * H + H2 + (int64_t)C * H2 + C + 1) * (int64_t)sizeof(float));
   hipStream_t st = cgnn_stream(stream);
 #define CGNN_HL(HH, R) k_head_loss_t<HH, HH / 2, 2, R><<<tg, 256, 0, st>>>(P, B, W1, b1, W2, b2, labels, d, use, H1, fac, logits, dP, slab)
   if (H == 64) CGNN_HL(64, 16);

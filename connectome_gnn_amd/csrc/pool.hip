@@ -68,9 +68,13 @@ int cgnn_pool_mean_fwd_f32(const float* X, int64_t ldx, const int32_t* gptr, flo
   if (num_graphs < 0 || F <= 0 || ldx < F) return CGNN_EINVAL;
   if (num_graphs == 0) return CGNN_OK;
   if (!X || !gptr || !P) return CGNN_EINVAL;
-  if (num_graphs > 65535) return CGNN_EUNSUPPORTED;
-  k_pool_mean_fwd<<<dim3((unsigned)((F + 31) / 32), (unsigned)num_graphs), 256, 0, cgnn_stream(stream)>>>(X, ldx, gptr, P, F);
-  CGNN_CHECK_LAUNCH();
+  // graphs ride on gridDim.y (<= 65535): larger batches (whole-dataset evaluation of small graphs) go in runs
+  for (int32_t g0 = 0; g0 < num_graphs; g0 += 65535) {
+    const int32_t ng = num_graphs - g0 < 65535 ? num_graphs - g0 : 65535;
+    k_pool_mean_fwd<<<dim3((unsigned)((F + 31) / 32), (unsigned)ng), 256, 0, cgnn_stream(stream)>>>(
+        X, ldx, gptr + g0, P + (int64_t)g0 * F, F);
+    CGNN_CHECK_LAUNCH();
+  }
   return CGNN_OK;
 }
 
@@ -79,11 +83,14 @@ int cgnn_pool_mean_bwd_f32(const float* dP, const int32_t* gptr, float* dX, int6
   if (num_graphs < 0 || F <= 0 || lddx < F) return CGNN_EINVAL;
   if (num_graphs == 0) return CGNN_OK;
   if (!dP || !gptr || !dX) return CGNN_EINVAL;
-  if (num_graphs > 65535) return CGNN_EUNSUPPORTED;
   // chunks per graph: enough blocks to fill the chip at any batch size, at most one per 1024 elements of a 1024-row graph
   const unsigned chunks = (unsigned)(num_graphs >= 2048 ? 1 : (2048 + num_graphs - 1) / num_graphs);
-  k_pool_mean_bwd<<<dim3(chunks, (unsigned)num_graphs), 256, 0, cgnn_stream(stream)>>>(dP, gptr, dX, lddx, F);
-  CGNN_CHECK_LAUNCH();
+  for (int32_t g0 = 0; g0 < num_graphs; g0 += 65535) {        // (gridDim.y <= 65535, as in the forward)
+    const int32_t ng = num_graphs - g0 < 65535 ? num_graphs - g0 : 65535;
+    k_pool_mean_bwd<<<dim3(chunks, (unsigned)ng), 256, 0, cgnn_stream(stream)>>>(dP + (int64_t)g0 * F, gptr + g0, dX,
+                                                                                lddx, F);
+    CGNN_CHECK_LAUNCH();
+  }
   return CGNN_OK;
 }
 

@@ -550,10 +550,12 @@ int64_t cgnn_csr_workspace_bytes(int64_t nn, int64_t ne) {
 int cgnn_csr_build(const int64_t* edge_index, const int64_t* node_graph, int64_t nn, int64_t ne,
                    int32_t* rowptr_dst, int32_t* eid_dst, int32_t* col_dst,
                    int32_t* rowptr_src, int32_t* eid_src, int32_t* col_src, int32_t* flags,
-                   void* workspace, void* stream) {
+                   void* workspace, int64_t workspace_bytes, void* stream) {
   if (nn < 0 || ne < 0 || nn >= INT32_MAX || ne >= INT32_MAX) return CGNN_EINVAL;
   if (!rowptr_dst || !rowptr_src || !flags || !workspace) return CGNN_EINVAL;
   if (ne > 0 && (!edge_index || !eid_dst || !col_dst || !eid_src || !col_src)) return CGNN_EINVAL;
+  CGNN_NEED_BYTES(workspace, workspace_bytes,
+                  (2 * nn + 2 * ((nn + 1 + kScanTile - 1) / kScanTile)) * (int64_t)sizeof(int32_t));
   hipStream_t st = cgnn_stream(stream);
   const int64_t* src = edge_index;
   const int64_t* dst = edge_index + ne;
@@ -676,10 +678,12 @@ int cgnn_sage_norm(const int64_t* edge_index, const float* w, int64_t nn, int64_
 }
 
 int cgnn_bell_plan(const int32_t* tile_ptr, const int32_t* tile_blk, int32_t num_tiles,
-                   int32_t num_blocks, const int32_t* rowptr, int32_t* blk_off, int32_t* scratch,
+                   int32_t num_blocks, const int32_t* rowptr, int32_t* blk_off, int32_t* scratch, int64_t scratch_bytes,
                    void* stream) {
   if (num_tiles < 0 || num_blocks < 0 || !blk_off || !scratch) return CGNN_EINVAL;
   if (num_tiles > 0 && (!tile_ptr || !tile_blk || !rowptr)) return CGNN_EINVAL;
+  CGNN_NEED_BYTES(scratch, scratch_bytes,
+                  (((int64_t)num_blocks + 1 + kScanTile - 1) / kScanTile) * (int64_t)sizeof(int32_t));
   hipStream_t st = cgnn_stream(stream);
   k_zero_i32<<<blocks_for(num_blocks + 1, 256), 256, 0, st>>>(blk_off, num_blocks + 1);
   if (num_tiles > 0) k_bell_width<<<num_tiles, 64, 0, st>>>(tile_ptr, tile_blk, num_tiles, rowptr, blk_off);

@@ -174,13 +174,13 @@ class FusedGCNEncode(torch.autograd.Function):
                     slab = torch.empty(slab_rows, 128, dtype=torch.float64, device=dev) if training else None
                     with _lib.timed("cgnn_gcn_l0_fwd"):
                         _lib.check(lib.cgnn_gcn_l0_fwd(
-                            tp, _lib.ptr(x0), f0, _lib.ptr(w), _lib.ptr(b), _lib.ptr(p0), None, _lib.ptr(slab),
+                            tp, _lib.ptr(x0), f0, _lib.ptr(w), _lib.ptr(b), _lib.ptr(p0), None, _lib.ptr(slab), _lib.nbytes(slab),
                             _lib.ptr(center), _lib.ptr(w_eff), _lib.ptr(mean_off), st()), "cgnn_gcn_l0_fwd")
                 elif l == 0:
                     with _lib.timed("cgnn_gcn_fused_fwd_first"):
                         _lib.check(lib.cgnn_gcn_fused_fwd_first(
                             tp, _lib.ptr(x0), x0.shape[1], _lib.ptr(w), _lib.ptr(b), _lib.ptr(y),
-                            _lib.ptr(stat_slab), st()), "cgnn_gcn_fused_fwd_first")
+                            _lib.ptr(stat_slab), _lib.nbytes(stat_slab), st()), "cgnn_gcn_fused_fwd_first")
                 else:
                     mask = torch.empty(nn_ * 16, dtype=torch.uint8, device=dev) if p > 0 else None
                     seed = _lib.next_seed(dev) if p > 0 else 0
@@ -188,7 +188,7 @@ class FusedGCNEncode(torch.autograd.Function):
                         _lib.check(lib.cgnn_gcn_fused_fwd(
                             tp, _lib.ptr(ys[-1]), ctypes.byref(l0src) if ys[-1] is None else None,
                             _lib.ptr(bns[-1]), p, seed, rng_ptr(l), _lib.ptr(mask),
-                            _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), _lib.ptr(stat_slab), st()),
+                            _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), _lib.ptr(stat_slab), _lib.nbytes(stat_slab), st()),
                             "cgnn_gcn_fused_fwd")
                     masks.append(mask)
                 bn_mod = bns_mod[l]
@@ -311,11 +311,11 @@ class FusedGCNEncode(torch.autograd.Function):
                 if c.fsum is not None:
                     _lib.check(lib.cgnn_gcn_fused_pool_bwd_sums(
                         _lib.ptr(d_pooled), _lib.ptr(c.fsum), c.fsum.data_ptr() + 4 * B * HID, _lib.ptr(s.gptr), B,
-                        _lib.ptr(s_slab), st()), "cgnn_gcn_fused_pool_bwd_sums")
+                        _lib.ptr(s_slab), _lib.nbytes(s_slab), st()), "cgnn_gcn_fused_pool_bwd_sums")
                 else:
                     _lib.check(lib.cgnn_gcn_fused_pool_bwd(
                         _lib.ptr(d_pooled), _lib.ptr(c.ys[-1]), _lib.ptr(c.bns[-1]), c.p,
-                        _lib.ptr(c.masks[-1]), _lib.ptr(s.gptr), B, None, _lib.ptr(s_slab), st()),
+                        _lib.ptr(c.masks[-1]), _lib.ptr(s.gptr), B, None, _lib.ptr(s_slab), _lib.nbytes(s_slab), st()),
                         "cgnn_gcn_fused_pool_bwd")
                 bwc = bn_backward(L - 1)
             for l in range(L - 1, 0, -1):
@@ -328,8 +328,8 @@ class FusedGCNEncode(torch.autograd.Function):
                         tp, _lib.ptr(dz), _lib.ptr(c.ys[l]), _lib.ptr(c.bns[l]), _lib.ptr(bwc),
                         _lib.ptr(c.ys[l - 1]), ctypes.byref(c.l0src) if c.ys[l - 1] is None else None,
                         _lib.ptr(c.bns[l - 1]), c.p, _lib.ptr(c.masks[l - 1]),
-                        _lib.ptr(w), _lib.ptr(dz_prev), _lib.ptr(s_slab), _lib.ptr(dw_slab),
-                        _lib.ptr(db_slab), *extra, st()), "cgnn_gcn_fused_bwd")
+                        _lib.ptr(w), _lib.ptr(dz_prev), _lib.ptr(s_slab), _lib.nbytes(s_slab), _lib.ptr(dw_slab), _lib.nbytes(dw_slab),
+                        _lib.ptr(db_slab), _lib.nbytes(db_slab), *extra, st()), "cgnn_gcn_fused_bwd")
                 dw, db = torch.empty(HID, HID, **f32), torch.empty(HID, **f32)
                 jobs.append((dw_slab, db_slab, grid, HID, HID, dw, db))
                 grads[4 * l], grads[4 * l + 1] = dw, db
@@ -344,7 +344,7 @@ class FusedGCNEncode(torch.autograd.Function):
                 with _lib.timed("cgnn_gcn_l0_bwd"):
                     _lib.check(lib.cgnn_gcn_l0_bwd(
                         _lib.ptr(dz), None, ctypes.byref(c.l0src), _lib.ptr(c.bns[0]), _lib.ptr(bwc),
-                        _lib.ptr(c.p0), nn_, _lib.ptr(dw_slab0), _lib.ptr(db_slab0), _lib.ptr(c.l0keep[2]), st()),
+                        _lib.ptr(c.p0), nn_, _lib.ptr(dw_slab0), _lib.nbytes(dw_slab0), _lib.ptr(db_slab0), _lib.nbytes(db_slab0), _lib.ptr(c.l0keep[2]), st()),
                         "cgnn_gcn_l0_bwd")
                 jobs.append((dw_slab0, db_slab0, g0, 8, c.f0, dw0, db0))
             else:
@@ -354,7 +354,7 @@ class FusedGCNEncode(torch.autograd.Function):
                 with _lib.timed("cgnn_gcn_fused_bwd_first"):
                     _lib.check(lib.cgnn_gcn_fused_bwd_first(
                         tp, _lib.ptr(dz), _lib.ptr(c.ys[0]), _lib.ptr(c.bns[0]), _lib.ptr(bwc),
-                        _lib.ptr(c.x0), c.f0, _lib.ptr(dw_slab), _lib.ptr(db_slab), c.p, *extra, st()),
+                        _lib.ptr(c.x0), c.f0, _lib.ptr(dw_slab), _lib.nbytes(dw_slab), _lib.ptr(db_slab), _lib.nbytes(db_slab), c.p, *extra, st()),
                         "cgnn_gcn_fused_bwd_first")
                 jobs.append((dw_slab, db_slab, grid, 16, c.f0, dw0, db0))
             grads[0], grads[1] = dw0, db0

@@ -40,8 +40,8 @@ MAX_NODES = 1024          # dense pitch limit of cgnn_dense_adj_f16
 
 def eligible(model, batch, structure: BatchStructure) -> Optional[str]:
     hid = model.convs[0].linear.weight.shape[0]
-    if hid % 64 or not bool(_lib.load().cgnn_bn_act_width_ok(hid)):
-        return "hidden_dim is not 64, 128, 256, ..."
+    if hid not in (64, 128, 256):
+        return "hidden_dim is not 64, 128 or 256 (the half projections of gemm_h16.hip)"
     if not structure.block_diagonal:
         return "edges cross graph boundaries"
     if structure.max_nodes_per_graph > MAX_NODES:
@@ -145,7 +145,7 @@ class GcnHalfEncode(torch.autograd.Function):
                     y = _agg(s, mf, t, b, slab)
                 if training and slab is None:
                     slab = torch.empty(rows, 2 * hid, dtype=torch.float64, device=dev)
-                    _lib.check(lib.cgnn_bn_act_fwd_stats_f16(_lib.ptr(y), n_nodes, hid, _lib.ptr(slab), sp),
+                    _lib.check(lib.cgnn_bn_act_fwd_stats_f16(_lib.ptr(y), n_nodes, hid, _lib.ptr(slab), _lib.nbytes(slab), sp),
                                "cgnn_bn_act_fwd_stats_f16")
                 bn = bns_mod[li]
                 coef = _f32(dev, 4 * hid)
@@ -200,7 +200,7 @@ class GcnHalfEncode(torch.autograd.Function):
                 else:
                     slab, srows = torch.empty(rows, 2 * hid, dtype=torch.float64, device=dev), rows
                     _lib.check(lib.cgnn_bn_act_bwd_stats_f16(_lib.ptr(dx), _lib.ptr(y), _lib.ptr(mask), _lib.ptr(coef),
-                                                             1, sv.p, n_nodes, hid, _lib.ptr(slab), *pool, sp),
+                                                             1, sv.p, n_nodes, hid, _lib.ptr(slab), _lib.nbytes(slab), *pool, sp),
                                "cgnn_bn_act_bwd_stats_f16")
                     dgamma, dbeta, bwc = _f32(dev, hid), _f32(dev, hid), _f32(dev, 2 * hid)
                     _lib.check(lib.cgnn_bn_act_bwd_finalize(_lib.ptr(slab), srows, hid, float(max(n_nodes, 1)), None,
@@ -219,7 +219,7 @@ class GcnHalfEncode(torch.autograd.Function):
                     cs_slab = torch.empty(cs_rows, hid, dtype=torch.float64, device=dev)
                     dy = torch.empty_like(y)
                     _lib.check(lib.cgnn_bn_act_bwd_apply_f16(_lib.ptr(dx), _lib.ptr(y), _lib.ptr(mask), _lib.ptr(coef),
-                                                             _lib.ptr(bwc), 1, sv.p, 0, _lib.ptr(cs_slab), _lib.ptr(dy),
+                                                             _lib.ptr(bwc), 1, sv.p, 0, _lib.ptr(cs_slab), _lib.nbytes(cs_slab), _lib.ptr(dy),
                                                              n_nodes, hid, *pool, sp), "cgnn_bn_act_bwd_apply_f16")
                     deferred.add(cs_slab, cs_rows, hid, db)       # all layers' db: one launch at the end
                     dt = None

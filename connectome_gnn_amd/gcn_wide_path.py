@@ -121,7 +121,7 @@ class GcnWideEncode(torch.autograd.Function):
                 if training and slab is None:
                     slab = torch.empty(rows, 2 * hid, dtype=torch.float64, device=dev)
                     srows = rows
-                    _lib.check(lib.cgnn_bn_act_fwd_stats(_lib.ptr(y), n_nodes, hid, _lib.ptr(slab), st()),
+                    _lib.check(lib.cgnn_bn_act_fwd_stats(_lib.ptr(y), n_nodes, hid, _lib.ptr(slab), _lib.nbytes(slab), st()),
                                "cgnn_bn_act_fwd_stats")
                 coef, blk = bn_forward_coef(lib, slab, srows, hid, n_nodes, training, gamma, beta,
                                             bns_mod[li], sv.sync_group, st(), dev)
@@ -175,7 +175,7 @@ class GcnWideEncode(torch.autograd.Function):
                     slab = torch.empty(rows, 2 * hid, dtype=torch.float64, device=dev)
                     _lib.check(lib.cgnn_bn_act_bwd_stats(_lib.ptr(dx), _lib.ptr(y), _lib.ptr(mask),
                                                          _lib.ptr(coef), 1, sv.p, n_nodes, hid,
-                                                         _lib.ptr(slab), *pool, st()), "cgnn_bn_act_bwd_stats")
+                                                         _lib.ptr(slab), _lib.nbytes(slab), *pool, st()), "cgnn_bn_act_bwd_stats")
                     dgamma, dbeta, bwc = bn_backward_coefs(lib, slab, rows, hid, n_nodes, sv.training,
                                                            sv.sync_group, sv.count_block, st(), dev)
                 cs_rows = int(lib.cgnn_bn_act_apply_blocks(n_nodes, hid))
@@ -183,7 +183,7 @@ class GcnWideEncode(torch.autograd.Function):
                 dy = torch.empty_like(y)
                 _lib.check(lib.cgnn_bn_act_bwd_apply(_lib.ptr(dx), _lib.ptr(y), _lib.ptr(mask),
                                                      _lib.ptr(coef), _lib.ptr(bwc), 1, sv.p, 0,
-                                                     _lib.ptr(cs_slab), _lib.ptr(dy), n_nodes, hid,
+                                                     _lib.ptr(cs_slab), _lib.nbytes(cs_slab), _lib.ptr(dy), n_nodes, hid,
                                                      *pool, st()), "cgnn_bn_act_bwd_apply")
                 db = _f32(dev, hid)
                 deferred.add(cs_slab, cs_rows, hid, db)       # all layers' db: one launch at the end

@@ -17,8 +17,15 @@ What makes the step capturable:
 The batch must be resident with its structure (CSR / blocked-ELL) already built: structure
 building reads sizes back to the host and stays outside the graph, like collate.  Autograd graphs
 of EARLIER eager steps on the same parameters must be gone by then (do not keep their ``loss``
-tensors alive): their AccumulateGrad nodes are tied to the stream they ran on, and meeting them
-from the capturing stream ends the capture with a fault inside the HIP runtime.
+tensors alive; ``loss.detach()`` / ``float(loss)`` are fine): a parameter's AccumulateGrad node
+lives as long as any graph that references it and stays tied to the stream it was created on, the
+autograd engine then synchronises the capturing stream with that (default) stream inside the
+capture, and ``capture_end`` takes the process down (segmentation fault in the HIP runtime;
+torch's own warning names the cause: "The AccumulateGrad node's stream does not match ... may
+break CUDA graph capture ... caused by an AccumulateGrad node created prior to the current
+iteration being kept alive", tools/capture_probe.py).  ``_stale_autograd_graph`` looks for
+exactly that condition with a throw-away backward on a side stream BEFORE anything is captured or
+any optimisation step is taken, and the constructor raises a RuntimeError instead.
 
 Data parallel (``grad_sync`` = dist.GradSync): gradients are views of one flat buffer that lives
 outside the graph's pool, so the step is cut at its single exchange point into
@@ -39,6 +46,7 @@ from typing import Callable, Optional
 import torch
 
 from . import ops
+from .structure import call_prepare
 
 
 class GraphedTrainStep:
@@ -71,10 +79,13 @@ class GraphedTrainStep:
         if split and self._has_sync_bn():
             raise ValueError("SyncBatchNorm exchanges statistics inside forward/backward: a captured "
                              "step needs collectives='captured' (or use per-rank BatchNorm)")
-        try:
-            model.prepare_batch(batch, reuse=True)          # host syncs happen here, not in capture
-        except TypeError:                                   # (a model with the reference's signature)
-            model.prepare_batch(batch)
+        call_prepare(model.prepare_batch, batch)            # host syncs happen here, not in capture
+        if self._stale_autograd_graph(dev):
+            raise RuntimeError(
+                "GraphedTrainStep: the autograd graph of an earlier step on these parameters is still alive "
+                "(a kept, non-detached `loss` or output tensor).  Its AccumulateGrad nodes are bound to the stream "
+                "that step ran on, and capturing a backward pass through them crashes the process.  Drop those "
+                "tensors (`del loss`, or keep `loss.detach()` / `float(loss)`) before building a captured step.")
         if getattr(model, "rng_device_state", None) is None:
             model.rng_device_state = torch.randint(0, 2 ** 31 - 1, (16,), dtype=torch.int32, device=dev)
         side = torch.cuda.Stream(device=dev)
@@ -108,6 +119,34 @@ class GraphedTrainStep:
                 self._exchange()
                 self.optimizer.step()
                 self._end_of_step()
+
+    def _stale_autograd_graph(self, dev) -> bool:
+        """True if some parameter's AccumulateGrad node outlived the step that created it (an earlier
+        autograd graph is being kept alive): a zero-valued backward through every parameter on a fresh side
+        stream makes torch's engine report the stream mismatch (input_buffer.cpp) while nothing is being
+        captured.  Gradients are restored to what they were; no parameter changes."""
+        import warnings
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        if not params:
+            return False
+        saved = [p.grad for p in params]
+        for p in params:
+            p.grad = None
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        always = torch.is_warn_always_enabled()
+        torch.set_warn_always(True)                          # (the engine warns once per process otherwise)
+        try:
+            with warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter("always")
+                with torch.cuda.stream(side):
+                    torch.stack([p.reshape(-1)[0] for p in params]).sum().mul(0.0).backward()
+        finally:
+            torch.set_warn_always(always)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            for p, g in zip(params, saved):
+                p.grad = g
+        return any("AccumulateGrad node's stream does not match" in str(w.message) for w in caught)
 
     def _end_of_step(self) -> None:
         """Captured after the optimizer step (subclasses: per-step bookkeeping on the device)."""

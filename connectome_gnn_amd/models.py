@@ -135,6 +135,12 @@ class _ConnectomeModel(nn.Module):
         self.storage = storage
         if storage == "fp16" and not self._relu_after_bn:
             raise ValueError("storage='fp16' is implemented for GCNConnectome only")
+        if storage == "fp16" and in_channels < 2:
+            # measured: with ONE input feature layer 0 is rank one, every channel of its
+            # BatchNorm output is the same signal up to sign, and half-rounded activations put up to 10 % on the
+            # classifier's weight gradient (fp32 storage: 1e-6 on the same inputs)
+            raise ValueError("storage='fp16' needs at least 2 input features (a rank-one layer 0 loses the "
+                             "classifier gradient to half rounding); use storage='fp32'")
         self.impl_used = None
         self.rng_device_state = None  # uint32 device words for graph-captured dropout (graphed.py)
         # parity hook: when True, every training forward leaves the dropout keep decisions it drew

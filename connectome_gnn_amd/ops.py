@@ -150,7 +150,7 @@ def colsum_raw(a: torch.Tensor) -> torch.Tensor:
     slab = _scratch(lib.cgnn_colsum_workspace_bytes(m, n), a.device)
     with _lib.device_guard(a.device):
         _lib.check(lib.cgnn_colsum_f32(_lib.ptr(a), a.stride(0), _lib.ptr(out), m, n,
-                                       _lib.ptr(slab), _lib.stream_ptr()), "cgnn_colsum_f32")
+                                       _lib.ptr(slab), _lib.nbytes(slab), _lib.stream_ptr()), "cgnn_colsum_f32")
     return out
 
 
@@ -189,7 +189,21 @@ def linear_bwd_weight_raw(dy, x, dw, k0: int) -> None:
     with _lib.device_guard(dy.device):
         _lib.check(lib.cgnn_linear_bwd_weight_f32(
             _lib.ptr(dy), dy.stride(0), _lib.ptr(x), x.stride(0), _lib.ptr(dw), dw.stride(0), k0,
-            m, n, k, _lib.ptr(slab), _lib.stream_ptr()), "cgnn_linear_bwd_weight_f32")
+            m, n, k, _lib.ptr(slab), _lib.nbytes(slab), _lib.stream_ptr()), "cgnn_linear_bwd_weight_f32")
+
+
+def linear_bwd_weight2_raw(dy, x1, x2, dw) -> None:
+    """dW [N, K1 + K2] = dY^T [X1 | X2] (cgnn_linear_bwd_weight2_f32: one pass over dY when the joint shape
+    fits the weight-stationary kernel, else panel by panel); panels may differ in width."""
+    lib = _lib.load()
+    m, n = dy.shape
+    k1, k2 = x1.shape[1], x2.shape[1]
+    slab = _scratch(lib.cgnn_linear_bwd_weight2_workspace_bytes(m, n, k1, k2), dy.device)
+    with _lib.device_guard(dy.device):
+        _lib.check(lib.cgnn_linear_bwd_weight2_f32(
+            _lib.ptr(dy), dy.stride(0), _lib.ptr(x1), x1.stride(0), k1, _lib.ptr(x2), x2.stride(0), k2,
+            _lib.ptr(dw), dw.stride(0), m, n, _lib.ptr(slab), _lib.nbytes(slab), _lib.stream_ptr()),
+            "cgnn_linear_bwd_weight2_f32")
 
 
 # ------------------------------------------------------------------------- autograd Functions
@@ -296,7 +310,7 @@ def dense_aggregate_f16_raw(structure, m, x, bias=None, stat_slab=None) -> torch
     with _lib.device_guard(x.device), _lib.timed("cgnn_dense_aggregate_f16", f"F={f}"):
         _lib.check(lib.cgnn_dense_aggregate_f16(
             _lib.ptr(m), m.shape[1], _lib.ptr(structure.gptr), structure.num_graphs, _lib.ptr(x),
-            x.stride(0), f, _lib.ptr(bias), _lib.ptr(y), y.stride(0), _lib.ptr(stat_slab), _lib.stream_ptr()),
+            x.stride(0), f, _lib.ptr(bias), _lib.ptr(y), y.stride(0), _lib.ptr(stat_slab), _lib.nbytes(stat_slab), _lib.stream_ptr()),
             "cgnn_dense_aggregate_f16")
     return y
 
@@ -367,7 +381,7 @@ def dense_aggregate_c16_raw(structure, pack: DensePack, x, bias=None, stat_slab=
             _lib.ptr(pack.dfrag), _lib.ptr(pack.dstep), _lib.ptr(pack.doff), _lib.ptr(pack.sent),
             _lib.ptr(pack.sstep), _lib.ptr(pack.soff), pack.pitch, _lib.ptr(structure.gptr),
             structure.num_graphs, _lib.ptr(x), x.stride(0), f, _lib.ptr(bias), _lib.ptr(y), y.stride(0),
-            _lib.ptr(stat_slab), _lib.stream_ptr()), "cgnn_dense_aggregate_c16")
+            _lib.ptr(stat_slab), _lib.nbytes(stat_slab), _lib.stream_ptr()), "cgnn_dense_aggregate_c16")
     return y
 
 
@@ -384,7 +398,7 @@ def dense_aggregate_c16_bnbwd_raw(structure, pack: DensePack, dx, dP, yl, mask, 
             _lib.ptr(pack.dfrag), _lib.ptr(pack.dstep), _lib.ptr(pack.doff), _lib.ptr(pack.sent),
             _lib.ptr(pack.sstep), _lib.ptr(pack.soff), pack.pitch, _lib.ptr(structure.gptr), structure.num_graphs,
             _lib.ptr(dx), 0 if dx is None else dx.stride(0), _lib.ptr(dP), _lib.ptr(yl), yl.stride(0), _lib.ptr(mask),
-            _lib.ptr(coef), _lib.ptr(bwc), int(relu), float(p), f, _lib.ptr(dt), dt.stride(0), _lib.ptr(cs),
+            _lib.ptr(coef), _lib.ptr(bwc), int(relu), float(p), f, _lib.ptr(dt), dt.stride(0), _lib.ptr(cs), _lib.nbytes(cs),
             _lib.stream_ptr()), "cgnn_dense_aggregate_c16_bnbwd")
     return dt, cs
 
@@ -422,7 +436,7 @@ def linear_fwd_stats_f16_raw(x, w, bias, grid: int):
     slab = torch.empty(grid, 2 * n, dtype=torch.float64, device=x.device)
     with _lib.device_guard(x.device), _lib.timed("cgnn_linear_fwd_stats_f16", f"K={k},N={n}"):
         rc = lib.cgnn_linear_fwd_stats_f16(_lib.ptr(x), x.stride(0), k, _lib.ptr(w), w.stride(0), kw, _lib.ptr(bias),
-                                           _lib.ptr(y), y.stride(0), m, n, _lib.ptr(slab), _lib.stream_ptr())
+                                           _lib.ptr(y), y.stride(0), m, n, _lib.ptr(slab), _lib.nbytes(slab), _lib.stream_ptr())
     if rc == _lib.CGNN_EUNSUPPORTED:
         return None, None
     _lib.check(rc, "cgnn_linear_fwd_stats_f16")
@@ -458,7 +472,7 @@ def linear_bwd_weight_f16_raw(dy, x, kw: Optional[int] = None) -> torch.Tensor:
     dw = torch.empty(n, kw, dtype=torch.float32, device=dy.device)
     with _lib.device_guard(dy.device), _lib.timed("cgnn_linear_bwd_weight_f16", f"K={k},N={n}"):
         _lib.check(lib.cgnn_linear_bwd_weight_f16(_lib.ptr(dy), dy.stride(0), _lib.ptr(x), x.stride(0), _lib.ptr(dw),
-                                                  kw, kw, m, n, k, _lib.ptr(slab), _lib.stream_ptr()),
+                                                  kw, kw, m, n, k, _lib.ptr(slab), _lib.nbytes(slab), _lib.stream_ptr()),
                    "cgnn_linear_bwd_weight_f16")
     return dw
 
@@ -607,7 +621,7 @@ class _BnActDrop(torch.autograd.Function):
             rows = int(lib.cgnn_bn_act_slab_rows(m))
             slab = torch.empty(rows, 2 * n, dtype=torch.float64, device=dev) if training else None
             if training:
-                _lib.check(lib.cgnn_bn_act_fwd_stats(_lib.ptr(y), m, n, _lib.ptr(slab), st()),
+                _lib.check(lib.cgnn_bn_act_fwd_stats(_lib.ptr(y), m, n, _lib.ptr(slab), _lib.nbytes(slab), st()),
                            "cgnn_bn_act_fwd_stats")
             _lib.check(lib.cgnn_bn_act_finalize(
                 _lib.ptr(slab), rows, n, float(max(m, 1)), None, int(training), _lib.ptr(gamma.contiguous()),
@@ -642,14 +656,14 @@ class _BnActDrop(torch.autograd.Function):
             rows = int(lib.cgnn_bn_act_slab_rows(m))
             slab = torch.empty(rows, 2 * n, dtype=torch.float64, device=dev)
             _lib.check(lib.cgnn_bn_act_bwd_stats(_lib.ptr(dx), _lib.ptr(y), _lib.ptr(mask), _lib.ptr(coef),
-                                                 int(relu), p_eff, m, n, _lib.ptr(slab), None, None, None,
+                                                 int(relu), p_eff, m, n, _lib.ptr(slab), _lib.nbytes(slab), None, None, None,
                                                  st()),
                        "cgnn_bn_act_bwd_stats")
             _lib.check(lib.cgnn_bn_act_bwd_finalize(_lib.ptr(slab), rows, n, float(max(m, 1)), None,
                                                     int(not training), _lib.ptr(dgamma), _lib.ptr(dbeta),
                                                     _lib.ptr(bwc), st()), "cgnn_bn_act_bwd_finalize")
             _lib.check(lib.cgnn_bn_act_bwd_apply(_lib.ptr(dx), _lib.ptr(y), _lib.ptr(mask), _lib.ptr(coef),
-                                                 _lib.ptr(bwc), int(relu), p_eff, 0, None, _lib.ptr(dy), m, n,
+                                                 _lib.ptr(bwc), int(relu), p_eff, 0, None, 0, _lib.ptr(dy), m, n,
                                                  None, None, None, st()),
                        "cgnn_bn_act_bwd_apply")
         return dy, dgamma, dbeta, None, None, None, None, None, None
@@ -707,7 +721,7 @@ class _Head(torch.autograd.Function):
             dp = torch.empty_like(p)
             flat = torch.empty(wd, dtype=torch.float32, device=dev)
             _lib.check(lib.cgnn_head_bwd_f32(_lib.ptr(dl), _lib.ptr(p), _lib.ptr(h1), _lib.ptr(fac), bsz, h,
-                                             h2, c, _lib.ptr(w1), _lib.ptr(w2), _lib.ptr(dp), _lib.ptr(slab),
+                                             h2, c, _lib.ptr(w1), _lib.ptr(w2), _lib.ptr(dp), _lib.ptr(slab), _lib.nbytes(slab),
                                              _lib.stream_ptr()), "cgnn_head_bwd_f32")
             _lib.check(lib.cgnn_slab_reduce_f32(_lib.ptr(slab), rows, 1, wd, wd, _lib.ptr(flat), wd,
                                                 _lib.stream_ptr()), "cgnn_slab_reduce_f32")
@@ -747,7 +761,7 @@ class _HeadLoss(torch.autograd.Function):
             _lib.check(lib.cgnn_head_loss_f32(_lib.ptr(p), bsz, h, h2, c, _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2),
                                               _lib.ptr(b2), _lib.ptr(labels.contiguous()), p_eff, seed,
                                               rng_word if p_eff > 0 else None, _lib.ptr(h1), _lib.ptr(fac),
-                                              _lib.ptr(logits), _lib.ptr(dp), _lib.ptr(slab), sp), "cgnn_head_loss_f32")
+                                              _lib.ptr(logits), _lib.ptr(dp), _lib.ptr(slab), _lib.nbytes(slab), sp), "cgnn_head_loss_f32")
             _lib.check(lib.cgnn_slab_reduce_f32(_lib.ptr(slab), rows, 1, wd + 1, wd + 1, _lib.ptr(flat), wd + 1, sp),
                        "cgnn_slab_reduce_f32")
         if record is not None:
@@ -777,7 +791,7 @@ class _HeadLoss(torch.autograd.Function):
                 dp2 = torch.empty_like(p)
                 fl2 = torch.empty(wd, dtype=torch.float32, device=p.device)
                 _lib.check(lib.cgnn_head_bwd_f32(_lib.ptr(dl), _lib.ptr(p), _lib.ptr(h1), _lib.ptr(fac), bsz, h, h2, c,
-                                                 _lib.ptr(w1), _lib.ptr(w2), _lib.ptr(dp2), _lib.ptr(slab),
+                                                 _lib.ptr(w1), _lib.ptr(w2), _lib.ptr(dp2), _lib.ptr(slab), _lib.nbytes(slab),
                                                  _lib.stream_ptr()), "cgnn_head_bwd_f32")
                 _lib.check(lib.cgnn_slab_reduce_f32(_lib.ptr(slab), rows, 1, wd, wd, _lib.ptr(fl2), wd,
                                                     _lib.stream_ptr()), "cgnn_slab_reduce_f32")

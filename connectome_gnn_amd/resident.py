@@ -11,6 +11,7 @@ from __future__ import annotations
 import torch
 
 from .graph import ConnectomeBatch, shard_slice
+from .structure import call_prepare
 from .synthetic import PackedDataset
 
 
@@ -131,10 +132,7 @@ class ResidentDataLoader:
                 for chunk in self._chunks():
                     b = assemble_batch(self.dataset, chunk)
                     if self.prepare is not None:
-                        try:
-                            self.prepare(b, reuse=True)      # kept batches: amortised structure work pays
-                        except TypeError:
-                            self.prepare(b)
+                        call_prepare(self.prepare, b)        # kept batches: amortised structure work pays
                     self._cache.append(b)
             order = torch.randperm(len(self._cache)).tolist() if self.shuffle == "batches" \
                 else range(len(self._cache))

@@ -36,6 +36,10 @@ def eligible(model, batch, structure: BatchStructure) -> Optional[str]:
         return "hidden_dim is not 64, 128, 256, ..."
     if not structure.tiled_ok(hid) and not isinstance(structure, BatchStructure):
         return "graphs do not fit an LDS tile and the structure has no CSR form"
+    if not structure.tiled_ok(hid) and hid not in (64, 128, 256):
+        # off the tiled aggregate the backward adds dX1 inside the gather kernel (ops.aggregate_raw(yadd=...)),
+        # which covers widths 64 / 128 / 256 only: wider layers on large graphs take the layered path
+        return "graphs do not fit an LDS tile and hidden_dim is not 64, 128 or 256"
     if batch.node_features.requires_grad:
         return "node_features require grad"
     if not bn_modules_ok(model):
@@ -162,7 +166,7 @@ def _linear_fwd_stats(lib, x1, x2, w, b, grid, relu: bool = True):
     slab = torch.empty(grid, 2 * n, dtype=torch.float64, device=x1.device)
     rc = lib.cgnn_linear_fwd_stats_f32(
         _lib.ptr(x1), x1.stride(0), k1, _lib.ptr(x2), 0 if x2 is None else x2.stride(0), k2,
-        _lib.ptr(w), _lib.ptr(b), int(relu), _lib.ptr(y), y.stride(0), m, n, _lib.ptr(slab),
+        _lib.ptr(w), _lib.ptr(b), int(relu), _lib.ptr(y), y.stride(0), m, n, _lib.ptr(slab), _lib.nbytes(slab),
         _lib.stream_ptr())
     if rc == _lib.CGNN_EUNSUPPORTED:
         return None, None
@@ -252,7 +256,7 @@ class SageEncode(torch.autograd.Function):
                     if training:
                         slab = torch.empty(rows, 2 * hid, dtype=torch.float64, device=dev)
                         srows = rows
-                        _lib.check(lib.cgnn_bn_act_fwd_stats(_lib.ptr(z), n_nodes, hid, _lib.ptr(slab), st()),
+                        _lib.check(lib.cgnn_bn_act_fwd_stats(_lib.ptr(z), n_nodes, hid, _lib.ptr(slab), _lib.nbytes(slab), st()),
                                    "cgnn_bn_act_fwd_stats")
                 coef, blk = bn_forward_coef(lib, slab, srows, hid, n_nodes, training, gamma, beta,
                                             bns_mod[li], sv.sync_group, st(), dev)
@@ -308,7 +312,7 @@ class SageEncode(torch.autograd.Function):
                     slab = torch.empty(rows, 2 * hid, dtype=torch.float64, device=dev)
                     _lib.check(lib.cgnn_bn_act_bwd_stats(_lib.ptr(dx), _lib.ptr(z), _lib.ptr(mask),
                                                          _lib.ptr(coef), 0, sv.p, n_nodes, hid,
-                                                         _lib.ptr(slab), *pool, st()), "cgnn_bn_act_bwd_stats")
+                                                         _lib.ptr(slab), _lib.nbytes(slab), *pool, st()), "cgnn_bn_act_bwd_stats")
                     dgamma, dbeta, bwc = bn_backward_coefs(lib, slab, rows, hid, n_nodes, sv.training,
                                                            sv.sync_group, sv.count_block, st(), dev)
                 cs_rows = int(lib.cgnn_bn_act_apply_blocks(n_nodes, hid))
@@ -316,7 +320,7 @@ class SageEncode(torch.autograd.Function):
                 dpre = torch.empty_like(z)
                 _lib.check(lib.cgnn_bn_act_bwd_apply(_lib.ptr(dx), _lib.ptr(z), _lib.ptr(mask),
                                                      _lib.ptr(coef), _lib.ptr(bwc), 0, sv.p, 1,
-                                                     _lib.ptr(cs_slab), _lib.ptr(dpre), n_nodes, hid,
+                                                     _lib.ptr(cs_slab), _lib.nbytes(cs_slab), _lib.ptr(dpre), n_nodes, hid,
                                                      *pool, st()), "cgnn_bn_act_bwd_apply")
                 db = _f32(dev, hid)
                 deferred.add(cs_slab, cs_rows, hid, db)       # all layers' db: one launch at the end
@@ -327,12 +331,7 @@ class SageEncode(torch.autograd.Function):
                     grads[0:4] = [dwp[:, :2 * fin].contiguous(), db, dgamma, dbeta]
                     break
                 dw = torch.empty_like(w)
-                ws = torch.empty(max(int(lib.cgnn_linear_bwd_weight_workspace_bytes(n_nodes, hid, 2 * fin)), 16),
-                                 dtype=torch.uint8, device=dev)
-                _lib.check(lib.cgnn_linear_bwd_weight2_f32(
-                    _lib.ptr(dpre), dpre.stride(0), _lib.ptr(x), x.stride(0), fin, _lib.ptr(agg),
-                    agg.stride(0), fin, _lib.ptr(dw), dw.stride(0), n_nodes, hid, _lib.ptr(ws), st()),
-                    "cgnn_linear_bwd_weight2_f32")
+                ops.linear_bwd_weight2_raw(dpre, x, agg, dw)
                 grads[4 * li:4 * li + 4] = [dw, db, dgamma, dbeta]
                 if li == 0:
                     break

@@ -55,6 +55,22 @@ def twin_view(structure, x: torch.Tensor):
     return twin, twin.permuted_features(x), twin
 
 
+def call_prepare(prepare, batch) -> None:
+    """``prepare(batch, reuse=True)`` when the callable takes ``reuse`` (connectome_gnn_amd models'
+    ``prepare_batch``), else ``prepare(batch)`` -- decided from the signature, so a TypeError raised INSIDE
+    the callable is never mistaken for a missing keyword (and the callable never runs twice)."""
+    import inspect
+    try:
+        params = inspect.signature(prepare).parameters
+        takes = "reuse" in params or any(p.kind is inspect.Parameter.VAR_KEYWORD for p in params.values())
+    except (TypeError, ValueError):          # builtins / C callables without a signature
+        takes = False
+    if takes:
+        prepare(batch, reuse=True)
+    else:
+        prepare(batch)
+
+
 def unpermute_record(twin, rec) -> None:
     """Keep bytes recorded per node of the twin -> the batch's node order (parity hook)."""
     if twin is None or rec is None or rec.get("layers") is None:
@@ -155,7 +171,7 @@ class BatchStructure:
                     _lib.ptr(ei), _lib.ptr(node_graph), nn_, ne,
                     _lib.ptr(s.rowptr_dst), _lib.ptr(s.eid_dst), _lib.ptr(s.col_dst),
                     _lib.ptr(s.rowptr_src), _lib.ptr(s.eid_src), _lib.ptr(s.col_src),
-                    _lib.ptr(flags), _lib.ptr(ws), _lib.stream_ptr(dev)), "cgnn_csr_build")
+                    _lib.ptr(flags), _lib.ptr(ws), _lib.nbytes(ws), _lib.stream_ptr(dev)), "cgnn_csr_build")
                 f = flags.tolist()                  # one sync per batch, at build time only
         if f[0]:
             # the reference would raise from scatter_add_/index (models.py:104,112)
@@ -326,7 +342,7 @@ class BatchStructure:
                 blk_off = torch.empty(nb + 1, **i32)
                 scratch = torch.empty(nb // 2048 + 8, **i32)
                 _lib.check(lib.cgnn_bell_plan(_lib.ptr(tptr), _lib.ptr(tile_blk), nt, nb,
-                                              _lib.ptr(rowptr), _lib.ptr(blk_off), _lib.ptr(scratch),
+                                              _lib.ptr(rowptr), _lib.ptr(blk_off), _lib.ptr(scratch), _lib.nbytes(scratch),
                                               _lib.stream_ptr()), "cgnn_bell_plan")
                 # entries <= 16 * (max degree of the ordering + 1) per block: sized from the degree
                 # bound recorded at CSR build, so no read-back (and no stall of the stream) here

@@ -34,7 +34,10 @@ extern "C" {
 #define CGNN_ELAUNCH      (-2)  /* hipGetLastError() != hipSuccess after a launch */
 #define CGNN_EUNSUPPORTED (-3)  /* shape outside what this build of the kernels covers */
 
-#define CGNN_ABI_VERSION 1
+#define CGNN_ABI_VERSION 2   /* 2: every scratch / partial-sum buffer the library WRITES is passed with its
+                              * byte count (`<name>_bytes` right after the pointer); a buffer shorter than what
+                              * the path about to run writes makes the call return CGNN_EINVAL before any launch
+                              * (a NULL optional buffer ignores its count) */
 
 /* Library/ABI version and the gfx target the kernels were compiled for ("gfx950"). */
 int cgnn_abi_version(void);
@@ -64,7 +67,7 @@ int cgnn_csr_build(const int64_t* edge_index, const int64_t* node_graph,
                    int64_t num_nodes, int64_t num_edges,
                    int32_t* rowptr_dst, int32_t* eid_dst, int32_t* col_dst,
                    int32_t* rowptr_src, int32_t* eid_src, int32_t* col_src,
-                   int32_t* flags, void* workspace, void* stream);
+                   int32_t* flags, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Same outputs as cgnn_csr_build for batches whose COO is grouped by graph: the edges of graph g
  * are exactly the run [eptr[g], eptr[g+1]) and both endpoints lie in [gptr[g], gptr[g+1]) -- what
@@ -143,24 +146,26 @@ int cgnn_linear_fwd_stats_f32(const float* X1, int64_t ldx1, int32_t K1,
                               const float* X2, int64_t ldx2, int32_t K2,
                               const float* W, const float* bias, int32_t relu,
                               float* Y, int64_t ldy, int64_t M, int32_t N,
-                              double* stat_slab, void* stream);
+                              double* stat_slab, int64_t stat_slab_bytes, void* stream);
 
 int cgnn_linear_bwd_input_f32(const float* dY, int64_t lddy, const float* W, int32_t ldw,
                               int32_t k0, float* dX, int64_t lddx,
                               int64_t M, int32_t N, int32_t K, void* stream);
 
-/* Bytes of `slab` scratch for bwd_weight. */
+/* Bytes of `slab` scratch for cgnn_linear_bwd_weight_f32(M, N, K) / for cgnn_linear_bwd_weight2_f32 with
+ * panels K1, K2 (the larger of the joint one-pass form and the per-panel forms it may fall back to). */
 int64_t cgnn_linear_bwd_weight_workspace_bytes(int64_t M, int32_t N, int32_t K);
+int64_t cgnn_linear_bwd_weight2_workspace_bytes(int64_t M, int32_t N, int32_t K1, int32_t K2);
 
 int cgnn_linear_bwd_weight_f32(const float* dY, int64_t lddy, const float* X, int64_t ldx,
                                float* dW, int32_t ldw, int32_t k0,
-                               int64_t M, int32_t N, int32_t K, void* slab, void* stream);
+                               int64_t M, int32_t N, int32_t K, void* slab, int64_t slab_bytes, void* stream);
 
 /* Both K-panels of dW = dY^T [X1 | X2] in one pass over dY (SAGELayer's Linear(2*in, out)).
- * slab: cgnn_linear_bwd_weight_workspace_bytes(M, N, K1 + K2) bytes. */
+ * slab: cgnn_linear_bwd_weight2_workspace_bytes(M, N, K1, K2) bytes. */
 int cgnn_linear_bwd_weight2_f32(const float* dY, int64_t lddy, const float* X1, int64_t ldx1,
                                 int32_t K1, const float* X2, int64_t ldx2, int32_t K2, float* dW,
-                                int32_t ldw, int64_t M, int32_t N, void* slab, void* stream);
+                                int32_t ldw, int64_t M, int32_t N, void* slab, int64_t slab_bytes, void* stream);
 
 /* fp16-STORAGE forms of the projection for large dense parcellations (BASELINE config 5; the
  * reference, models.py:111 and its autograd backward, has no fp16 path -- results are the fp32
@@ -185,11 +190,11 @@ int cgnn_linear_bwd_input_f16(const void* dY, int64_t lddy, const float* W, int3
  * half-rounded output columns, N = 128 or 256; combined by cgnn_bn_act_finalize with rows =
  * cgnn_fused_grid()): the projection in front of a BatchNorm (models.py:111,208) needs no statistics pass. */
 int cgnn_linear_fwd_stats_f16(const void* X, int64_t ldx, int32_t K, const float* W, int32_t ldw, int32_t Kw,
-                              const float* bias, void* Y, int64_t ldy, int64_t M, int32_t N, double* stat_slab,
+                              const float* bias, void* Y, int64_t ldy, int64_t M, int32_t N, double* stat_slab, int64_t stat_slab_bytes,
                               void* stream);
 int64_t cgnn_linear_bwd_weight_f16_workspace_bytes(int64_t M, int32_t N, int32_t K);
 int cgnn_linear_bwd_weight_f16(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW,
-                               int32_t ldw, int32_t Kw, int64_t M, int32_t N, int32_t K, void* slab,
+                               int32_t ldw, int32_t Kw, int64_t M, int32_t N, int32_t K, void* slab, int64_t slab_bytes,
                                void* stream);
 /* Y[M, Fp] (half) = [X[M, F] (fp32) | zeros]: the input features of a batch as a half panel. */
 int cgnn_pad_cast_f16(const float* X, int64_t ldx, int32_t F, void* Y, int32_t Fp, int64_t M, void* stream);
@@ -198,7 +203,7 @@ int cgnn_pad_cast_f16(const float* X, int64_t ldx, int32_t F, void* Y, int32_t F
  * slab: cgnn_colsum_workspace_bytes(M, N) bytes. */
 int64_t cgnn_colsum_workspace_bytes(int64_t M, int32_t N);
 int cgnn_colsum_f32(const float* A, int64_t lda, float* out, int64_t M, int32_t N,
-                    void* slab, void* stream);
+                    void* slab, int64_t slab_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Per-graph mean-pool readout, models.py:40-47,57-59: P[g,:] = sum_{n in g} X[n,:] / (n_g+1e-8)
@@ -254,7 +259,7 @@ int cgnn_pool_mean_bwd_f32(const float* dP, const int32_t* gptr, float* dX, int6
  * ceil(rows/16), NB = num_blocks = tile_blk[T]), rowptr int32 [Nn+1] of the ordering.
  * blk_off int32 [NB+1] out (in entries); scratch: int32 [NB/2048 + 8]. */
 int cgnn_bell_plan(const int32_t* tile_ptr, const int32_t* tile_blk, int32_t num_tiles,
-                   int32_t num_blocks, const int32_t* rowptr, int32_t* blk_off, int32_t* scratch,
+                   int32_t num_blocks, const int32_t* rowptr, int32_t* blk_off, int32_t* scratch, int64_t scratch_bytes,
                    void* stream);
 /* Pass 2: fill entries (8 bytes each, blk_off[NB] of them).  self_weight: weight of the appended
  * self-loop entry -- 1 for GCN (models.py:97-100), 0 for GraphSAGE (no self-loop, models.py:146). */
@@ -373,7 +378,7 @@ int cgnn_dense_adj_f16(const int32_t* rowptr, const int32_t* col, const float* c
                        void* M, void* stream);
 int cgnn_dense_aggregate_f16(const void* M, int32_t P, const int32_t* gptr, int32_t num_graphs,
                              const void* X, int64_t ldx, int32_t F, const float* bias, void* Y,
-                             int64_t ldy, double* stat_slab, void* stream);
+                             int64_t ldy, double* stat_slab, int64_t stat_slab_bytes, void* stream);
 
 /* stat_slab (both aggregates; NULL = none): [cgnn_fused_grid()][2 * F] fp64 per-workgroup column sums
  * and sums of squares of the half-rounded result (BatchNorm statistics in the epilogue; finalise with
@@ -402,7 +407,7 @@ int cgnn_dense_aggregate_c16(const void* dfrag, const int32_t* dstep, const uint
                              const uint32_t* sent, const int32_t* sstep, const uint32_t* soff,
                              int32_t P, const int32_t* gptr, int32_t num_graphs, const void* X,
                              int64_t ldx, int32_t F, const float* bias, void* Y, int64_t ldy,
-                             double* stat_slab, void* stream);
+                             double* stat_slab, int64_t stat_slab_bytes, void* stream);
 /* The backward product dT = A_hat^T dY of a GCN layer with dY never materialised: the slice handed to
  * the matrix cores is formed while it is staged,
  *     dY = a * (dX' * f - c1 - xhat * c2),   f = relu' * keep / (1-p),   xhat = (Yl - mean) * invstd
@@ -417,7 +422,7 @@ int cgnn_dense_aggregate_c16_bnbwd(const void* dfrag, const int32_t* dstep, cons
                                    int32_t P, const int32_t* gptr, int32_t num_graphs, const void* dX,
                                    int64_t lddx, const float* dP, const void* Yl, int64_t ldyl,
                                    const uint8_t* mask, const float* coef, const float* bwc, int32_t relu,
-                                   float p_drop, int32_t F, void* dT, int64_t lddt, double* cs_slab,
+                                   float p_drop, int32_t F, void* dT, int64_t lddt, double* cs_slab, int64_t cs_slab_bytes,
                                    void* stream);
 
 /* The DENSE FRAGMENTS of an aggregation operator applied in fp32 on the bf16 matrix pipe with exactly
@@ -447,7 +452,7 @@ int cgnn_band_aggregate_f32(const void* bfrag, const int32_t* bstep, const int32
 /* Layer 0 forward.  X0 [Nn,F0] (F0 <= 16), W0 [64,F0], bias [64] -> Y [Nn,64];
  * stat_slab [grid][128] fp64 (sum(y) | sum(y^2)) or NULL (eval). */
 int cgnn_gcn_fused_fwd_first(const cgnn_tiles* t, const float* X0, int32_t F0, const float* W0,
-                             const float* bias, float* Y, double* stat_slab, void* stream);
+                             const float* bias, float* Y, double* stat_slab, int64_t stat_slab_bytes, void* stream);
 
 /* Layer l>0 forward.  Yprev [Nn,64] + bn_prev -> X on the fly; W [64,64]; mask_out nullable.
  * Yprev == NULL: the previous layer is layer 0 in factored form, rows rebuilt from *l0. */
@@ -458,7 +463,7 @@ int cgnn_rng_advance(uint32_t* state, int32_t n, void* stream);
 int cgnn_gcn_fused_fwd(const cgnn_tiles* t, const float* Yprev, const cgnn_l0src* l0,
                        const float* bn_prev, float p_drop, uint64_t seed, const uint32_t* seed_dev,
                        uint8_t* mask_out, const float* W, const float* bias, float* Y,
-                       double* stat_slab, void* stream);
+                       double* stat_slab, int64_t stat_slab_bytes, void* stream);
 
 /* slab [rows][width] fp64 -> sums [width] fp64 (fixed-order tree). */
 int cgnn_bn_reduce(const double* slab, int32_t rows, int32_t width, double* sums, void* stream);
@@ -484,7 +489,7 @@ int cgnn_gcn_fused_pool_fwd(const float* Y, const float* bn, float p_drop, uint6
  * dP[g]/(n_g+1e-8) for every row of graph g, so  sum dZ = sum_g dP[g]/n_g * F1[g]  and
  * sum dZ*xhat = sum_g dP[g]/n_g * F2[g].  s_slab [cgnn_fused_grid()][128] fp64 partials. */
 int cgnn_gcn_fused_pool_bwd_sums(const float* dP, const float* F1, const float* F2,
-                                 const int32_t* gptr, int32_t num_graphs, double* s_slab,
+                                 const int32_t* gptr, int32_t num_graphs, double* s_slab, int64_t s_slab_bytes,
                                  void* stream);
 /* (cgnn_gcn_fused_pool_bwd_sums + cgnn_bn_bwd_stats_finalize) in one launch: dgamma/dbeta [64] and
  * the c1|c2 block bwc [128] of the last layer, for per-rank BatchNorm statistics (no exchange
@@ -499,7 +504,7 @@ int cgnn_gcn_fused_pool_bwd_finalize(const float* dP, const float* F1, const flo
  * dZ may be NULL (sums only) when the last layer's backward rebuilds dZ itself (dP != NULL there). */
 int cgnn_gcn_fused_pool_bwd(const float* dP, const float* Y, const float* bn, float p_drop,
                             const uint8_t* mask, const int32_t* gptr, int32_t num_graphs,
-                            float* dZ, double* s_slab, void* stream);
+                            float* dZ, double* s_slab, int64_t s_slab_bytes, void* stream);
 
 /* BatchNorm backward coefficients: dgamma = sum dZ*xhat, dbeta = sum dZ, bwc = [c1|c2]. */
 int cgnn_bn_bwd_finalize(const double* sums, double count, const double* count_dev,
@@ -515,14 +520,14 @@ int cgnn_bn_bwd_finalize(const double* sums, double count, const double* count_d
 int cgnn_gcn_fused_bwd(const cgnn_tiles* t, const float* dZ, const float* Y, const float* bn,
                        const float* bwc, const float* Yprev, const cgnn_l0src* l0,
                        const float* bn_prev, float p_drop, const uint8_t* mask_prev, const float* W,
-                       float* dZprev, double* s_slab_prev, float* dW_slab, double* db_slab,
+                       float* dZprev, double* s_slab_prev, int64_t s_slab_prev_bytes, float* dW_slab, int64_t dW_slab_bytes, double* db_slab, int64_t db_slab_bytes,
                        const float* dP, const int32_t* node_graph, const int32_t* gptr,
                        const uint8_t* mask_cur, void* stream);
 
 /* Layer 0 backward: dW0 = dT^T X0 only.  dW_slab [grid][64*16] (columns >= F0 are zero). */
 int cgnn_gcn_fused_bwd_first(const cgnn_tiles* t, const float* dZ, const float* Y,
                              const float* bn, const float* bwc, const float* X0, int32_t F0,
-                             float* dW_slab, double* db_slab, float p_drop, const float* dP,
+                             float* dW_slab, int64_t dW_slab_bytes, double* db_slab, int64_t db_slab_bytes, float p_drop, const float* dP,
                              const int32_t* node_graph, const int32_t* gptr,
                              const uint8_t* mask_cur, void* stream);
 
@@ -555,18 +560,18 @@ int cgnn_l0_grid(int64_t num_nodes);
  * dW0[:, k] = dW'[:, k] + c[k] (dW'[:, F0] + rbar db0) in the first F0 of the 8 slab columns. */
 int cgnn_gcn_l0_center(const cgnn_tiles* t, const float* X0, int32_t F0, float* center, void* stream);
 int cgnn_gcn_l0_fwd(const cgnn_tiles* t, const float* X0, int32_t F0, const float* W0,
-                    const float* bias, float* P0, float* Y, double* stat_slab, const float* center,
+                    const float* bias, float* P0, float* Y, double* stat_slab, int64_t stat_slab_bytes, const float* center,
                     float* w_eff, float* mean_offset, void* stream);
 int cgnn_gcn_l0_bwd(const float* dZ, const float* Y, const cgnn_l0src* l0, const float* bn,
-                    const float* bwc, const float* P0, int64_t num_nodes, float* dW_slab,
-                    double* db_slab, const float* center, void* stream);
+                    const float* bwc, const float* P0, int64_t num_nodes, float* dW_slab, int64_t dW_slab_bytes,
+                    double* db_slab, int64_t db_slab_bytes, const float* center, void* stream);
 
 /* fp16-storage forms of the BatchNorm(+ReLU)+dropout kernels (cgnn_bn_act_*): the [M,N] activation
  * arrays (Y, X, dX, dY) are IEEE half, the arithmetic is fp32, the statistics fp64, coefficient
  * blocks / masks / slabs / pooled rows exactly as in the fp32 forms.  Used by the fp16-storage
  * GCN encoder for large dense parcellations (BASELINE config 5); the reference has no fp16 path
  * (models.py is fp32-only), results are the fp32 oracle's to fp16 resolution. */
-int cgnn_bn_act_fwd_stats_f16(const void* Y, int64_t M, int32_t N, double* slab, void* stream);
+int cgnn_bn_act_fwd_stats_f16(const void* Y, int64_t M, int32_t N, double* slab, int64_t slab_bytes, void* stream);
 int cgnn_bn_act_fwd_apply_f16(const void* Y, const float* coef, int32_t relu, float p_drop, uint64_t seed,
                               const uint32_t* seed_dev, uint8_t* mask_out, void* X, int64_t M,
                               int32_t N, void* stream);
@@ -574,12 +579,12 @@ int cgnn_bn_act_pool_fwd_f16(const void* Y, const float* coef, int32_t relu, flo
                              const uint32_t* seed_dev, uint8_t* mask_out, const int32_t* gptr,
                              int32_t num_graphs, float* P, int32_t N, float* Fsum, void* stream);
 int cgnn_bn_act_bwd_stats_f16(const void* dX, const void* Y, const uint8_t* mask, const float* coef,
-                              int32_t relu, float p_drop, int64_t M, int32_t N, double* slab,
+                              int32_t relu, float p_drop, int64_t M, int32_t N, double* slab, int64_t slab_bytes,
                               const float* dP, const int32_t* node_graph, const int32_t* gptr,
                               void* stream);
 int cgnn_bn_act_bwd_apply_f16(const void* dX, const void* Y, const uint8_t* mask, const float* coef,
                               const float* bwc, int32_t relu, float p_drop, int32_t relu_in,
-                              double* colsum_slab, void* dY, int64_t M, int32_t N, const float* dP,
+                              double* colsum_slab, int64_t colsum_slab_bytes, void* dY, int64_t M, int32_t N, const float* dP,
                               const int32_t* node_graph, const int32_t* gptr, void* stream);
 
 /* ---- optimizer: torch.optim.Adam's update (L2 weight decay, no amsgrad) for up to
@@ -666,7 +671,7 @@ int cgnn_slab_reduce_f64_multi(const cgnn_reduce_jobs* jobs, void* stream);
  * ------------------------------------------------------------------------------------- */
 int cgnn_bn_act_width_ok(int32_t N);
 int64_t cgnn_bn_act_slab_rows(int64_t M);
-int cgnn_bn_act_fwd_stats(const float* Y, int64_t M, int32_t N, double* slab, void* stream);
+int cgnn_bn_act_fwd_stats(const float* Y, int64_t M, int32_t N, double* slab, int64_t slab_bytes, void* stream);
 /* count_dev (nullable): the row count read from device memory instead of `count` -- under
  * full-batch BatchNorm across ranks the caller all-reduces [sum | sumsq | rows] and passes the
  * reduced block as a 1-row slab with count_dev = &block[2N]; nothing returns to the host. */
@@ -693,7 +698,7 @@ int cgnn_bn_act_pool_bwd_finalize(const float* dP, const float* Fsum, const int3
                                   int32_t N, double count, int32_t zero_coef, float* dgamma, float* dbeta,
                                   float* bwc, void* stream);
 int cgnn_bn_act_bwd_stats(const float* dX, const float* Y, const uint8_t* mask, const float* coef,
-                          int32_t relu, float p_drop, int64_t M, int32_t N, double* slab,
+                          int32_t relu, float p_drop, int64_t M, int32_t N, double* slab, int64_t slab_bytes,
                           const float* dP, const int32_t* node_graph, const int32_t* gptr,
                           void* stream);
 int cgnn_bn_act_bwd_finalize(const double* slab, int32_t rows, int32_t N, double count,
@@ -706,7 +711,7 @@ int cgnn_bn_act_bwd_finalize(const double* slab, int32_t rows, int32_t N, double
 int64_t cgnn_bn_act_apply_blocks(int64_t M, int32_t N);
 int cgnn_bn_act_bwd_apply(const float* dX, const float* Y, const uint8_t* mask, const float* coef,
                           const float* bwc, int32_t relu, float p_drop, int32_t relu_in,
-                          double* colsum_slab, float* dY, int64_t M, int32_t N, const float* dP,
+                          double* colsum_slab, int64_t colsum_slab_bytes, float* dY, int64_t M, int32_t N, const float* dP,
                           const int32_t* node_graph, const int32_t* gptr, void* stream);
 
 /* ---------------------------------------------------------------------------------------
@@ -727,7 +732,7 @@ int cgnn_head_fwd_f32(const float* P, int32_t B, int32_t H, int32_t H2, int32_t 
                       void* stream);
 int cgnn_head_bwd_f32(const float* dlogits, const float* P, const float* H1, const float* fac,
                       int32_t B, int32_t H, int32_t H2, int32_t C, const float* W1, const float* W2,
-                      float* dP, float* slab, void* stream);
+                      float* dP, float* slab, int64_t slab_bytes, void* stream);
 
 /* Mean cross-entropy of the step (torch.nn.CrossEntropyLoss defaults; reference train.py:39,49):
  * loss[0] = mean_i(logsumexp(logits[i,:]) - logits[i, labels[i]]); dlogits [B,C] = its gradient
@@ -750,7 +755,7 @@ int cgnn_head_loss_grid(int32_t B, int32_t H, int32_t H2, int32_t C);   /* rows 
 int cgnn_head_loss_f32(const float* P, int32_t B, int32_t H, int32_t H2, int32_t C, const float* W1,
                        const float* b1, const float* W2, const float* b2, const int64_t* labels,
                        float p_drop, uint64_t seed, const uint32_t* seed_dev, float* H1, float* fac,
-                       float* logits, float* dP, float* slab, void* stream);
+                       float* logits, float* dP, float* slab, int64_t slab_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,7 @@
 """GPU parity of the individual HIP kernels (through the C ABI) against the oracle / plain
 fp32 torch CPU references.  Integer structure is bit-exact; floating point within 1e-5
 (rtol) + 1e-6 (atol) -- BASELINE.json north_star: "within 1e-5 fp32"."""
+import ctypes
 import math
 
 import numpy as np
@@ -904,7 +905,7 @@ def test_pooled_bn_pass_factor_sums_give_the_backward_statistics(sizes, n, relu,
     rows = int(lib.cgnn_bn_act_slab_rows(m))
     slab = torch.empty(rows, 2 * n, dtype=torch.float64, device=DEV)
     _lib.check(getattr(lib, "cgnn_bn_act_bwd_stats" + sfx)(None, _lib.ptr(y), _lib.ptr(mask), _lib.ptr(coef), int(relu), p,
-                                                          m, n, _lib.ptr(slab), _lib.ptr(dP), _lib.ptr(node_graph),
+                                                          m, n, _lib.ptr(slab), _lib.nbytes(slab), _lib.ptr(dP), _lib.ptr(node_graph),
                                                           _lib.ptr(gptr), sp), "bwd_stats")
     want = [torch.empty(n, device=DEV), torch.empty(n, device=DEV), torch.empty(2 * n, device=DEV)]
     _lib.check(lib.cgnn_bn_act_bwd_finalize(_lib.ptr(slab), rows, n, float(m), None, 0, *(_lib.ptr(t) for t in want), sp),
@@ -981,10 +982,108 @@ def test_dense_aggregate_with_bn_backward_prologue_equals_two_passes(sizes, deg,
     dy = torch.empty_like(y)
     pool = (_lib.ptr(dP), _lib.ptr(s.node_graph), _lib.ptr(s.gptr)) if pooled else (None, None, None)
     _lib.check(lib.cgnn_bn_act_bwd_apply_f16(_lib.ptr(dx), _lib.ptr(y), _lib.ptr(mask), _lib.ptr(coef), _lib.ptr(bwc), 1, p, 0,
-                                             _lib.ptr(cs), _lib.ptr(dy), nn_, f, *pool, sp), "bwd_apply")
+                                             _lib.ptr(cs), _lib.nbytes(cs), _lib.ptr(dy), nn_, f, *pool, sp), "bwd_apply")
     want = ops.dense_aggregate_c16_raw(s, pk, dy)
     got, cs2 = ops.dense_aggregate_c16_bnbwd_raw(s, pk, dx, dP, y, mask, coef, bwc, True, p)
     assert cs2.shape == (len(sizes), f)
     assert torch.equal(got, want)
     db_want, db_got = cs.sum(0), cs2.sum(0)
     torch.testing.assert_close(db_got, db_want, rtol=1e-6, atol=1e-6 * float(dy.float().abs().sum(0).max()) + 1e-9)
+
+
+# ------------------------------------------------------------------ ABI 2: scratch buffers carry their size
+def test_short_scratch_buffers_are_refused_before_any_launch():
+    """Every scratch / partial-sum buffer the library writes is passed with its byte count (ABI 2).  The
+    round-3 fault -- GraphSAGE hidden 256 on >= 4096 nodes wrote 33 MB of weight-gradient partials into a
+    1 MB slab -- is now CGNN_EINVAL (-1): a 1-byte slab at that shape, and at shapes of the other slab
+    writers, is refused and nothing is launched (the outputs keep their sentinel)."""
+    from connectome_gnn_amd import _lib
+    lib = _lib.load()
+    sp = _lib.stream_ptr()
+    m, hid = 5760, 256                                        # 16 x 360-ROI graphs, GraphSAGE hidden 256
+    dy = torch.randn(m, hid, device=DEV)
+    x1, x2 = torch.randn(m, hid, device=DEV), torch.randn(m, hid, device=DEV)
+    dw = torch.full((hid, 2 * hid), 7.0, device=DEV)
+    tiny = torch.zeros(1, dtype=torch.uint8, device=DEV)
+    need = int(lib.cgnn_linear_bwd_weight2_workspace_bytes(m, hid, hid, hid))
+    assert need > 8 << 20                                      # the per-panel weight-stationary form: 256 partials
+    rc = lib.cgnn_linear_bwd_weight2_f32(_lib.ptr(dy), hid, _lib.ptr(x1), hid, hid, _lib.ptr(x2), hid, hid,
+                                         _lib.ptr(dw), 2 * hid, m, hid, _lib.ptr(tiny), 1, sp)
+    assert rc == _lib.CGNN_EINVAL
+    rc = lib.cgnn_linear_bwd_weight_f32(_lib.ptr(dy), hid, _lib.ptr(x1), hid, _lib.ptr(dw), 2 * hid, 0, m, hid, hid,
+                                        _lib.ptr(tiny), 1, sp)
+    assert rc == _lib.CGNN_EINVAL
+    # one byte short of the documented size is refused too, the documented size is accepted
+    ws = torch.empty(need, dtype=torch.uint8, device=DEV)
+    assert lib.cgnn_linear_bwd_weight2_f32(_lib.ptr(dy), hid, _lib.ptr(x1), hid, hid, _lib.ptr(x2), hid, hid,
+                                           _lib.ptr(dw), 2 * hid, m, hid, _lib.ptr(ws), need - 257, sp) == _lib.CGNN_EINVAL
+    torch.cuda.synchronize()
+    assert bool((dw == 7.0).all())                             # nothing ran
+    assert lib.cgnn_linear_bwd_weight2_f32(_lib.ptr(dy), hid, _lib.ptr(x1), hid, hid, _lib.ptr(x2), hid, hid,
+                                           _lib.ptr(dw), 2 * hid, m, hid, _lib.ptr(ws), need, sp) == _lib.CGNN_OK
+    want = dy.double().t() @ torch.cat([x1, x2], 1).double()
+    torch.testing.assert_close(dw.double(), want, rtol=1e-5, atol=1e-5 * float(want.abs().max()))
+    # the other families of slab writers
+    out = torch.full((hid,), 7.0, device=DEV)
+    assert lib.cgnn_colsum_f32(_lib.ptr(dy), hid, _lib.ptr(out), m, hid, _lib.ptr(tiny), 1, sp) == _lib.CGNN_EINVAL
+    assert lib.cgnn_bn_act_fwd_stats(_lib.ptr(dy), m, hid, _lib.ptr(tiny), 1, sp) == _lib.CGNN_EINVAL
+    assert lib.cgnn_bn_act_bwd_apply(_lib.ptr(dy), _lib.ptr(x1), None, _lib.ptr(x2), _lib.ptr(x2), 1, 0.0, 0,
+                                     _lib.ptr(tiny), 1, _lib.ptr(dw), m, hid, None, None, None, sp) == _lib.CGNN_EINVAL
+    dyh = dy.half()
+    assert lib.cgnn_linear_bwd_weight_f16(_lib.ptr(dyh), hid, _lib.ptr(dyh), hid, _lib.ptr(dw), 2 * hid, hid, m, hid,
+                                          hid, _lib.ptr(tiny), 1, sp) == _lib.CGNN_EINVAL
+    assert lib.cgnn_linear_fwd_stats_f16(_lib.ptr(dyh), hid, hid, _lib.ptr(x1), hid, hid, None, _lib.ptr(dyh), hid, m,
+                                         hid, _lib.ptr(tiny), 1, sp) in (_lib.CGNN_EINVAL, _lib.CGNN_EUNSUPPORTED)
+    h2, c, bsz = 32, 2, 512
+    z = torch.zeros(bsz * 64, device=DEV)
+    assert lib.cgnn_head_bwd_f32(_lib.ptr(z), _lib.ptr(z), _lib.ptr(z), _lib.ptr(z), bsz, 64, h2, c, _lib.ptr(z),
+                                 _lib.ptr(z), _lib.ptr(z), _lib.ptr(tiny), 1, sp) == _lib.CGNN_EINVAL
+    b = _batch(*_rand_graph_batch([84] * 6, 8, 3), 5).to(DEV)
+    s = b.structure()
+    grid = int(lib.cgnn_fused_grid())
+    meta = s.fused_meta(384, grid, 1.0)
+    tp = ctypes.byref(s.tiles_struct(meta, s.gcn_dis(meta)))
+    y = torch.full((b.num_nodes, 64), 7.0, device=DEV)
+    w0, b0 = torch.randn(64, 5, device=DEV), torch.zeros(64, device=DEV)
+    assert lib.cgnn_gcn_fused_fwd_first(tp, _lib.ptr(b.node_features), 5, _lib.ptr(w0), _lib.ptr(b0), _lib.ptr(y),
+                                        _lib.ptr(tiny), 1, sp) == _lib.CGNN_EINVAL
+    torch.cuda.synchronize()
+    assert bool((y == 7.0).all()) and bool((out == 7.0).all())
+
+
+@pytest.mark.parametrize("m,n,k1,k2", [(5000, 128, 64, 256), (4500, 128, 256, 64), (4100, 64, 32, 128), (300, 128, 64, 256),
+                                       (5000, 256, 64, 128)])
+def test_two_panel_weight_gradient_with_unequal_panels(m, n, k1, k2):
+    """cgnn_linear_bwd_weight2_f32 with K1 != K2: outside the joint weight-stationary form each panel may take its
+    own (one [N x Ki] partial per workgroup); the slab is sized by cgnn_linear_bwd_weight2_workspace_bytes from
+    the actual panels (sizing from K1 + K2 under-counted 64 + 256 at N = 128, M >= 4096)."""
+    from connectome_gnn_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(m + n + k1)
+    dy, x1, x2 = torch.randn(m, n, generator=g), torch.randn(m, k1, generator=g), torch.randn(m, k2, generator=g)
+    need = int(lib.cgnn_linear_bwd_weight2_workspace_bytes(m, n, k1, k2))
+    for k in (k1, k2):
+        assert need >= int(lib.cgnn_linear_bwd_weight_workspace_bytes(m, n, k))
+    dw = torch.empty(n, k1 + k2, device=DEV)
+    ops.linear_bwd_weight2_raw(dy.to(DEV), x1.to(DEV), x2.to(DEV), dw)
+    want = dy.double().t() @ torch.cat([x1, x2], 1).double()
+    torch.testing.assert_close(dw.cpu().double(), want, rtol=1e-5, atol=1e-5 * float(want.abs().max()) + 1e-6)
+
+
+def test_pool_mean_more_graphs_than_a_grid_dimension():
+    """Mean-pool readout (models.py:40-47,57-59) over more than 65535 graphs (whole-dataset evaluation of small
+    graphs): the graphs ride on gridDim.y in runs of 65535."""
+    from connectome_gnn_amd import ops
+    B, f = 70_001, 8
+    sizes = torch.randint(1, 4, (B,), generator=torch.Generator().manual_seed(2))
+    ptr = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(sizes, 0)])
+    nn_ = int(ptr[-1])
+    x = torch.randn(nn_, f, generator=torch.Generator().manual_seed(3))
+    xd = x.to(DEV).requires_grad_(True)
+    p = ops.pool_mean(xd, ptr.to(device=DEV, dtype=torch.int32), B)
+    seg = torch.repeat_interleave(torch.arange(B), sizes)
+    want = torch.zeros(B, f).index_add_(0, seg, x) / (sizes.float() + 1e-8)[:, None]
+    torch.testing.assert_close(p.cpu(), want, **TOL)
+    cot = torch.randn(B, f, generator=torch.Generator().manual_seed(4))
+    (p * cot.to(DEV)).sum().backward()
+    torch.testing.assert_close(xd.grad.cpu(), (cot / (sizes.float() + 1e-8)[:, None])[seg], **TOL)

@@ -1192,3 +1192,22 @@ def test_degree_ordered_twin_is_the_same_model_on_ragged_batches():
             continue
         g1 = outs[1][1][k]
         assert float((g1 - g0).abs().max()) <= 2e-5 * float(g0.abs().max()) + 2e-6, k
+
+
+@pytest.mark.parametrize("mode", ["keep", "drop"])
+def test_capture_with_a_live_earlier_autograd_graph_raises_instead_of_crashing(mode):
+    """building a captured step while a non-detached `loss` of an earlier eager step is alive used to
+    end in a segmentation fault inside capture_end (stale AccumulateGrad nodes bound to the default stream).
+    GraphedTrainStep now detects the condition before capturing and raises; once the tensors are dropped the
+    same call captures and replays.  Run in a child process (tools/capture_probe.py): undetected, the condition
+    kills the interpreter."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "capture_probe.py"), mode], cwd=root,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    assert "captured + replayed ok" in r.stdout
+    if mode == "keep":
+        assert "detected:" in r.stdout

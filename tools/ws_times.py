@@ -21,12 +21,12 @@ if os.environ.get("ZERO"):      # all-zero operands: the clock the chip holds wi
     for t in (x1, x2, w, b, dy):
         t.zero_()
 grid = int(lib.cgnn_fused_grid())
-ws = torch.empty(max(int(lib.cgnn_linear_bwd_weight_workspace_bytes(m, h, 2 * h)), 16), dtype=torch.uint8, device="cuda")
+ws = torch.empty(max(int(lib.cgnn_linear_bwd_weight2_workspace_bytes(m, h, h, h)), 16), dtype=torch.uint8, device="cuda")
 
 
 def bwd_w():
     _lib.check(lib.cgnn_linear_bwd_weight2_f32(_lib.ptr(dy), h, _lib.ptr(x1), h, h, _lib.ptr(x2), h, h, _lib.ptr(dw),
-                                               2 * h, m, h, _lib.ptr(ws), _lib.stream_ptr()), "bw")
+                                               2 * h, m, h, _lib.ptr(ws), _lib.nbytes(ws), _lib.stream_ptr()), "bw")
 
 
 fns = {"fwd+stats K=256 N=128": lambda: sage_path._linear_fwd_stats(lib, x1, x2, w, b, grid),
