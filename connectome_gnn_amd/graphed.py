@@ -57,13 +57,17 @@ class GraphedTrainStep:
     def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer, batch,
                  loss_fn: Optional[Callable] = None, grad_sync: Optional[Callable[[], None]] = None,
                  warmup: int = 3, collectives: str = "split", local_graphs: Optional[int] = None,
-                 make_batch: Optional[Callable[[], object]] = None):
+                 make_batch: Optional[Callable[[], object]] = None, tolerate_capture_failure: bool = False):
         """local_graphs: with dist.GradSync and shards that may be unequal, this rank's graph count
         (the update is then the exact global-batch gradient, see dist.GradSync).
 
         make_batch: assemble the batch INSIDE the captured step from fixed-address inputs (``batch``
         is then only the first batch, used for the device and the warm-up): every replay re-runs the
-        assembly, so one graph serves any batch of that shape -- see GraphedResidentStep."""
+        assembly, so one graph serves any batch of that shape -- see GraphedResidentStep.
+
+        tolerate_capture_failure: an exception during capture (after the warm-up steps, which are real
+        optimisation steps) is kept in ``capture_error`` and ``graph`` is left None instead of raising, so a
+        caller that asked for "a graph where capture succeeds" can carry on eagerly from ``first_loss``."""
         if collectives not in ("split", "captured"):
             raise ValueError("collectives must be 'split' or 'captured'")
         dev = batch.node_features.device
@@ -106,6 +110,20 @@ class GraphedTrainStep:
         # thread's calls are part of the capture
         import torch.distributed as dist
         mode = {"capture_error_mode": "thread_local"} if dist.is_available() and dist.is_initialized() else {}
+        self.capture_error = None
+        try:
+            self._capture(split, mode)
+        except Exception as exc:                            # noqa: BLE001
+            if not tolerate_capture_failure:
+                raise
+            self.capture_error, self.graph, self.graph_tail = exc, None, None
+            torch.cuda.synchronize(dev)
+            for prm in model.parameters():                  # a half-captured step may have left pool-owned grads
+                prm.grad = None
+            if hasattr(grad_sync, "zero_grad"):
+                grad_sync.zero_grad()
+
+    def _capture(self, split: bool, mode: dict) -> None:
         if split:
             with torch.cuda.graph(self.graph, **mode):
                 self.loss = self._fwd_bwd()
@@ -178,6 +196,8 @@ class GraphedTrainStep:
             self.grad_sync()
 
     def __call__(self) -> torch.Tensor:
+        if self.graph is None:
+            raise RuntimeError(f"this step was not captured: {self.capture_error!r}")
         self.graph.replay()
         if self.graph_tail is not None:
             self._exchange()

@@ -11,6 +11,15 @@ different is how the host and the GPU are kept apart:
   * the criterion is the one-launch HIP cross-entropy (``ops.CrossEntropyLoss``), numerically
     ``torch.nn.CrossEntropyLoss()`` with default arguments;
   * the default device is "cuda" (this package has no CPU path);
+  * the UNCHANGED reference script -- a list of ``ConnectomeGraph`` behind a ``ConnectomeDataLoader`` and
+    ``Trainer(model, torch.optim.Adam(...), device)`` (examples/demo.py:92-134) -- does not collate on the
+    host: on first sight of such a loader its dataset is packed once into HBM (``PackedDataset``), every
+    epoch's permutation is drawn by the same global ``torch.randperm`` call the loader would make
+    (graph.py:192-194, so seeded runs and golden G7 do not change), batches are assembled on the device
+    bit-identically to ``collate_graphs``, and where the model's one-node encoder is served by the per-subject
+    structure cache the step is captured once per batch size and replayed (``graph=None`` = "where capture
+    succeeds"; a plain ``torch.optim.Adam`` that has not stepped yet is switched to ``capturable=True`` for
+    that).  Irregular datasets (graphs of different sizes) keep the host loader;
   * data-parallel use: ``grad_sync`` (see dist.GradSync) runs between backward and the step,
     weighted by this rank's graph count so that unequal shards (partial tails) still give the
     global-batch gradient; epoch tallies (loss, hits, graphs) are summed over ranks before they
@@ -93,8 +102,14 @@ class _BestWeights:
 class Trainer:
     def __init__(self, model: nn.Module, optimizer: torch.optim.Optimizer, device: str = "cuda",
                  grad_sync: Optional[Callable[[], None]] = None, loss_fn: Optional[nn.Module] = None,
-                 graph: bool = False, graph_collectives: str = "split", max_graphs: int = 32):
-        """``graph=True``: a RESIDENT batch that comes round again (same device tensors, e.g. a
+                 graph: Optional[bool] = None, graph_collectives: str = "split", max_graphs: int = 32,
+                 resident: bool = True):
+        """``resident`` (default on): a list-backed ``ConnectomeDataLoader`` of equally sized graphs is packed
+        into HBM on first sight and iterated on the device (module docstring); ``graph=None`` (default) then
+        replays a captured step where the model's encoder allows it and falls back to eager launches where
+        capture fails; ``graph=False`` never captures.
+
+        ``graph=True``: a RESIDENT batch that comes round again (same device tensors, e.g. a
         ``ResidentDataLoader(cache_batches=True)`` or any loader that yields the same device
         batches each epoch) gets its training step captured as a HIP graph
         (graphed.GraphedTrainStep) on its SECOND sighting and replayed afterwards -- one launch
@@ -113,6 +128,9 @@ class Trainer:
         self.loss_fn = loss_fn if loss_fn is not None else ops.CrossEntropyLoss()
         self.grad_sync = grad_sync
         self.graph = bool(graph)
+        self._graph_auto = graph is None          # decided per loader (resident + capturable), see _resident_loader
+        self.resident = bool(resident)
+        self._resident: Dict[int, tuple] = {}
         self.graph_collectives = graph_collectives
         self.max_graphs = int(max_graphs)
         self._graphs: Dict[tuple, object] = {}
@@ -122,6 +140,88 @@ class Trainer:
                 if not grp.get("capturable", False):
                     raise ValueError("Trainer(graph=True) needs a capturable optimizer, e.g. "
                                      "torch.optim.Adam(params, ..., capturable=True)")
+
+    # ------------------------------------------------------------- the reference script's loader, on the device
+    def _resident_loader(self, loader, training: bool):
+        """The device-resident twin of a list-backed ``ConnectomeDataLoader`` (same batch size, shuffle flag,
+        rank / world size; its permutation comes from the same global-RNG call), built once per loader; None
+        when `loader` is anything else, the device is not a GPU or the graphs are not all one size."""
+        from .graph import ConnectomeDataLoader
+        if not self.resident or type(loader) is not ConnectomeDataLoader:
+            return None
+        dev = torch.device(self.device)
+        if dev.type != "cuda":
+            return None
+        data = loader.dataset
+        if not isinstance(data, (list, tuple)) or len(data) == 0:
+            return None
+        sig = (id(data), len(data), id(data[0]), id(data[-1]), loader.batch_size, bool(loader.shuffle),
+               loader.rank, loader.world_size)
+        hit = self._resident.get(id(loader))
+        if hit is not None and hit[0]() is loader and hit[1] == sig:
+            rl = hit[2]
+        else:
+            rl = self._pack(loader, data, dev)
+            self._resident[id(loader)] = (weakref.ref(loader), sig, rl)
+            if len(self._resident) > 16:                       # loaders that are gone
+                for key in [k for k, v in self._resident.items() if v[0]() is None]:
+                    del self._resident[key]
+        if rl is not None and training and self._graph_auto and not self.graph \
+                and rl.structure_cache is not None and self._make_capturable():
+            self.graph = True
+        return rl
+
+    def _pack(self, loader, data, dev):
+        from .resident import ResidentDataLoader
+        from .synthetic import PackedDataset
+        g0 = data[0]
+        n, e, f = g0.num_nodes, g0.num_edges, g0.num_features
+        for g in data:
+            lab = g.label
+            if g.num_nodes != n or g.num_edges != e or g.num_features != f or not torch.is_tensor(lab) \
+                    or lab.dim() != 0 or lab.dtype != torch.long or g.node_features.dtype != torch.float32 \
+                    or g.edge_weight.dtype != torch.float32 or g.edge_index.dtype != torch.long:
+                return None                  # irregular (or unlabelled) data: the host loader stays
+        ds = PackedDataset.from_graphs(list(data)).to(dev)
+        rl = ResidentDataLoader(ds, batch_size=loader.batch_size, shuffle=bool(loader.shuffle), rank=loader.rank,
+                                world_size=loader.world_size)
+        if self._subject_cache_serves(ds, loader.batch_size):
+            from .structure_cache import SubjectStructureCache
+            rl.structure_cache = SubjectStructureCache(ds)
+        return rl
+
+    def _subject_cache_serves(self, ds, batch_size: int) -> bool:
+        """The per-subject structure cache (structure_cache.py) carries what the per-tile GCN encoder and the
+        GraphSAGE encoder index with, and nothing else (no CSR)."""
+        from . import fused, sage_path
+        from .models import GCNConnectome, GraphSAGEConnectome
+        from .structure_cache import MAX_ROWS
+        m = self.model
+        n = int(ds.x.shape[1])
+        if not (0 < n <= MAX_ROWS) or getattr(m, "impl", None) == "layered" or getattr(m, "storage", "fp32") != "fp32" \
+                or any(isinstance(mod, nn.SyncBatchNorm) for mod in m.modules()) or not sage_path.bn_modules_ok(m):
+            return False
+        hid, fin = m.convs[0].linear.weight.shape
+        if type(m) is GCNConnectome:                       # the per-tile kernels (fused.eligible)
+            return hid == fused.HID and fin <= fused.MAX_F0
+        if type(m) is GraphSAGEConnectome:                 # sage_path.eligible over LDS tiles
+            return hid in (64, 128, 256)
+        return False
+
+    def _make_capturable(self) -> bool:
+        """A captured step needs an optimizer whose step counter lives on the device.  Ours
+        (optim.Adam) does; a plain torch.optim.Adam / AdamW that has not stepped yet is switched to
+        ``capturable=True`` (same update, its state is created on the device at the first step)."""
+        opt = self.optimizer
+        groups = getattr(opt, "param_groups", [])
+        if groups and all(g.get("capturable", False) for g in groups):
+            return True
+        if type(opt) in (torch.optim.Adam, torch.optim.AdamW) and len(opt.state) == 0 \
+                and all(not g.get("differentiable", False) for g in groups):
+            for g in groups:
+                g["capturable"] = True
+            return True
+        return False
 
     def _data_parallel(self) -> bool:
         return self.grad_sync is not None and torch.distributed.is_initialized() \
@@ -172,8 +272,23 @@ class Trainer:
             if len(self._graphs) < self.max_graphs:
                 from .graphed import GraphedResidentStep
                 local = batch.num_graphs if isinstance(self.grad_sync, cdist.GradSync) else None
-                step = GraphedResidentStep(self.model, self.optimizer, batch, self.loss_fn, grad_sync=self.grad_sync,
-                                           warmup=1, collectives=self.graph_collectives, local_graphs=local)
+                try:
+                    step = GraphedResidentStep(self.model, self.optimizer, batch, self.loss_fn, grad_sync=self.grad_sync,
+                                               warmup=1, collectives=self.graph_collectives, local_graphs=local,
+                                               tolerate_capture_failure=self._graph_auto)
+                except (RuntimeError, ValueError) as exc:
+                    # refused BEFORE any step was taken (e.g. a live autograd graph of an earlier step)
+                    if not self._graph_auto:
+                        raise
+                    import warnings
+                    warnings.warn(f"Trainer: no step capture ({exc}); eager launches")
+                    self.graph = self._graph_auto = False
+                    return None
+                if step.graph is None:        # graph=None ("where capture succeeds") and it did not: eager from here
+                    import warnings
+                    warnings.warn(f"Trainer: step capture failed ({step.capture_error!r}); eager launches")
+                    self.graph = self._graph_auto = False
+                    return step.first_loss    # (the warm-up pass was this batch's step)
                 self._graphs[rkey] = step
                 return step.first_loss        # the warm-up pass WAS this batch's step (eager)
             return None
@@ -264,6 +379,7 @@ class Trainer:
         """One pass over ``loader``; mean loss weighted by graphs per batch (train.py:52-54)."""
         self.model.train()
         tally = _DeviceTally()
+        loader = self._resident_loader(loader, True) or loader
         if not self._replay_epoch(loader, tally):
             for batch in loader:
                 graphs = batch.num_graphs
@@ -277,6 +393,7 @@ class Trainer:
         """Accuracy and mean loss (reference train.py:56-74)."""
         self.model.eval()
         losses, hits = _DeviceTally(), _DeviceTally()
+        loader = self._resident_loader(loader, False) or loader
         for batch in loader:
             batch = batch.to(self.device)
             graphs = batch.num_graphs

@@ -243,3 +243,53 @@ def _trainer_replay_equals_eager(ds, masks=True, cls="gcn"):
     ld = ResidentDataLoader(ds, batch_size=40, shuffle=False, structure_cache=True, prepare=tr.model.prepare_batch)
     vals = {round(tr.train_epoch(ld), 7) for _ in range(4)}
     assert len(vals) >= 3, vals
+
+
+@pytest.mark.parametrize("kind,hidden", [("gcn", 64), ("sage", 64), ("gcn", 32)])
+def test_the_unchanged_reference_script_is_served_from_the_device(kind, hidden):
+    """`Trainer(model, torch.optim.Adam(...), device)` over a list-backed
+    `ConnectomeDataLoader` (reference examples/demo.py:92-134, graph.py:174-197) packs the dataset into HBM
+    once, draws each epoch's permutation with the loader's own global-RNG call, assembles batches on the
+    device and -- where the per-subject structure cache serves the encoder -- replays one captured step per
+    batch size.  Same trajectory as the host loader (dropout 0: the masks' stream is the only thing that
+    may differ), same RNG consumption; hidden 32 (no cache, layered path) is served eagerly."""
+    import connectome_gnn_amd as C
+    graphs = C.generate_dataset(72, 84, 8, seed=5)
+    hist, rng_after, evals, trainers = {}, {}, {}, {}
+    for mode in ("host", "default"):
+        torch.manual_seed(3)
+        cls = C.GCNConnectome if kind == "gcn" else C.GraphSAGEConnectome
+        m = cls(5, hidden, dropout=0.0)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-4)
+        tr = C.Trainer(m, opt, device="cuda", **({"resident": False, "graph": False} if mode == "host" else {}))
+        ld = C.ConnectomeDataLoader(graphs[:56], batch_size=16, shuffle=True)        # 3 x 16 + 8: two batch sizes
+        vl = C.ConnectomeDataLoader(graphs[56:], batch_size=16, shuffle=False)
+        hist[mode] = tr.fit(ld, vl, num_epochs=4, patience=10, verbose=False)
+        evals[mode] = tr.evaluate(vl)
+        rng_after[mode] = torch.get_rng_state()
+        trainers[mode] = tr
+    for key in ("train_loss", "val_loss", "val_acc"):
+        torch.testing.assert_close(torch.tensor(hist["default"][key]), torch.tensor(hist["host"][key]),
+                                   rtol=2e-4, atol=2e-6, msg=lambda s: f"{key}: {s}")
+    assert evals["default"]["total"] == evals["host"]["total"] == 16
+    assert torch.equal(rng_after["default"], rng_after["host"])      # the same randperm calls, nothing else drawn
+    tr = trainers["default"]
+    assert len(tr._resident) == 2 and all(v[2] is not None for v in tr._resident.values())
+    served = hidden == 64
+    assert tr.graph is served
+    if served:
+        assert sorted(k[2] for k in tr._graphs) == [8, 16]           # one captured step per batch size
+        assert all(g["capturable"] for g in tr.optimizer.param_groups)
+    else:
+        assert not tr._graphs
+    assert not trainers["host"]._graphs and not trainers["host"]._resident
+
+
+def test_irregular_datasets_keep_the_host_loader():
+    import connectome_gnn_amd as C
+    graphs = C.generate_dataset(8, 20, 4, seed=1) + C.generate_dataset(8, 35, 4, seed=2)
+    m = C.GCNConnectome(5, 64, dropout=0.0)
+    tr = C.Trainer(m, torch.optim.Adam(m.parameters(), lr=1e-3), device="cuda")
+    ld = C.ConnectomeDataLoader(graphs, batch_size=8, shuffle=True)
+    loss = tr.train_epoch(ld)
+    assert loss == loss and list(tr._resident.values())[0][2] is None and not tr.graph
