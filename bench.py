@@ -148,16 +148,21 @@ def pmc_traffic(workload: str, bsz: int):
     return None, None, None
 
 
-def end_to_end(C, ds, model, opt, bsz: int, epochs: int = 6) -> dict:
+def end_to_end(C, ds, model, opt, bsz: int, epochs: int = 6, dataset=None) -> dict:
     """Fresh-batch throughput: Trainer.train_epoch over a ResidentDataLoader
     that re-shuffles every epoch, so on-device assembly, the CSR / blocked-ELL builds of every
-    batch AND the step are inside the clock.  The resident set is this bench's synthetic shard
-    tiled to 4 batches per epoch; the next batch is built on a side stream (prefetch)."""
+    batch AND the step are inside the clock.  `dataset` = the config's own dataset (BASELINE config 4:
+    32,768 distinct subjects = 8 steps per epoch), resident in HBM; without it this bench's synthetic
+    shard tiled to 4 batches per epoch.  The next batch is built on a side stream (prefetch)."""
     from connectome_gnn_amd.resident import ResidentDataLoader
     from connectome_gnn_amd.synthetic import PackedDataset
-    rep = lambda t: t.repeat(4, *([1] * (t.dim() - 1)))
-    big = PackedDataset(rep(ds.x), rep(ds.edge_local), rep(ds.edge_weight), rep(ds.labels))
-    tr = C.Trainer(model, opt, device=str(ds.x.device))
+    if dataset is not None:
+        big = dataset.to(ds.x.device)
+        epochs = 3
+    else:
+        rep = lambda t: t.repeat(4, *([1] * (t.dim() - 1)))
+        big = PackedDataset(rep(ds.x), rep(ds.edge_local), rep(ds.edge_weight), rep(ds.labels))
+    tr = C.Trainer(model, opt, device=str(ds.x.device), graph=False)
 
     def timed_epochs(ld, trainer=None, n_epochs=epochs):
         trainer = trainer or tr
@@ -190,7 +195,10 @@ def end_to_end(C, ds, model, opt, bsz: int, epochs: int = 6) -> dict:
     ld = ResidentDataLoader(big, batch_size=bsz, shuffle=True, prefetch=True, prepare=model.prepare_batch)
     dt = timed_epochs(ld)
     steps = epochs * len(ld)
+    nbytes = lambda *ts: int(sum(t.numel() * t.element_size() for t in ts))
     out = {"graphs_per_s": steps * bsz / dt, "ms_per_step": dt / steps * 1e3, "steps": steps,
+           "subjects": big.num_subjects, "steps_per_epoch": len(ld),
+           "dataset_hbm_bytes": nbytes(big.x, big.edge_local, big.edge_weight, big.labels),
            "what": "assemble + CSR/blocked-ELL build + step per fresh shuffled batch, prefetch on a "
                    "side stream, Trainer.train_epoch API, eager launches"}
     # the same loop with the batches composed once and only their ORDER re-drawn every epoch
@@ -205,8 +213,18 @@ def end_to_end(C, ds, model, opt, bsz: int, epochs: int = 6) -> dict:
     # per-SUBJECT cache (structure_cache.py; one graph per tile, per-tile GCN path)
     n = int(big.x.shape[1])
     if n <= 384 and getattr(model, "_fused_kind", None) == "tile":
-        ld3 = ResidentDataLoader(big, batch_size=bsz, shuffle=True, structure_cache=True, prefetch=True,
-                                 prepare=model.prepare_batch)
+        from connectome_gnn_amd.structure_cache import SubjectStructureCache
+        torch.cuda.synchronize()
+        t_c = time.perf_counter()
+        cache = SubjectStructureCache(big)                 # one per dataset, shared by the loaders below
+        torch.cuda.synchronize()
+        fam = cache.family("gcn")
+        out["subject_cache_build"] = {
+            "seconds": time.perf_counter() - t_c,
+            "hbm_bytes": nbytes(fam.ent_dst, fam.ent_src, fam.blk_off_dst, fam.blk_off_src, fam.norm),
+            "what": "blocked-ELL entries (both orderings), block offsets and dis of every subject, built once"}
+        ld3 = ResidentDataLoader(big, batch_size=bsz, shuffle=True, prefetch=True, prepare=model.prepare_batch)
+        ld3.structure_cache = cache
         dt3 = timed_epochs(ld3)
         out["subject_cache"] = {"graphs_per_s": steps * bsz / dt3, "ms_per_step": dt3 / steps * 1e3,
                                 "what": "fresh shuffled batch every step; blocked-ELL / dis of every "
@@ -219,12 +237,13 @@ def end_to_end(C, ds, model, opt, bsz: int, epochs: int = 6) -> dict:
             for tag, b2 in (("subject_cache_graph", bsz), ("subject_cache_graph_512", 512)):
                 if b2 > bsz:
                     continue
-                ld4 = ResidentDataLoader(big, batch_size=b2, shuffle=True, structure_cache=True, prefetch=True,
-                                         prepare=model.prepare_batch)
-                ne = epochs if b2 == bsz else 2
+                ld4 = ResidentDataLoader(big, batch_size=b2, shuffle=True, prefetch=True, prepare=model.prepare_batch)
+                ld4.structure_cache = cache
+                ne = epochs if b2 == bsz else (1 if dataset is not None else 2)
                 dt4 = timed_epochs(ld4, trg, ne)
                 st4 = ne * len(ld4)
                 out[tag] = {"graphs_per_s": st4 * b2 / dt4, "ms_per_step": dt4 / st4 * 1e3, "batch": b2,
+                            "steps_per_epoch": len(ld4),
                             "what": "fresh shuffled batch every step through Trainer(graph=True): HIP-graph "
                                     "replay with the batch assembled inside the graph from its subject ids"}
             trg.clear_graphs()
@@ -272,6 +291,100 @@ def trainer_replay_record(args, name: str, dev, label: str) -> dict:
             "roofline": None, "final_loss": last}
 
 
+def demo_record(dev) -> dict:
+    """BASELINE config 1: the reference's demo experiment (examples/demo.py = /root/reference/examples/demo.py:35-134
+    on this package: 300 x 84-ROI subjects, GCN + GraphSAGE hidden 64, batch 16, Adam, 30 epochs, patience 8)
+    through the drop-in API with its defaults -- list-backed ConnectomeDataLoader, Trainer(model, torch.optim.Adam).
+    Wall seconds of the whole script incl. data generation (reference on 8 CPU cores: 11.2 s)."""
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import demo
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = demo.run(device=str(dev), epochs=30, verbose=False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"workload": "cfg1-demo-300x84-gcn+sage-h64-b16", "launch": "examples/demo.py, Trainer defaults",
+            "wall_seconds": dt, "unit": "s", "higher_is_better": False,
+            "test_accuracy": {k: v["test"]["accuracy"] for k, v in res.items()},
+            "epochs_run": {k: len(v["history"]["train_loss"]) for k, v in res.items()},
+            "impl": {k: v["impl"] for k, v in res.items()}}
+
+
+def plain_loader_record(args, name: str, dev, label: str) -> dict:
+    """A config the way the UNCHANGED reference script runs it: a Python list of ConnectomeGraph on the host,
+    `ConnectomeDataLoader(graphs, batch_size, shuffle=True)` (reference graph.py:174-197) and
+    `Trainer(model, torch.optim.Adam(...), device)` with every default (train.py:19-54).  The Trainer packs
+    the list into HBM on first sight and replays a captured step per batch size (train.py module docstring);
+    the one-off packing is reported beside the steady-state step."""
+    import connectome_gnn_amd as C
+    from connectome_gnn_amd.synthetic import generate_packed
+    wl = WORKLOADS[name]
+    n, k, hidden, bsz = wl["n"], wl["k"], wl["hidden"], wl["batch"]
+    host = generate_packed(8 * bsz, n, k, seed=42)
+    graphs = [host.graph(i) for i in range(host.num_subjects)]
+    torch.manual_seed(42)
+    cls = C.GCNConnectome if wl["model"] == "gcn" else C.GraphSAGEConnectome
+    model = cls(5, hidden, 2, 3, 0.3)
+    tr = C.Trainer(model, torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4), device=str(dev))
+    ld = C.ConnectomeDataLoader(graphs, batch_size=bsz, shuffle=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tr.train_epoch(ld)                       # packs, builds the subject cache, captures
+    torch.cuda.synchronize()
+    first = time.perf_counter() - t0
+    tr.train_epoch(ld)
+    epochs = max(1, -(-args.steps // len(ld)))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(epochs):
+        last = tr.train_epoch(ld)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    steps = epochs * len(ld)
+    gps = steps * bsz / dt
+    bpg = algorithmic_bytes_per_graph(wl["model"], n, n * k, hidden)
+    rec = {"workload": label, "launch": "ConnectomeDataLoader(list) + Trainer(model, torch.optim.Adam) defaults "
+                                        f"({'hip-graph replay' if tr.graph else 'eager'})",
+           "dtype": "f32", "graphs_per_gpu": bsz, "impl": getattr(model, "impl_used", None),
+           "ms_per_step": dt / steps * 1e3, "value": gps, "unit": "graphs/s", "steps": steps,
+           "first_epoch_seconds": first,
+           "step_algorithmic": {"frac": bpg * gps / (HBM_PEAK_GBS * 1e9), "bytes_per_graph": bpg,
+                                "real_hbm_bytes_per_step": None, "real_traffic_frac": None},
+           "roofline": None, "final_loss": last}
+    tr.clear_graphs()
+    return rec
+
+
+def inference_record(name: str, dev, label: str, dataset=None) -> dict:
+    """N4: `Trainer.evaluate` (reference train.py:56-74) over a device-resident dataset, eval-mode
+    BatchNorm, no dropout; graphs/s incl. the loader, the loss / hit tallies and the one read-back."""
+    import connectome_gnn_amd as C
+    from connectome_gnn_amd.optim import Adam
+    from connectome_gnn_amd.resident import ResidentDataLoader
+    from connectome_gnn_amd.synthetic import generate_packed
+    wl = WORKLOADS[name]
+    n, k, hidden, bsz = wl["n"], wl["k"], wl["hidden"], wl["batch"]
+    ds = (dataset if dataset is not None else generate_packed(8 * bsz, n, k, seed=42)).to(dev)
+    torch.manual_seed(42)
+    cls = C.GCNConnectome if wl["model"] == "gcn" else C.GraphSAGEConnectome
+    model = cls(5, hidden, 2, 3, 0.3).to(dev)
+    tr = C.Trainer(model, Adam(model.parameters(), lr=1e-3), device=str(dev), graph=False)
+    ld = ResidentDataLoader(ds, batch_size=bsz, shuffle=False, structure_cache=True)
+    for _ in range(2):
+        tr.evaluate(ld)
+    reps = max(1, 24 // len(ld))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ev = tr.evaluate(ld)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"workload": label, "launch": "Trainer.evaluate over ResidentDataLoader(structure_cache=True), eager",
+            "dtype": "f32", "graphs_per_gpu": bsz, "impl": getattr(model, "impl_used", None),
+            "ms_per_batch": dt / (reps * len(ld)) * 1e3, "value": reps * ds.num_subjects / dt, "unit": "graphs/s",
+            "subjects": ds.num_subjects, "accuracy": ev["accuracy"]}
+
+
 def spawn_workers(n: int) -> int:
     """`python bench.py --gpus N` outside torchrun: start N ranks as a CHILD torch.distributed.run
     (never an exec: this process may not be replaced once anything has initialised the GPU, and
@@ -294,7 +407,7 @@ def note(rank: int, msg: str) -> None:
 
 
 def run_workload(args, name: str, rank: int, world: int, dev, *, launch: str, batch: int = 0,
-                 label: str = None, extras: bool = True) -> dict:
+                 label: str = None, extras: bool = True, e2e_dataset=None) -> dict:
     """Warm up, time `args.steps` steps of workload `name` and return the JSON record (on every
     rank; only rank 0's is printed).  `label` names the record when it differs from the workload
     key (the 512-graph shard of the headline)."""
@@ -538,7 +651,7 @@ def run_workload(args, name: str, rank: int, world: int, dev, *, launch: str, ba
                                        "what": "same step, dataset preprocessed with "
                                                "PackedDataset.relabel_by_degree()"}
     if extras and rank == 0 and world == 1 and not args.no_end_to_end and n <= 384:
-        out["end_to_end"] = end_to_end(C, ds, model, opt, bsz)
+        out["end_to_end"] = end_to_end(C, ds, model, opt, bsz, dataset=e2e_dataset)
     return out
 
 
@@ -549,6 +662,9 @@ EXTRA_CONFIGS = (
     ("cfg2-gcn-512x84-h64", "cfg2-gcn-512x84-h64", "graph", 0),
     # the same config through the drop-in Trainer with per-epoch reshuffling (VERDICT r2 missing #4)
     ("cfg2-gcn-512x84-h64", "cfg2-gcn-512x84-h64", "trainer", 0),
+    # ... and through the reference script's own plumbing: list of graphs, ConnectomeDataLoader, Trainer defaults
+    ("cfg2-gcn-512x84-h64", "cfg2-gcn-512x84-h64", "plain", 0),
+    ("cfg1-demo", "cfg2-gcn-512x84-h64", "demo", 0),
     ("cfg3-sage-512x360-h128", "cfg3-sage-512x360-h128", "graph", 0),
     ("cfg3-sage-512x360-h128", "cfg3-sage-512x360-h128", "trainer", 0),
     ("cfg5-gcn-64x1000-h256-fp16", "cfg5-gcn-64x1000-h256-fp16", "graph", 0),
@@ -603,6 +719,9 @@ def main() -> None:
     ap.add_argument("--no-configs", action="store_true",
                     help="headline only: skip the other single-GPU BASELINE configs (cfg2/3/5, 512-graph shard)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
+    ap.add_argument("--subjects", type=int, default=32768,
+                    help="subjects of the headline config's dataset for the end-to-end (loader-inclusive) "
+                         "measurement: BASELINE config 4 says 32768 (8 steps of 4096 per epoch on one GPU)")
     ap.add_argument("--one-device", action="store_true",
                     help="rehearsal only: every rank on cuda:0 (use with --backend gloo)")
     args = ap.parse_args()
@@ -612,6 +731,18 @@ def main() -> None:
         raise SystemExit(spawn_workers(args.gpus))      # nothing has touched the GPU yet
 
     from connectome_gnn_amd import dist as cdist
+
+    # BASELINE config 4's dataset (32,768 x 360-ROI subjects, 3.5 GB): generated on the host cores by forked
+    # workers NOW, before this process touches the GPU (a fork afterwards would share the device handles)
+    e2e_dataset = None
+    headline_default = args.workload.startswith("cfg4") and not args.batch and args.impl == "auto"
+    if args.gpus == 1 and headline_default and not args.no_end_to_end and args.subjects > 4096:
+        from connectome_gnn_amd.synthetic import generate_packed
+        wl0 = WORKLOADS[args.workload]
+        t_gen = time.perf_counter()
+        e2e_dataset = generate_packed(args.subjects, wl0["n"], wl0["k"], seed=4242,
+                                      workers=min(16, os.cpu_count() or 1))
+        note(0, f"generated {args.subjects} x {wl0['n']}-ROI subjects in {time.perf_counter() - t_gen:.1f} s")
 
     if args.one_device:
         os.environ["LOCAL_RANK"] = "0"
@@ -623,9 +754,18 @@ def main() -> None:
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    out = run_workload(args, args.workload, rank, world, dev, launch=args.launch, batch=args.batch)
-    headline_default = args.workload.startswith("cfg4") and not args.batch and args.impl == "auto"
+    out = run_workload(args, args.workload, rank, world, dev, launch=args.launch, batch=args.batch,
+                       e2e_dataset=e2e_dataset)
     if world == 1 and headline_default and not args.no_configs:
+        out["inference"] = []
+        for label, key, data in (("cfg4-headline-gcn-4096x360-h64", args.workload, e2e_dataset),
+                                 ("cfg2-gcn-512x84-h64", "cfg2-gcn-512x84-h64", None)):
+            try:
+                out["inference"].append(inference_record(key, dev, label, data))
+            except Exception as exc:         # noqa: BLE001
+                out["inference"].append({"workload": label, "error": f"{type(exc).__name__}: {exc}"})
+                torch.cuda.synchronize()
+        e2e_dataset = None
         import gc
         out["configs"] = []
         for label, key, launch, batch in EXTRA_CONFIGS:
@@ -635,6 +775,12 @@ def main() -> None:
             try:
                 if launch == "trainer":
                     out["configs"].append(trainer_replay_record(args, key, dev, label))
+                    continue
+                if launch == "plain":
+                    out["configs"].append(plain_loader_record(args, key, dev, label))
+                    continue
+                if launch == "demo":
+                    out["configs"].append(demo_record(dev))
                     continue
                 rec = run_workload(args, key, rank, world, dev, launch=launch, batch=batch, label=label,
                                    extras=False)

@@ -220,6 +220,12 @@ class Trainer:
                 and all(not g.get("differentiable", False) for g in groups):
             for g in groups:
                 g["capturable"] = True
+                # the multi-tensor update in ONE kernel instead of a dozen _foreach launches per step, when the
+                # caller left the implementation choice to torch (both flags at their default None) and every
+                # parameter is an fp32 device tensor
+                if g.get("foreach") is None and g.get("fused") is None and not g.get("amsgrad", False) \
+                        and all(p.is_cuda and p.dtype == torch.float32 for p in g["params"]):
+                    g["fused"] = True
             return True
         return False
 
