@@ -180,39 +180,9 @@ def test_full_grid_real_size_vs_oracle(kind, n, k, hidden, nb, twin):
                                           (128, 0, 128, False),
                                           (256, 0, 128, True)])
 def test_ws_gemm_200k_rows(k1, k2, n, relu):
-    """Weight-stationary fwd / bwd_input / bwd_weight at M = 200,000: ~24 row blocks of 32 per wave.
-    Against a float64 product.  With 25.6 M ReLU decisions a few pre-activations sit within fp32 rounding
-    of zero (one of them moves a whole row of dX by dy_j * W[j, :]), so the reference takes the kernel's
-    own decisions, which must agree with float64's wherever |pre| > 1e-5."""
-    from connectome_gnn_amd import ops
-    m = 200_000
-    g = torch.Generator().manual_seed(m + n + k1)
-    x1 = torch.randn(m, k1, generator=g)
-    x2 = torch.randn(m, k2, generator=g) if k2 else None
-    w = torch.randn(n, k1 + k2, generator=g) / (k1 + k2) ** 0.5
-    bv = torch.randn(n, generator=g)
-    cot = torch.randn(m, n, generator=g)
-    ts = [t.clone().to(DEV).requires_grad_(True) if t is not None else None for t in (x1, x2, w, bv)]
-    y = ops.linear(*ts, relu)
-    (y * cot.to(DEV)).sum().backward()
-    xx = (x1 if x2 is None else torch.cat([x1, x2], 1)).double()
-    pre = xx @ w.double().t() + bv.double()
-    if relu:
-        keep = (y.detach().cpu() > 0)
-        disagree = keep != (pre > 0)
-        assert int(disagree.sum()) <= 16 and float(pre[disagree].abs().max() if disagree.any() else 0.0) < 1e-5
-        want_y, dpre = pre * keep, cot.double() * keep
-    else:
-        want_y, dpre = pre, cot.double()
-    close = lambda got, want: torch.testing.assert_close(
-        got.detach().cpu().double(), want, rtol=1e-5, atol=1e-5 * float(want.abs().max()) + 1e-6)
-    close(y, want_y)
-    dx = dpre @ w.double()
-    close(ts[0].grad, dx[:, :k1])
-    if x2 is not None:
-        close(ts[1].grad, dx[:, k1:])
-    close(ts[2].grad, dpre.t() @ xx)
-    close(ts[3].grad, dpre.sum(0))
+    """Weight-stationary fwd / bwd_input / bwd_weight at M = 200,000: ~24 row blocks of 32 per wave, against a
+    float64 product (ReLU decisions within rounding of zero taken from the kernel, see K.linear_check)."""
+    K.linear_check(200_000, k1, k2, n, relu, True)
 
 
 @pytest.mark.parametrize("k,n", [(256, 256), (128, 128), (64, 256)])
