@@ -406,6 +406,52 @@ def note(rank: int, msg: str) -> None:
         print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
+def plan_run(scaling: str, launch: str, gbatch: int, rank: int, world: int) -> dict:
+    """The rank bookkeeping of one run, free of any GPU work (tests/test_host_logic.py drives it for --gpus 8):
+    which graphs this rank trains on, what the global batch is, and how the step is launched.
+    strong: the global batch `gbatch` is cut into contiguous runs, sizes differing by at most one
+    graph; weak: every rank trains on its own `gbatch` graphs.  launch "auto" replays a HIP graph when the
+    per-rank shard is host-bound (< 2048 graphs), else launches eagerly."""
+    if scaling == "strong":
+        from connectome_gnn_amd.graph import shard_slice
+        shard_sizes = [len(shard_slice(list(range(gbatch)), r, world)) for r in range(world)]
+        bsz, global_batch = shard_sizes[rank], gbatch
+        if min(shard_sizes) == 0:
+            raise SystemExit(f"global batch {gbatch} < world size {world}")
+    else:
+        shard_sizes = [gbatch] * world
+        bsz, global_batch = gbatch, gbatch * world
+    if launch == "auto":
+        launch = "graph" if bsz < 2048 else "eager"
+    return {"shard_sizes": shard_sizes, "graphs_this_rank": bsz, "global_batch": global_batch,
+            "equal_shards": len(set(shard_sizes)) == 1, "launch": launch,
+            "local_graphs": None if len(set(shard_sizes)) == 1 else bsz}
+
+
+def parallel_config(world: int, backend, scaling: str, sync_bn: bool, graphed: bool, collectives: str,
+                    launch_note) -> dict:
+    """The `config` keys that say what ran across ranks (backend "nccl" IS RCCL on ROCm)."""
+    return {"launch": ("hip-graph replay" + (f" ({collectives} all-reduce)" if world > 1 else "")) if graphed else "eager",
+            "launch_note": launch_note,
+            "bn": "sync" if (world > 1 and sync_bn) else "per-rank",
+            "backend": ("rccl" if backend == "nccl" else backend), "rccl_ranks": world if backend == "nccl" else 0,
+            "parallelism": f"graph-sharded dp{world}"}
+
+
+def projection_8gpu(headline_ms: float, shard_ms: float, gbatch: int = 4096) -> dict:
+    """NOT a measurement: what the 1-GPU records imply for 8-GPU strong scaling of the headline batch -- each
+    rank's 512-graph step as timed here on one GPU plus ONE gradient all-reduce of 45 KB (latency-bound over
+    xGMI; 30-50 us assumed, RCCL has not run on this build's hardware).  Reported under `projection`, never as
+    `value`; the driver's SCALE_rNN.json is the measurement when a node exists."""
+    out = {"what": "projection from 1-GPU timings, not measured", "n_gpus": 8, "global_batch": gbatch,
+           "shard_ms_per_step_measured_1gpu": shard_ms, "allreduce_ms_assumed": [0.03, 0.05],
+           "headline_ms_per_step_measured_1gpu": headline_ms}
+    gps = [gbatch / ((shard_ms + a) * 1e-3) for a in out["allreduce_ms_assumed"]]
+    out["graphs_per_s"] = gps
+    out["speedup_vs_1gpu"] = [g / (gbatch / (headline_ms * 1e-3)) for g in gps]
+    return out
+
+
 def run_workload(args, name: str, rank: int, world: int, dev, *, launch: str, batch: int = 0,
                  label: str = None, extras: bool = True, e2e_dataset=None) -> dict:
     """Warm up, time `args.steps` steps of workload `name` and return the JSON record (on every
@@ -422,20 +468,9 @@ def run_workload(args, name: str, rank: int, world: int, dev, *, launch: str, ba
         wl["batch"] = batch
     model_kind, n, k, hidden, gbatch = wl["model"], wl["n"], wl["k"], wl["hidden"], wl["batch"]
     e = n * k
-    if args.scaling == "strong":
-        # contiguous runs of the global batch; sizes differ by at most one graph
-        from connectome_gnn_amd.graph import shard_slice
-        shard_sizes = [len(shard_slice(list(range(gbatch)), r, world)) for r in range(world)]
-        bsz, global_batch = shard_sizes[rank], gbatch
-        if min(shard_sizes) == 0:
-            raise SystemExit(f"global batch {gbatch} < world size {world}")
-    else:
-        shard_sizes = [gbatch] * world
-        bsz, global_batch = gbatch, gbatch * world
-    equal_shards = len(set(shard_sizes)) == 1
-    if launch == "auto":
-        launch = "graph" if bsz < 2048 else "eager"
-    use_graph = launch == "graph"
+    plan = plan_run(args.scaling, launch, gbatch, rank, world)
+    shard_sizes, bsz, global_batch = plan["shard_sizes"], plan["graphs_this_rank"], plan["global_batch"]
+    equal_shards, launch, use_graph = plan["equal_shards"], plan["launch"], plan["launch"] == "graph"
 
     # ---- data: this rank's shard of the synthetic dataset, resident in HBM ------------------
     ds = generate_packed(bsz, n, k, seed=42 + rank).to(dev)
@@ -473,7 +508,7 @@ def run_workload(args, name: str, rank: int, world: int, dev, *, launch: str, ba
         from connectome_gnn_amd.optim import Adam      # torch.optim.Adam's update as one launch
         opt = Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
     loss_fn = cops.CrossEntropyLoss()        # the Trainer's criterion: CrossEntropyLoss defaults
-    local_graphs = None if equal_shards else bsz
+    local_graphs = plan["local_graphs"]
 
     def eager_step(i: int):
         b = batches[i % len(batches)]
@@ -607,12 +642,8 @@ def run_workload(args, name: str, rank: int, world: int, dev, *, launch: str, ba
                    "graphs_per_gpu": bsz, "global_batch": global_batch, "shard_sizes": shard_sizes,
                    "dropout": 0.3,
                    "optimizer": "Adam lr1e-3 wd1e-4" + (" (torch fused)" if args.optimizer == "torch" else " (optim.Adam)"), "impl": impl_used,
-                   "launch": ("hip-graph replay" + (f" ({collectives} all-reduce)" if world > 1 else ""))
-                   if graphed is not None else "eager",
-                   "launch_note": launch_note,
-                   "bn": "sync" if (world > 1 and args.sync_bn) else "per-rank",
-                   "backend": ("rccl" if backend == "nccl" else backend), "rccl_ranks": world if backend == "nccl" else 0,
-                   "parallelism": f"graph-sharded dp{world}"},
+                   **parallel_config(world, backend, args.scaling, args.sync_bn, graphed is not None, collectives,
+                                     launch_note)},
         "step_algorithmic": {"bytes_per_graph": bpg,
                              "GBps": bpg * graphs_per_s / world / 1e9,
                              "frac_of_hbm_peak": bpg * graphs_per_s / world / (HBM_PEAK_GBS * 1e9),
@@ -788,6 +819,10 @@ def main() -> None:
             except Exception as exc:         # noqa: BLE001 -- one config must not cost the headline line
                 out["configs"].append({"workload": label, "launch": launch, "error": f"{type(exc).__name__}: {exc}"})
                 torch.cuda.synchronize()
+    if rank == 0 and world == 1 and "configs" in out:
+        shard = [c for c in out["configs"] if c.get("workload", "").startswith("shard512") and "ms_per_step" in c]
+        if shard:
+            out["projection"] = projection_8gpu(out["ms_per_step"], shard[0]["ms_per_step"])
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             wl = WORKLOADS[args.workload]

@@ -94,8 +94,7 @@ def test_g7_trainer_trajectory(kind):
                   num_epochs=3, patience=8, verbose=False)
     gh = G.group(d, f"{kind}_hist")
     np.testing.assert_allclose(hist["train_loss"], gh["train_loss"].numpy(), rtol=1e-4, atol=1e-5)
-    np.testing.assert_allclose(hist["val_loss"], gh["val_loss"].numpy(),
-                               rtol=1e-3 if kind == "gcn" else 1e-4, atol=1e-5)
+    np.testing.assert_allclose(hist["val_loss"], gh["val_loss"].numpy(), rtol=1e-4, atol=1e-5)
     ev = tr.evaluate(C.ConnectomeDataLoader(gs[30:], batch_size=10, shuffle=False))
     assert ev["total"] == 10 and 0.0 <= ev["accuracy"] <= 1.0
     sd = m.state_dict()

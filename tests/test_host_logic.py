@@ -294,3 +294,36 @@ def test_bench_extra_configs_name_known_workloads():
                  "shard512-gcn-512x360-h64"):
         assert want in labels
     assert all(key in bench.WORKLOADS and launch in ("eager", "graph", "auto", "trainer", "plain", "demo") for _, key, launch, _ in bench.EXTRA_CONFIGS)
+
+
+def test_bench_rank_bookkeeping_for_eight_gpus():
+    """The 8-GPU run nobody can rehearse on hardware: bench.py's rank bookkeeping driven for
+    --gpus 8 with no GPU work -- shard sizes, launch=auto -> HIP-graph replay at 512 graphs per rank, the config
+    keys that name RCCL, the unequal-shard weights, and the projected figure kept out of `value`."""
+    import bench
+    sizes = []
+    for r in range(8):
+        p = bench.plan_run("strong", "auto", 4096, r, 8)
+        assert p["shard_sizes"] == [512] * 8 and p["graphs_this_rank"] == 512 and p["global_batch"] == 4096
+        assert p["equal_shards"] and p["local_graphs"] is None
+        assert p["launch"] == "graph"                      # 512 graphs per rank are host-bound when launched eagerly
+        sizes.append(p["graphs_this_rank"])
+    assert sum(sizes) == 4096
+    # 1, 2, 4 GPUs of the driver's scaling sweep: eager at >= 2048 graphs per rank, replay below
+    assert [bench.plan_run("strong", "auto", 4096, 0, w)["launch"] for w in (1, 2, 4, 8)] == ["eager", "eager", "graph", "graph"]
+    # a global batch that does not divide: contiguous runs differing by one graph, weights = local counts
+    p = [bench.plan_run("strong", "auto", 4100, r, 8) for r in range(8)]
+    assert [q["graphs_this_rank"] for q in p] == [513] * 4 + [512] * 4 and not p[0]["equal_shards"]
+    assert [q["local_graphs"] for q in p] == [513] * 4 + [512] * 4
+    w = bench.plan_run("weak", "auto", 4096, 3, 8)
+    assert w["global_batch"] == 8 * 4096 and w["graphs_this_rank"] == 4096 and w["launch"] == "eager"
+    with pytest.raises(SystemExit):
+        bench.plan_run("strong", "auto", 4, 0, 8)
+    cfg = bench.parallel_config(8, "nccl", "strong", False, True, "split", None)
+    assert cfg["backend"] == "rccl" and cfg["rccl_ranks"] == 8 and cfg["bn"] == "per-rank"
+    assert cfg["launch"] == "hip-graph replay (split all-reduce)" and cfg["parallelism"] == "graph-sharded dp8"
+    cfg = bench.parallel_config(8, "gloo", "strong", True, False, "split", "graph capture failed on another rank; eager launches")
+    assert cfg["rccl_ranks"] == 0 and cfg["launch"] == "eager" and cfg["bn"] == "sync" and "another rank" in cfg["launch_note"]
+    pr = bench.projection_8gpu(1.86, 0.327)
+    assert "value" not in pr and pr["what"].startswith("projection") and pr["n_gpus"] == 8
+    assert 4.5 < pr["speedup_vs_1gpu"][1] < pr["speedup_vs_1gpu"][0] < 6.0
