@@ -453,7 +453,7 @@ def projection_8gpu(headline_ms: float, shard_ms: float, gbatch: int = 4096) -> 
 
 
 def run_workload(args, name: str, rank: int, world: int, dev, *, launch: str, batch: int = 0,
-                 label: str = None, extras: bool = True, e2e_dataset=None) -> dict:
+                 label: str = None, extras: bool = True, e2e_dataset=None, dp_plumbing: bool = False) -> dict:
     """Warm up, time `args.steps` steps of workload `name` and return the JSON record (on every
     rank; only rank 0's is printed).  `label` names the record when it differs from the workload
     key (the 512-graph shard of the headline)."""
@@ -497,7 +497,10 @@ def run_workload(args, name: str, rank: int, world: int, dev, *, launch: str, ba
         cdist.broadcast_parameters(model)
         if args.sync_bn:
             model = cdist.convert_sync_batchnorm(model)
-    sync = cdist.GradSync(model.parameters()) if world > 1 else None
+    # (--dp-plumbing: one rank with the data-parallel gradient path in place -- gradients land in the flat
+    # all-reduce buffer, the exchange itself is a no-op at world 1: what a rank's step costs besides the wire)
+    dp_plumbing = dp_plumbing or getattr(args, "dp_plumbing", False)
+    sync = cdist.GradSync(model.parameters()) if (world > 1 or dp_plumbing) else None
     collectives = args.collectives
     if use_graph and world > 1 and args.sync_bn:
         collectives = "captured"          # sync-BN exchanges sit inside forward/backward
@@ -702,6 +705,9 @@ EXTRA_CONFIGS = (
     ("cfg5-gcn-64x1000-h256-fp32", "cfg5-gcn-64x1000-h256-fp32", "graph", 0),
     # one rank's share of the headline batch at 8 GPUs (strong scaling), for the >= 6x projection
     ("shard512-gcn-512x360-h64", "cfg4-headline-gcn-4096x360-h64", "graph", 512),
+    # ... and the same shard with the data-parallel gradient path in place (dist.GradSync: gradients written into
+    # the flat all-reduce buffer; at world 1 the exchange itself is a no-op): a rank's step minus the wire
+    ("shard512-dp-plumbing-gcn-512x360-h64", "cfg4-headline-gcn-4096x360-h64", "graph-dp", 512),
 )
 
 
@@ -753,6 +759,9 @@ def main() -> None:
     ap.add_argument("--subjects", type=int, default=32768,
                     help="subjects of the headline config's dataset for the end-to-end (loader-inclusive) "
                          "measurement: BASELINE config 4 says 32768 (8 steps of 4096 per epoch on one GPU)")
+    ap.add_argument("--dp-plumbing", action="store_true",
+                    help="single rank with dist.GradSync in place (flat gradient buffer, exchange a no-op): the "
+                         "per-rank step of a data-parallel run without the wire")
     ap.add_argument("--one-device", action="store_true",
                     help="rehearsal only: every rank on cuda:0 (use with --backend gloo)")
     args = ap.parse_args()
@@ -813,16 +822,18 @@ def main() -> None:
                 if launch == "demo":
                     out["configs"].append(demo_record(dev))
                     continue
-                rec = run_workload(args, key, rank, world, dev, launch=launch, batch=batch, label=label,
-                                   extras=False)
+                rec = run_workload(args, key, rank, world, dev, launch=launch.replace("-dp", ""), batch=batch,
+                                   label=label, extras=False, dp_plumbing=launch.endswith("-dp"))
                 out["configs"].append(summarise(rec))
             except Exception as exc:         # noqa: BLE001 -- one config must not cost the headline line
                 out["configs"].append({"workload": label, "launch": launch, "error": f"{type(exc).__name__}: {exc}"})
                 torch.cuda.synchronize()
     if rank == 0 and world == 1 and "configs" in out:
-        shard = [c for c in out["configs"] if c.get("workload", "").startswith("shard512") and "ms_per_step" in c]
+        shard = [c for c in out["configs"] if c.get("workload", "").startswith("shard512-dp") and "ms_per_step" in c] \
+            or [c for c in out["configs"] if c.get("workload", "").startswith("shard512") and "ms_per_step" in c]
         if shard:
             out["projection"] = projection_8gpu(out["ms_per_step"], shard[0]["ms_per_step"])
+            out["projection"]["shard_record"] = shard[0]["workload"]
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             wl = WORKLOADS[args.workload]

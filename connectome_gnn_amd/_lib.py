@@ -200,6 +200,7 @@ PROTOTYPES = {
     "cgnn_gcn_l0_bwd": (c_int, [P, P, LP, P, P, P, I64, P, I64, P, I64, P, P]),
     "cgnn_slab_reduce_f32": (c_int, [P, I32, I32, I32, I32, P, I32, P]),
     "cgnn_slab_reduce_f64": (c_int, [P, I32, I32, P, P]),
+    "cgnn_slab_reduce_f32_split": (c_int, [P, I32, I32, I32, P, P, P]),
 }
 
 

@@ -1158,7 +1158,8 @@ template <typename T>
 __global__ void __launch_bounds__(256) k_slab_reduce(const T* __restrict__ slab, int rows,
                                                      int width, double* __restrict__ out_d,
                                                      float* __restrict__ out_f, int out_cols,
-                                                     int take_cols, int ld_out) {
+                                                     int take_cols, int ld_out,
+                                                     float* __restrict__ out_tail = nullptr, int split = 0) {
   // one block per 4 output elements: 64 threads (one wave) per element, fixed-order tree
   const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -1168,7 +1169,9 @@ __global__ void __launch_bounds__(256) k_slab_reduce(const T* __restrict__ slab,
   s = cgnn_wave_sum(s);
   if (e < width && lane == 0) {
     if (out_d) out_d[e] = s;
-    if (out_f) {
+    if (out_tail && e >= split) {
+      out_tail[e - split] = (float)s;
+    } else if (out_f) {
       const int rr = e / out_cols, cc = e % out_cols;
       if (cc < take_cols) out_f[(int64_t)rr * ld_out + cc] = (float)s;
     }
@@ -1714,6 +1717,15 @@ int cgnn_slab_reduce_f32(const float* slab, int32_t rows, int32_t out_rows, int3
   const int width = out_rows * out_cols;
   k_slab_reduce<float><<<(width + 3) / 4, 256, 0, cgnn_stream(stream)>>>(
       slab, rows, width, nullptr, out, out_cols, take_cols, ld_out);
+  CGNN_CHECK_LAUNCH();
+  return CGNN_OK;
+}
+
+int cgnn_slab_reduce_f32_split(const float* slab, int32_t rows, int32_t width, int32_t split, float* out,
+                               float* out_tail, void* stream) {
+  if (!slab || !out || !out_tail || rows <= 0 || width <= 0 || split <= 0 || split >= width) return CGNN_EINVAL;
+  k_slab_reduce<float><<<(width + 3) / 4, 256, 0, cgnn_stream(stream)>>>(slab, rows, width, nullptr, out, width,
+                                                                        width, width, out_tail, split);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }

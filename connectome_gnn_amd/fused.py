@@ -91,7 +91,7 @@ def _l0_center(lib, s, x0: torch.Tensor, tiles_ref, stream) -> torch.Tensor:
 class _Ctx:
     """Everything of one forward pass that backward needs and autograd must not track."""
     __slots__ = ("s", "meta", "dis", "tiles", "grid", "ys", "bns", "masks", "p", "x0", "f0", "p0", "count_dev", "fsum", "l0src", "l0keep",
-                 "count", "sync_group", "num_layers", "training")
+                 "count", "sync_group", "num_layers", "training", "grad_dst")
 
 
 def _sync_sums(buf: torch.Tensor, group) -> None:
@@ -243,6 +243,7 @@ class FusedGCNEncode(torch.autograd.Function):
         c.count_dev = count_dev
         c.fsum = fsum
         c.l0src, c.l0keep = l0src, l0keep
+        c.grad_dst = meta.get("grad_dst") or [None] * (4 * L)
         if meta.get("record") is not None:
             meta["record"]["layers"] = list(masks)
         ctx.c = c
@@ -271,10 +272,19 @@ class FusedGCNEncode(torch.autograd.Function):
         dz = torch.empty(nn_, HID, **f32)
         dz_prev = torch.empty(nn_, HID, **f32) if L > 1 else None
         grads: List[Optional[torch.Tensor]] = [None] * (4 * L)
+        dst = c.grad_dst
+
+        def out(i: int, *shape) -> torch.Tensor:
+            """where parameter i's gradient is written: its armed .grad view (ops.grad_destination; the
+            gradient is then NOT returned to autograd) or a fresh tensor"""
+            return dst[i] if dst[i] is not None else torch.empty(*shape, **f32)
 
         def bn_backward(l: int) -> torch.Tensor:
             """sums of layer l (in s_slab) -> dgamma/dbeta of layer l and its c1|c2 block."""
-            dgamma, dbeta, bwc = torch.empty(HID, **f32), torch.empty(HID, **f32), torch.empty(2 * HID, **f32)
+            direct = c.sync_group is None       # (under sync-BN the parameter gradients are the LOCAL sums)
+            dgamma = out(4 * l + 2, HID) if direct else torch.empty(HID, **f32)
+            dbeta = out(4 * l + 3, HID) if direct else torch.empty(HID, **f32)
+            bwc = torch.empty(2 * HID, **f32)
             if c.sync_group is None:
                 _lib.check(lib.cgnn_bn_bwd_stats_finalize(
                     _lib.ptr(s_slab), grid, c.count, int(not c.training), _lib.ptr(dgamma),
@@ -301,7 +311,7 @@ class FusedGCNEncode(torch.autograd.Function):
         with _lib.device_guard(dev):
             if c.fsum is not None and c.sync_group is None:
                 # per-rank BatchNorm: the sums over all graphs and the coefficients in one launch
-                dgamma, dbeta, bwc = torch.empty(HID, **f32), torch.empty(HID, **f32), torch.empty(2 * HID, **f32)
+                dgamma, dbeta, bwc = out(4 * (L - 1) + 2, HID), out(4 * (L - 1) + 3, HID), torch.empty(2 * HID, **f32)
                 _lib.check(lib.cgnn_gcn_fused_pool_bwd_finalize(
                     _lib.ptr(d_pooled), _lib.ptr(c.fsum), c.fsum.data_ptr() + 4 * B * HID, _lib.ptr(s.gptr), B,
                     c.count, int(not c.training), _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(bwc), st()),
@@ -330,12 +340,12 @@ class FusedGCNEncode(torch.autograd.Function):
                         _lib.ptr(c.bns[l - 1]), c.p, _lib.ptr(c.masks[l - 1]),
                         _lib.ptr(w), _lib.ptr(dz_prev), _lib.ptr(s_slab), _lib.nbytes(s_slab), _lib.ptr(dw_slab), _lib.nbytes(dw_slab),
                         _lib.ptr(db_slab), _lib.nbytes(db_slab), *extra, st()), "cgnn_gcn_fused_bwd")
-                dw, db = torch.empty(HID, HID, **f32), torch.empty(HID, **f32)
+                dw, db = out(4 * l, HID, HID), out(4 * l + 1, HID)
                 jobs.append((dw_slab, db_slab, grid, HID, HID, dw, db))
                 grads[4 * l], grads[4 * l + 1] = dw, db
                 bwc = bn_backward(l - 1)
                 dz, dz_prev = dz_prev, dz
-            dw0, db0 = torch.empty(HID, c.f0, **f32), torch.empty(HID, **f32)
+            dw0, db0 = out(0, HID, c.f0), out(1, HID)
             if c.p0 is not None:
                 # dW0 = dY0^T P0, db0 = sum dY0: streaming, no aggregation (fused_gcn_l0.hip)
                 g0 = lib.cgnn_l0_grid(nn_)
@@ -368,7 +378,9 @@ class FusedGCNEncode(torch.autograd.Function):
                     jb.dW[i], jb.db[i] = dw_o.data_ptr(), db_o.data_ptr()
                 _lib.check(lib.cgnn_dw_db_reduce_multi(ctypes.byref(jb), st()), "cgnn_dw_db_reduce_multi")
         ctx.c = None
-        return (None, None, *grads)
+        # (a gradient written into its armed .grad view is not handed to autograd again)
+        return (None, None, *[None if (dst[i] is not None and grads[i] is dst[i]) else grads[i]
+                              for i in range(4 * L)])
 
 
 def encode(model, batch, structure: BatchStructure) -> torch.Tensor:
@@ -384,7 +396,9 @@ def encode(model, batch, structure: BatchStructure) -> torch.Tensor:
     # features enter in the batch's own order)
     from .structure import twin_view, unpermute_record
     structure, x0, twin = twin_view(structure, batch.node_features)
+    from .ops import grad_destination
     meta = {"structure": structure, "batch_norms": list(model.batch_norms),
+            "grad_dst": [grad_destination(q) for q in params] if (model.training and torch.is_grad_enabled()) else None,
             "training": model.training, "dropout": float(model.dropout), "sync_group": sync_group,
             "rng_state": getattr(model, "rng_device_state", None), "record": model._dropout_record()}
     out = FusedGCNEncode.apply(x0, meta, *params)

@@ -738,7 +738,10 @@ class _HeadLoss(torch.autograd.Function):
     through cgnn_head_bwd_f32 on top."""
 
     @staticmethod
-    def forward(ctx, p, w1, b1, w2, b2, labels, p_drop, training, rng_word, record=None):
+    def forward(ctx, p, w1, b1, w2, b2, labels, p_drop, training, rng_word, record=None, grad_dst=None):
+        """grad_dst (optional): ONE contiguous fp32 run [W1 | b1 | W2 | b2] that receives the parameter
+        gradients directly (the adjacent ``.grad`` views of a flat data-parallel buffer, grad_destination);
+        backward then returns None for the four parameters."""
         lib = _lib.load()
         p, w1, b1, w2, b2 = (_prep(t, "head tensor") for t in (p, w1, b1, w2, b2))
         _require_device(labels, "labels")
@@ -762,11 +765,16 @@ class _HeadLoss(torch.autograd.Function):
                                               _lib.ptr(b2), _lib.ptr(labels.contiguous()), p_eff, seed,
                                               rng_word if p_eff > 0 else None, _lib.ptr(h1), _lib.ptr(fac),
                                               _lib.ptr(logits), _lib.ptr(dp), _lib.ptr(slab), _lib.nbytes(slab), sp), "cgnn_head_loss_f32")
-            _lib.check(lib.cgnn_slab_reduce_f32(_lib.ptr(slab), rows, 1, wd + 1, wd + 1, _lib.ptr(flat), wd + 1, sp),
-                       "cgnn_slab_reduce_f32")
+            if grad_dst is not None:
+                _lib.check(lib.cgnn_slab_reduce_f32_split(_lib.ptr(slab), rows, wd + 1, wd, _lib.ptr(grad_dst),
+                                                          flat.data_ptr() + 4 * wd, sp), "cgnn_slab_reduce_f32_split")
+            else:
+                _lib.check(lib.cgnn_slab_reduce_f32(_lib.ptr(slab), rows, 1, wd + 1, wd + 1, _lib.ptr(flat), wd + 1, sp),
+                           "cgnn_slab_reduce_f32")
         if record is not None:
             record["head_factor"] = fac
         ctx.save_for_backward(p, w1, w2, h1, fac, dp, flat)
+        ctx.grad_dst = grad_dst
         ctx.set_materialize_grads(False)
         return logits, flat[wd]
 
@@ -778,7 +786,13 @@ class _HeadLoss(torch.autograd.Function):
         o1, o2, o3 = h2 * h, h2 * h + h2, h2 * h + h2 + c * h2
         wd = o3 + c
         outs = None
-        if g is not None:
+        if g is not None and ctx.grad_dst is not None:
+            # the parameter gradients already sit in the caller's buffer (written by the forward launch)
+            if not _is_unit_grad(g):
+                dp = dp * g
+                ctx.grad_dst.mul_(g)
+            outs = [dp, None, None, None, None]
+        elif g is not None:
             if not _is_unit_grad(g):
                 dp, flat = dp * g, flat * g
             outs = [dp, flat[:o1].view(h2, h), flat[o1:o2], flat[o2:o3].view(c, h2), flat[o3:wd]]
@@ -796,10 +810,25 @@ class _HeadLoss(torch.autograd.Function):
                 _lib.check(lib.cgnn_slab_reduce_f32(_lib.ptr(slab), rows, 1, wd, wd, _lib.ptr(fl2), wd,
                                                     _lib.stream_ptr()), "cgnn_slab_reduce_f32")
             extra = [dp2, fl2[:o1].view(h2, h), fl2[o1:o2], fl2[o2:o3].view(c, h2), fl2[o3:]]
-            outs = extra if outs is None else [a + b for a, b in zip(outs, extra)]
+            outs = extra if outs is None else [b if a is None else a + b for a, b in zip(outs, extra)]
         if outs is None:
             outs = [None] * 5
-        return (*outs, None, None, None, None, None)
+        return (*outs, None, None, None, None, None, None)
+
+
+def grad_destination(p) -> Optional[torch.Tensor]:
+    """The tensor a hand-written backward may write ``p``'s gradient into INSTEAD of returning it to autograd
+    (it then returns None for that input): ``p.grad`` when its owner has just zeroed it and armed it for exactly
+    this (dist.GradSync.zero_grad: ``.grad`` is a view of the flat all-reduce buffer; writing there replaces
+    AccumulateGrad's in-place add, one launch per parameter).  Claiming disarms: a second op that uses the same
+    parameter gets None and goes through autograd."""
+    if not getattr(p, "_cgnn_direct", False):
+        return None
+    g = p.grad
+    p._cgnn_direct = False
+    if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape or not g.is_cuda:
+        return None
+    return g
 
 
 def head_loss_supported(classifier) -> bool:
@@ -814,7 +843,17 @@ def head_loss_supported(classifier) -> bool:
 def head_loss(classifier, pooled, labels, training: bool, rng_word=None, record=None):
     """(logits, mean cross-entropy) of head_loss_supported classifiers in one launch each way."""
     l1, _, drop, l2 = classifier
-    return _HeadLoss.apply(pooled, l1.weight, l1.bias, l2.weight, l2.bias, labels, drop.p, training, rng_word, record)
+    ps = (l1.weight, l1.bias, l2.weight, l2.bias)
+    dst = None
+    if training and all(getattr(q, "_cgnn_direct", False) for q in ps):
+        # the four gradients as ONE run of the flat buffer: only when their views are adjacent and in this order
+        views = [q.grad for q in ps]
+        if all(v is not None and v.is_contiguous() and v.dtype == torch.float32 for v in views) and all(
+                views[i].data_ptr() + 4 * views[i].numel() == views[i + 1].data_ptr() for i in range(3)):
+            for q in ps:
+                grad_destination(q)                       # claimed (disarmed)
+            dst = views[0]
+    return _HeadLoss.apply(pooled, l1.weight, l1.bias, l2.weight, l2.bias, labels, drop.p, training, rng_word, record, dst)
 
 
 def model_loss(model, loss_fn, batch) -> torch.Tensor:

@@ -646,6 +646,11 @@ int cgnn_slab_reduce_f32(const float* slab, int32_t rows, int32_t out_rows, int3
                          int32_t take_cols, float* out, int32_t ld_out, void* stream);
 int cgnn_slab_reduce_f64(const double* slab, int32_t rows, int32_t width, float* out,
                          void* stream);
+/* f32 slab [rows][width] -> out[0..split) and out_tail[0..width-split): the same fold with its result in two
+ * places -- the classifier's parameter gradients straight into a caller-owned gradient buffer (data-parallel
+ * training: the flat all-reduce buffer) and the loss column of cgnn_head_loss_f32's slab next to it. */
+int cgnn_slab_reduce_f32_split(const float* slab, int32_t rows, int32_t width, int32_t split, float* out,
+                               float* out_tail, void* stream);
 /* up to CGNN_REDUCE_MAX_JOBS of the f64 form in ONE launch (the bias gradients of every layer of a
  * backward pass: their per-block column sums are final long before the pass ends) */
 #define CGNN_REDUCE_MAX_JOBS 8

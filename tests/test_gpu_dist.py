@@ -134,3 +134,37 @@ def test_bench_self_launch_two_ranks(mode):
     assert out["config"]["graphs_per_gpu"] == (32 if scaling == "strong" else 64)
     assert out["config"]["launch"].startswith("hip-graph" if launch == "graph" else "eager")
     assert out["value"] > 0 and out["final_loss"] == out["final_loss"]      # finite, not NaN
+
+
+@pytest.mark.parametrize("kind", ["gcn64", "sage64", "gcn128"])
+def test_direct_gradient_writes_equal_autograd_accumulation(kind):
+    """dist.GradSync(direct=True): the one-node GCN encoder and the classifier + loss launch write their
+    parameter gradients straight into the zeroed views of the flat all-reduce buffer (ops.grad_destination)
+    instead of returning them to autograd, which would add each onto its view with a launch of its own.  Same
+    kernels, another destination: bit-identical to direct=False and to plain `.grad` (no GradSync); a second
+    micro-batch before the next zero_grad accumulates on top through autograd (gradient accumulation)."""
+    import connectome_gnn_amd as C
+    from connectome_gnn_amd import dist as cdist, ops
+    b1 = C.collate_graphs(C.generate_dataset(12, 84, 8, seed=4)).to("cuda")
+    b2 = C.collate_graphs(C.generate_dataset(12, 84, 8, seed=5)).to("cuda")
+    loss_fn = ops.CrossEntropyLoss()
+    got = {}
+    for mode in ("plain", "views", "direct"):
+        torch.manual_seed(1)
+        m = _make(kind).to("cuda").train()
+        sync = None if mode == "plain" else cdist.GradSync(m.parameters(), direct=(mode == "direct"))
+        if sync is not None:
+            sync.zero_grad()
+        ops.backward_unit(ops.model_loss(m, loss_fn, b1))
+        one = [p.grad.detach().clone() for p in m.parameters()]
+        if mode == "direct":
+            flat_ptr = sync.flat.data_ptr()
+            assert all(flat_ptr <= p.grad.data_ptr() < flat_ptr + 4 * sync.numel for p in m.parameters())
+            assert not any(getattr(p, "_cgnn_direct", False) for n_, p in m.named_parameters() if "classifier" in n_)
+        ops.backward_unit(ops.model_loss(m, loss_fn, b2))          # second micro-batch, no zero_grad in between
+        got[mode] = (one, [p.grad.detach().clone() for p in m.parameters()])
+    for mode in ("views", "direct"):
+        for (a, c), name in zip(zip(got[mode][0], got["plain"][0]), [n_ for n_, _ in _make(kind).named_parameters()]):
+            assert torch.equal(a, c), (mode, name)
+        for a, c in zip(got[mode][1], got["plain"][1]):
+            torch.testing.assert_close(a, c, rtol=1e-6, atol=1e-7)       # (a + b summed in another order)

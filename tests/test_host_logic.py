@@ -293,7 +293,7 @@ def test_bench_extra_configs_name_known_workloads():
     for want in ("cfg2-gcn-512x84-h64", "cfg3-sage-512x360-h128", "cfg5-gcn-64x1000-h256-fp16",
                  "shard512-gcn-512x360-h64"):
         assert want in labels
-    assert all(key in bench.WORKLOADS and launch in ("eager", "graph", "auto", "trainer", "plain", "demo") for _, key, launch, _ in bench.EXTRA_CONFIGS)
+    assert all(key in bench.WORKLOADS and launch in ("eager", "graph", "graph-dp", "auto", "trainer", "plain", "demo") for _, key, launch, _ in bench.EXTRA_CONFIGS)
 
 
 def test_bench_rank_bookkeeping_for_eight_gpus():
