@@ -368,7 +368,8 @@ def inference_record(name: str, dev, label: str, dataset=None) -> dict:
     torch.manual_seed(42)
     cls = C.GCNConnectome if wl["model"] == "gcn" else C.GraphSAGEConnectome
     model = cls(5, hidden, 2, 3, 0.3).to(dev)
-    tr = C.Trainer(model, Adam(model.parameters(), lr=1e-3), device=str(dev), graph=False)
+    use_graph = bsz < 2048          # (as --launch auto: small batches are host-bound when launched eagerly)
+    tr = C.Trainer(model, Adam(model.parameters(), lr=1e-3), device=str(dev), graph=use_graph)
     ld = ResidentDataLoader(ds, batch_size=bsz, shuffle=False, structure_cache=True)
     for _ in range(2):
         tr.evaluate(ld)
@@ -379,7 +380,8 @@ def inference_record(name: str, dev, label: str, dataset=None) -> dict:
         ev = tr.evaluate(ld)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return {"workload": label, "launch": "Trainer.evaluate over ResidentDataLoader(structure_cache=True), eager",
+    return {"workload": label, "launch": "Trainer.evaluate over ResidentDataLoader(structure_cache=True), "
+                                         + ("hip-graph replay (graphed.GraphedEvalStep)" if use_graph else "eager"),
             "dtype": "f32", "graphs_per_gpu": bsz, "impl": getattr(model, "impl_used", None),
             "ms_per_batch": dt / (reps * len(ld)) * 1e3, "value": reps * ds.num_subjects / dt, "unit": "graphs/s",
             "subjects": ds.num_subjects, "accuracy": ev["accuracy"]}

@@ -271,3 +271,66 @@ class GraphedResidentStep(GraphedTrainStep):
         out = self.tally.clone()        # (run_epoch resets the tally itself; a second take reads zero only after that)
         self.tally.zero_()
         return out.reshape(())
+
+
+class GraphedEvalStep:
+    """One captured EVALUATION step -- eval-mode forward (running BatchNorm statistics, no dropout), batch-mean
+    loss and hit count (reference train.py:56-74) -- for every batch of a given size drawn from a
+    device-resident dataset with a per-subject structure cache.  As in GraphedResidentStep the batch is
+    assembled inside the graph from a window of a device id buffer at a device cursor, and the step itself
+    adds loss x graphs and the hits to device tallies and advances the cursor: an evaluation pass is one copy
+    of the ids, one reset, n replays and one read-back of two numbers.  Parameters and running statistics are
+    read at replay time (they live at fixed addresses), so the same graph serves every epoch of training."""
+
+    def __init__(self, model: torch.nn.Module, loss_fn: Callable, first_batch):
+        from .structure_cache import ResidentBatch
+        from . import _lib
+        if model.training:
+            raise ValueError("GraphedEvalStep captures an eval-mode forward: call model.eval() first")
+        cache = first_batch._cache
+        dev = cache.dataset.x.device
+        b = int(first_batch._ids.numel())
+        self._b, self._lib, self.model = b, _lib, model
+        self.order_buf = torch.zeros(max(int(cache.dataset.num_subjects), b), dtype=torch.long, device=dev)
+        self.order_buf[:b].copy_(first_batch._ids)
+        self._state = torch.zeros(3, dtype=torch.long, device=dev)          # cursor | hits | loss tally (fp32)
+        self.cursor, self.hits = self._state[:1], self._state[1:2]
+        self.tally = self._state[2:].view(torch.float32)[:1]
+        ids_buf = self.order_buf[:b]
+        cache.static(b)
+        make = lambda: ResidentBatch(cache, ids_buf, ids_offset=self.cursor)
+
+        def body():
+            batch = make()
+            logits = model(batch)
+            loss = loss_fn(logits, batch.labels)
+            self.hits.add_((logits.argmax(dim=1) == batch.labels).sum())
+            with _lib.device_guard(dev):
+                _lib.check(_lib.load().cgnn_epoch_advance(_lib.ptr(self.cursor), b, _lib.ptr(loss), float(b),
+                                                          _lib.ptr(self.tally), _lib.stream_ptr(dev)), "cgnn_epoch_advance")
+
+        with torch.no_grad():
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                body()                                    # warm-up off the capture stream (builds nothing new)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            self._state.zero_()
+            self.graph = torch.cuda.CUDAGraph()
+            import torch.distributed as dist
+            mode = {"capture_error_mode": "thread_local"} if dist.is_available() and dist.is_initialized() else {}
+            with torch.cuda.graph(self.graph, **mode):
+                body()
+        self._state.zero_()
+
+    def run(self, ids: torch.Tensor, steps: int):
+        """``steps`` consecutive batches whose subject ids are ``ids`` (steps x batch_size, device or pinned
+        host): -> (sum of loss x graphs, hits) as device scalars (clones: the next run resets the tallies)."""
+        n = steps * self._b
+        if int(ids.numel()) != n or n > int(self.order_buf.numel()):
+            raise ValueError("run: ids must hold steps x batch_size subject ids (at most the dataset's size)")
+        self.order_buf[:n].copy_(ids, non_blocking=True)
+        self._state.zero_()
+        for _ in range(steps):
+            self.graph.replay()
+        return self.tally.clone().reshape(()), self.hits.clone().reshape(())

@@ -394,12 +394,66 @@ class Trainer:
         return loss_sum / max(seen, 1)
 
     # ---------------------------------------------------------------------------- evaluation
+    def _replay_eval(self, loader, losses: "_DeviceTally", hits: "_DeviceTally") -> bool:
+        """A whole evaluation pass over a ``ResidentDataLoader(structure_cache=...)`` from captured steps
+        (graphed.GraphedEvalStep, one per batch size; captured on first use).  False = not applicable: the
+        caller iterates eagerly."""
+        from .resident import ResidentDataLoader
+        cache = getattr(loader, "structure_cache", None)
+        if not (self.graph and isinstance(loader, ResidentDataLoader) and cache is not None
+                and not loader.cache_batches) or self._data_parallel():
+            return False
+        from .graphed import GraphedEvalStep
+        from .structure_cache import ResidentBatch
+        chunks = list(loader._chunks())
+        i = 0
+        while i < len(chunks):
+            size = int(chunks[i].numel())
+            j = i
+            while j < len(chunks) and int(chunks[j].numel()) == size:
+                j += 1
+            key = ("eval", id(cache), size)
+            step = self._graphs.get(key)
+            if step is None:
+                if len(self._graphs) >= self.max_graphs:
+                    step = False
+                else:
+                    try:
+                        step = GraphedEvalStep(self.model, self.loss_fn, ResidentBatch(cache, chunks[i]))
+                    except Exception as exc:              # noqa: BLE001 -- evaluation falls back to eager launches
+                        if not self._graph_auto:
+                            raise
+                        import warnings
+                        warnings.warn(f"Trainer: evaluation step not captured ({exc!r}); eager launches")
+                        torch.cuda.synchronize()
+                        step = False
+                    self._graphs[key] = step
+            run = chunks[i:j]
+            if step is False:
+                for c in run:
+                    b = ResidentBatch(cache, c)
+                    logits = self.model(b)
+                    losses.add(self.loss_fn(logits, b.labels) * size, size)
+                    hits.add((logits.argmax(dim=1) == b.labels).sum())
+            else:
+                ids = run[0] if len(run) == 1 else _joined(run)
+                loss_sum, hit_sum = step.run(ids.to(step.order_buf.device), len(run))
+                losses.add(loss_sum, size * len(run))
+                hits.add(hit_sum)
+            i = j
+        return True
+
     @torch.no_grad()
     def evaluate(self, loader) -> dict:
         """Accuracy and mean loss (reference train.py:56-74)."""
         self.model.eval()
         losses, hits = _DeviceTally(), _DeviceTally()
         loader = self._resident_loader(loader, False) or loader
+        if self._replay_eval(loader, losses, hits):
+            (loss_sum, hit_sum), seen = self._global_tallies(loader, losses, hits)
+            correct = int(round(hit_sum))
+            return {"accuracy": correct / max(seen, 1), "loss": loss_sum / max(seen, 1),
+                    "correct": correct, "total": seen}
         for batch in loader:
             batch = batch.to(self.device)
             graphs = batch.num_graphs

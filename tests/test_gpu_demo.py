@@ -272,13 +272,16 @@ def test_the_unchanged_reference_script_is_served_from_the_device(kind, hidden):
         torch.testing.assert_close(torch.tensor(hist["default"][key]), torch.tensor(hist["host"][key]),
                                    rtol=2e-4, atol=2e-6, msg=lambda s: f"{key}: {s}")
     assert evals["default"]["total"] == evals["host"]["total"] == 16
+    assert evals["default"]["correct"] == evals["host"]["correct"]
+    assert abs(evals["default"]["loss"] - evals["host"]["loss"]) <= 2e-4 * abs(evals["host"]["loss"]) + 2e-6
     assert torch.equal(rng_after["default"], rng_after["host"])      # the same randperm calls, nothing else drawn
     tr = trainers["default"]
     assert len(tr._resident) == 2 and all(v[2] is not None for v in tr._resident.values())
     served = hidden == 64
     assert tr.graph is served
     if served:
-        assert sorted(k[2] for k in tr._graphs) == [8, 16]           # one captured step per batch size
+        assert sorted(k[2] for k in tr._graphs if k[0] == "resident") == [8, 16]     # one captured step per batch size
+        assert sorted(k[2] for k in tr._graphs if k[0] == "eval") == [16]            # ... and the evaluation passes replay too
         assert all(g["capturable"] for g in tr.optimizer.param_groups)
     else:
         assert not tr._graphs
