@@ -51,7 +51,7 @@ def eligible(model, batch, structure: BatchStructure) -> Optional[str]:
 
 class _Saved:
     __slots__ = ("s", "ell", "norm", "xs", "ys", "coefs", "masks", "p", "training", "ws", "p0", "padded",
-                 "sync_group", "count_block", "fsum", "tiled", "band")
+                 "sync_group", "count_block", "fsum", "tiled", "band", "grad_dst")
 
 
 class GcnWideEncode(torch.autograd.Function):
@@ -84,6 +84,7 @@ class GcnWideEncode(torch.autograd.Function):
         sv.xs, sv.ys, sv.coefs, sv.masks, sv.ws = [], [], [], [], []
         sv.p0, sv.padded = None, False
         sv.sync_group, sv.count_block = cfg.get("sync_group"), None
+        sv.grad_dst = cfg.get("grad_dst") or [None] * len(params)
         nrm = sv.norm
         with _lib.device_guard(dev):
             if rng is not None and p > 0:
@@ -160,6 +161,7 @@ class GcnWideEncode(torch.autograd.Function):
         dP = dP.contiguous()
         nrm = sv.norm
         grads: List[Optional[torch.Tensor]] = [None] * (4 * L)
+        dst = sv.grad_dst
         with _lib.device_guard(dev):
             dx = None                      # last layer: gradient rebuilt from dP inside the kernels
             deferred = _lib.DeferredReduce()
@@ -167,17 +169,19 @@ class GcnWideEncode(torch.autograd.Function):
             for li in range(L - 1, -1, -1):
                 x, y, coef, mask, w = sv.xs[li], sv.ys[li], sv.coefs[li], sv.masks[li], sv.ws[li]
                 hid, fin = w.shape[0], x.shape[1]
+                bn_out = (dst[4 * li + 2], dst[4 * li + 3])
                 pool = (_lib.ptr(dP), _lib.ptr(s.node_graph), _lib.ptr(s.gptr)) if li == L - 1 \
                     else (None, None, None)
                 if li == L - 1 and sv.fsum is not None:
-                    dgamma, dbeta, bwc = pooled_bn_backward_coefs(lib, dP, sv.fsum, s, hid, n_nodes, sv.training, st(), dev)
+                    dgamma, dbeta, bwc = pooled_bn_backward_coefs(lib, dP, sv.fsum, s, hid, n_nodes, sv.training, st(), dev,
+                                                                  bn_out)
                 else:
                     slab = torch.empty(rows, 2 * hid, dtype=torch.float64, device=dev)
                     _lib.check(lib.cgnn_bn_act_bwd_stats(_lib.ptr(dx), _lib.ptr(y), _lib.ptr(mask),
                                                          _lib.ptr(coef), 1, sv.p, n_nodes, hid,
                                                          _lib.ptr(slab), _lib.nbytes(slab), *pool, st()), "cgnn_bn_act_bwd_stats")
                     dgamma, dbeta, bwc = bn_backward_coefs(lib, slab, rows, hid, n_nodes, sv.training,
-                                                           sv.sync_group, sv.count_block, st(), dev)
+                                                           sv.sync_group, sv.count_block, st(), dev, bn_out)
                 cs_rows = int(lib.cgnn_bn_act_apply_blocks(n_nodes, hid))
                 cs_slab = torch.empty(cs_rows, hid, dtype=torch.float64, device=dev)
                 dy = torch.empty_like(y)
@@ -185,7 +189,7 @@ class GcnWideEncode(torch.autograd.Function):
                                                      _lib.ptr(coef), _lib.ptr(bwc), 1, sv.p, 0,
                                                      _lib.ptr(cs_slab), _lib.nbytes(cs_slab), _lib.ptr(dy), n_nodes, hid,
                                                      *pool, st()), "cgnn_bn_act_bwd_apply")
-                db = _f32(dev, hid)
+                db = dst[4 * li + 1] if dst[4 * li + 1] is not None else _f32(dev, hid)
                 deferred.add(cs_slab, cs_rows, hid, db)       # all layers' db: one launch at the end
                 if li == 0:
                     # Y0 = P0 W0^T + b  ->  dW0 = dY0^T P0 (no aggregation in the backward)
@@ -194,7 +198,7 @@ class GcnWideEncode(torch.autograd.Function):
                         ops.linear_bwd_weight_raw(dy, sv.p0, dwp, 0)
                         dw = dwp[:, :fin].contiguous()
                     else:
-                        dw = torch.empty_like(w)
+                        dw = dst[0] if dst[0] is not None else torch.empty_like(w)
                         ops.linear_bwd_weight_raw(dy, sv.p0, dw, 0)
                     grads[0:4] = [dw, db, dgamma, dbeta]
                     break
@@ -203,13 +207,13 @@ class GcnWideEncode(torch.autograd.Function):
                 else:
                     dt = ops.aggregate_raw(s.rowptr_src, s.col_src, nrm.coef_src, nrm.selfc, None, None, dy,
                                            band=sv.band[1])
-                dw = torch.empty_like(w)
+                dw = dst[4 * li] if dst[4 * li] is not None else torch.empty_like(w)
                 ops.linear_bwd_weight_raw(dt, x, dw, 0)
                 grads[4 * li:4 * li + 4] = [dw, db, dgamma, dbeta]
                 dx = ops.linear_bwd_input_raw(dt, w, 0, fin)
             deferred.flush(st())
         ctx.sv = None
-        return (None, None, *grads)
+        return (None, None, *ops.undelivered(grads, dst))
 
 
 def encode(model, batch, structure: BatchStructure) -> torch.Tensor:
@@ -220,7 +224,8 @@ def encode(model, batch, structure: BatchStructure) -> torch.Tensor:
     structure, x0, twin = twin_view(structure, batch.node_features)
     cfg = {"structure": structure, "batch_norms": list(model.batch_norms), "training": model.training,
            "dropout": float(model.dropout), "rng_state": getattr(model, "rng_device_state", None),
-           "sync_group": sync_group_of(model), "record": model._dropout_record()}
+           "sync_group": sync_group_of(model), "record": model._dropout_record(),
+           "grad_dst": ops.claim_destinations(params, model.training)}
     out = GcnWideEncode.apply(x0, cfg, *params)
     unpermute_record(twin, cfg.get("record"))
     return out

@@ -831,6 +831,20 @@ def grad_destination(p) -> Optional[torch.Tensor]:
     return g
 
 
+def claim_destinations(params, training: bool):
+    """grad_destination of every parameter of a one-node encoder (None entries = through autograd), or
+    all-None outside a training forward."""
+    if not (training and torch.is_grad_enabled()):
+        return [None] * len(params)
+    return [grad_destination(q) for q in params]
+
+
+def undelivered(grads, dst):
+    """What a hand-written backward returns to autograd: None where the gradient was written into its
+    destination (grads[i] IS dst[i]), the gradient itself elsewhere."""
+    return [None if (d is not None and g is d) else g for g, d in zip(grads, dst)]
+
+
 def head_loss_supported(classifier) -> bool:
     """head_supported and one of the register-tiled shapes of cgnn_head_loss_f32 (two classes,
     hidden = 2 x the classifier's inner width in {32, 64, 128, 256}) -- the reference's default head."""

@@ -49,7 +49,7 @@ def eligible(model, batch, structure: BatchStructure) -> Optional[str]:
 
 class _Saved:
     __slots__ = ("s", "ell", "norm", "xs", "aggs", "zs", "coefs", "masks", "p", "training", "ws", "xa0",
-                 "sync_group", "count_block", "fsum", "tiled", "band")
+                 "sync_group", "count_block", "fsum", "tiled", "band", "grad_dst")
 
 
 PAD_K = 32          # layer 0: [x0 | agg(x0) | 0] packed to one 32-wide panel
@@ -123,12 +123,15 @@ def bn_forward_coef(lib, slab, srows, hid, n_nodes, training, gamma, beta, bn, s
     return coef, block
 
 
-def bn_backward_coefs(lib, slab, rows, hid, n_nodes, training, sync_group, count_block, sp, dev):
+def bn_backward_coefs(lib, slab, rows, hid, n_nodes, training, sync_group, count_block, sp, dev, out=(None, None)):
     """(dgamma, dbeta, bwc = c1|c2) from the backward statistics slab.  With a sync group the sums
     are all-reduced for c1|c2 while dgamma/dbeta stay the rank-local sums (the gradient all-reduce
     averages them), exactly like torch's SyncBatchNorm."""
     import torch.distributed as dist
-    dgamma, dbeta, bwc = _f32(dev, hid), _f32(dev, hid), _f32(dev, 2 * hid)
+    direct = sync_group is None or count_block is None      # (out: armed .grad views, ops.grad_destination)
+    dgamma = out[0] if (direct and out[0] is not None) else _f32(dev, hid)
+    dbeta = out[1] if (direct and out[1] is not None) else _f32(dev, hid)
+    bwc = _f32(dev, 2 * hid)
     if sync_group is None or count_block is None:
         _lib.check(lib.cgnn_bn_act_bwd_finalize(_lib.ptr(slab), rows, hid, float(max(n_nodes, 1)), None,
                                                 int(not training), _lib.ptr(dgamma), _lib.ptr(dbeta),
@@ -144,11 +147,13 @@ def bn_backward_coefs(lib, slab, rows, hid, n_nodes, training, sync_group, count
     return local_dgamma, local_dbeta, bwc
 
 
-def pooled_bn_backward_coefs(lib, dP, fsum, s, hid, n_nodes, training, sp, dev):
+def pooled_bn_backward_coefs(lib, dP, fsum, s, hid, n_nodes, training, sp, dev, out=(None, None)):
     """(dgamma, dbeta, bwc) of the LAST layer from the factor sums its pooled forward pass left
     (cgnn_bn_act_pool_fwd's Fsum): the readout's gradient is constant per graph, so no pass over the
     layer's [Nn, H] output is needed for the BatchNorm-backward sums."""
-    dgamma, dbeta, bwc = _f32(dev, hid), _f32(dev, hid), _f32(dev, 2 * hid)
+    dgamma = out[0] if out[0] is not None else _f32(dev, hid)
+    dbeta = out[1] if out[1] is not None else _f32(dev, hid)
+    bwc = _f32(dev, 2 * hid)
     _lib.check(lib.cgnn_bn_act_pool_bwd_finalize(_lib.ptr(dP), _lib.ptr(fsum), _lib.ptr(s.gptr), s.num_graphs, hid,
                                                  float(max(n_nodes, 1)), int(not training), _lib.ptr(dgamma),
                                                  _lib.ptr(dbeta), _lib.ptr(bwc), sp),
@@ -203,6 +208,7 @@ class SageEncode(torch.autograd.Function):
         sv.xs, sv.aggs, sv.zs, sv.coefs, sv.masks, sv.ws = [], [], [], [], [], []
         sv.xa0 = None
         sv.sync_group, sv.count_block = cfg.get("sync_group"), None
+        sv.grad_dst = cfg.get("grad_dst") or [None] * len(params)
         with _lib.device_guard(dev):
             if rng is not None and p > 0:
                 _lib.check(lib.cgnn_rng_advance(_lib.ptr(rng), L + 1, st()), "cgnn_rng_advance")
@@ -295,6 +301,7 @@ class SageEncode(torch.autograd.Function):
         n_nodes = s.num_nodes
         dP = dP.contiguous()
         grads: List[Optional[torch.Tensor]] = [None] * (4 * L)
+        dst = sv.grad_dst
         with _lib.device_guard(dev):
             dx = None                      # last layer: gradient rebuilt from dP inside the kernels
             deferred = _lib.DeferredReduce()
@@ -303,18 +310,20 @@ class SageEncode(torch.autograd.Function):
                 x, agg, z, coef, mask, w = (sv.xs[li], sv.aggs[li], sv.zs[li], sv.coefs[li],
                                             sv.masks[li], sv.ws[li])
                 hid, fin = w.shape[0], x.shape[1]
+                bn_out = (dst[4 * li + 2], dst[4 * li + 3])
                 # ---- BatchNorm + dropout backward, ReLU' of the layer and db in two passes
                 pool = (_lib.ptr(dP), _lib.ptr(s.node_graph), _lib.ptr(s.gptr)) if li == L - 1 \
                     else (None, None, None)
                 if li == L - 1 and sv.fsum is not None:
-                    dgamma, dbeta, bwc = pooled_bn_backward_coefs(lib, dP, sv.fsum, s, hid, n_nodes, sv.training, st(), dev)
+                    dgamma, dbeta, bwc = pooled_bn_backward_coefs(lib, dP, sv.fsum, s, hid, n_nodes, sv.training, st(), dev,
+                                                                  bn_out)
                 else:
                     slab = torch.empty(rows, 2 * hid, dtype=torch.float64, device=dev)
                     _lib.check(lib.cgnn_bn_act_bwd_stats(_lib.ptr(dx), _lib.ptr(z), _lib.ptr(mask),
                                                          _lib.ptr(coef), 0, sv.p, n_nodes, hid,
                                                          _lib.ptr(slab), _lib.nbytes(slab), *pool, st()), "cgnn_bn_act_bwd_stats")
                     dgamma, dbeta, bwc = bn_backward_coefs(lib, slab, rows, hid, n_nodes, sv.training,
-                                                           sv.sync_group, sv.count_block, st(), dev)
+                                                           sv.sync_group, sv.count_block, st(), dev, bn_out)
                 cs_rows = int(lib.cgnn_bn_act_apply_blocks(n_nodes, hid))
                 cs_slab = torch.empty(cs_rows, hid, dtype=torch.float64, device=dev)
                 dpre = torch.empty_like(z)
@@ -322,7 +331,7 @@ class SageEncode(torch.autograd.Function):
                                                      _lib.ptr(coef), _lib.ptr(bwc), 0, sv.p, 1,
                                                      _lib.ptr(cs_slab), _lib.nbytes(cs_slab), _lib.ptr(dpre), n_nodes, hid,
                                                      *pool, st()), "cgnn_bn_act_bwd_apply")
-                db = _f32(dev, hid)
+                db = dst[4 * li + 1] if dst[4 * li + 1] is not None else _f32(dev, hid)
                 deferred.add(cs_slab, cs_rows, hid, db)       # all layers' db: one launch at the end
                 # ---- dW = dPre^T [X | A]
                 if li == 0 and sv.xa0 is not None:
@@ -330,7 +339,7 @@ class SageEncode(torch.autograd.Function):
                     ops.linear_bwd_weight_raw(dpre, sv.xa0, dwp, 0)
                     grads[0:4] = [dwp[:, :2 * fin].contiguous(), db, dgamma, dbeta]
                     break
-                dw = torch.empty_like(w)
+                dw = dst[4 * li] if dst[4 * li] is not None else torch.empty_like(w)
                 ops.linear_bwd_weight2_raw(dpre, x, agg, dw)
                 grads[4 * li:4 * li + 4] = [dw, db, dgamma, dbeta]
                 if li == 0:
@@ -345,7 +354,7 @@ class SageEncode(torch.autograd.Function):
                                            dcat[:, fin:], band=sv.band[1], yadd=dcat[:, :fin])
             deferred.flush(st())
         ctx.sv = None
-        return (None, None, *grads)
+        return (None, None, *ops.undelivered(grads, dst))
 
 
 def encode(model, batch, structure: BatchStructure) -> torch.Tensor:
@@ -356,7 +365,8 @@ def encode(model, batch, structure: BatchStructure) -> torch.Tensor:
     structure, x0, twin = twin_view(structure, batch.node_features)
     cfg = {"structure": structure, "batch_norms": list(model.batch_norms), "training": model.training,
            "dropout": float(model.dropout), "rng_state": getattr(model, "rng_device_state", None),
-           "sync_group": sync_group_of(model), "record": model._dropout_record()}
+           "sync_group": sync_group_of(model), "record": model._dropout_record(),
+           "grad_dst": ops.claim_destinations(params, model.training)}
     out = SageEncode.apply(x0, cfg, *params)
     unpermute_record(twin, cfg.get("record"))
     return out

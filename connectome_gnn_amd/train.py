@@ -182,7 +182,17 @@ class Trainer:
                     or lab.dim() != 0 or lab.dtype != torch.long or g.node_features.dtype != torch.float32 \
                     or g.edge_weight.dtype != torch.float32 or g.edge_index.dtype != torch.long:
                 return None                  # irregular (or unlabelled) data: the host loader stays
-        ds = PackedDataset.from_graphs(list(data)).to(dev)
+        packed = PackedDataset.from_graphs(list(data))
+        # torch's cross-entropy raises on a target outside [0, C) (the reference's behaviour, train.py:49); the
+        # one-launch loss kernel cannot raise and turns it into a NaN loss, so the check is made here, once,
+        # on the host, where the labels still are
+        head = getattr(self.model, "classifier", None)
+        classes = getattr(head[-1], "out_features", None) if isinstance(head, nn.Sequential) and len(head) else None
+        if classes is not None and packed.labels.numel():
+            bad = (packed.labels != -100) & ((packed.labels < 0) | (packed.labels >= classes))
+            if bool(bad.any()):
+                raise IndexError(f"Target {int(packed.labels[bad][0])} is out of bounds (labels must lie in [0, {classes}))")
+        ds = packed.to(dev)
         rl = ResidentDataLoader(ds, batch_size=loader.batch_size, shuffle=bool(loader.shuffle), rank=loader.rank,
                                 world_size=loader.world_size)
         if self._subject_cache_serves(ds, loader.batch_size):

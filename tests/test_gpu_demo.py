@@ -296,3 +296,16 @@ def test_irregular_datasets_keep_the_host_loader():
     ld = C.ConnectomeDataLoader(graphs, batch_size=8, shuffle=True)
     loss = tr.train_epoch(ld)
     assert loss == loss and list(tr._resident.values())[0][2] is None and not tr.graph
+
+
+def test_out_of_range_label_raises_when_the_dataset_is_packed():
+    """torch's cross-entropy raises on a target outside [0, C) (reference train.py:49); the packed path checks
+    the labels once on the host instead of producing a NaN loss on the device."""
+    import connectome_gnn_amd as C
+    graphs = C.generate_dataset(8, 20, 4, seed=1)
+    graphs[3] = C.ConnectomeGraph(graphs[3].node_features, graphs[3].edge_index, graphs[3].edge_weight,
+                                  torch.tensor(2, dtype=torch.long))
+    m = C.GCNConnectome(5, 64)
+    tr = C.Trainer(m, torch.optim.Adam(m.parameters(), lr=1e-3), device="cuda")
+    with pytest.raises(IndexError, match="out of bounds"):
+        tr.train_epoch(C.ConnectomeDataLoader(graphs, batch_size=8, shuffle=False))
