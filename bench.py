@@ -110,15 +110,16 @@ def cpu_baseline(model: str, n: int, k: int, hidden: int, budget_s: float = 20.0
 # kernel-name PREFIXES whose launches make up the dominant kernel).  Prefixes, not full template
 # instantiations: a template parameter added to a kernel must not silently null the field.
 PMC_FILES = {
-    "cfg4-headline-gcn-4096x360-h64": (("r03_headline_pmc_traffic.json", "r02_headline_pmc_traffic.json"), 4096,
+    "cfg4-headline-gcn-4096x360-h64": (("r04_headline_pmc_traffic.json", "r03_headline_pmc_traffic.json", "r02_headline_pmc_traffic.json"), 4096,
                                        ("k_gcn_bwd<",)),
-    "cfg3-sage-512x360-h128": (("r03_cfg3_pmc_traffic.json", "r02_cfg3_pmc_traffic.json"), 512, ("k_agg_tiled",)),
-    "cfg2-gcn-512x84-h64": (("r03_cfg2_pmc_traffic.json", "r02_cfg2_pmc_traffic.json"), 512, ("k_gcn_bwd<",)),
-    "cfg5-gcn-64x1000-h256-fp16": (("r03_cfg5_fp16_pmc_traffic.json", "r02_cfg5_fp16_pmc_traffic.json"), 64,
+    "cfg3-sage-512x360-h128": (("r04_cfg3_pmc_traffic.json", "r03_cfg3_pmc_traffic.json", "r02_cfg3_pmc_traffic.json"), 512, ("k_agg_tiled",)),
+    "cfg2-gcn-512x84-h64": (("r04_cfg2_pmc_traffic.json", "r03_cfg2_pmc_traffic.json", "r02_cfg2_pmc_traffic.json"), 512, ("k_gcn_bwd<",)),
+    "cfg5-gcn-64x1000-h256-fp16": (("r04_cfg5_fp16_pmc_traffic.json", "r03_cfg5_fp16_pmc_traffic.json", "r02_cfg5_fp16_pmc_traffic.json"), 64,
                                    ("k_dense_agg",)),
-    "shard512-gcn-512x360-h64": (("r03_shard512_pmc_traffic.json",), 512, ("k_gcn_bwd<",)),
+    "shard512-gcn-512x360-h64": (("r04_shard512_pmc_traffic.json", "r03_shard512_pmc_traffic.json"), 512, ("k_gcn_bwd<",)),
+    "shard512-dp-plumbing-gcn-512x360-h64": (("r04_shard512_pmc_traffic.json", "r03_shard512_pmc_traffic.json"), 512, ("k_gcn_bwd<",)),
     # one aggregation = two launches (dense fragments on the matrix cores, then the remaining edges): SUMMED
-    "cfg5-gcn-64x1000-h256-fp32": (("r03_cfg5_fp32_pmc_traffic.json",), 64, (("k_band_agg",), ("k_agg_wave_row",))),
+    "cfg5-gcn-64x1000-h256-fp32": (("r04_cfg5_fp32_pmc_traffic.json", "r03_cfg5_fp32_pmc_traffic.json"), 64, (("k_band_agg",), ("k_agg_wave_row",))),
 }
 
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # copy the judged summaries of a tools/measure_all.sh sweep (gpurun_out/$TAG/) into profiles/$TAG_*
 cd "$(dirname "$0")/.."
-TAG=${TAG:-r03}
+TAG=${TAG:-r04}
 S=gpurun_out/$TAG; P=profiles
 cp $S/headline_bench.json $P/${TAG}_bench_all_configs.json
 cp $S/prof_headline/headline_kernel_stats.csv $P/${TAG}_headline_kernel_stats.csv

@@ -1,11 +1,11 @@
 #!/bin/bash
 # One-call measurement sweep on the GPU box (run from the repo root via gpurun).  Writes under
-# gpurun_out/$TAG/ (TAG = r03 by default); tools/collect_profiles.sh copies the judged summaries
+# gpurun_out/$TAG/ (TAG = r04 by default); tools/collect_profiles.sh copies the judged summaries
 # to profiles/ afterwards.  Kernel-trace and --pmc passes are separate runs (FETCH_SIZE and
 # WRITE_SIZE in passes of their own), as MI355X_MICROARCH.md prescribes.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${TAG:-r03}
+TAG=${TAG:-r04}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
