@@ -43,6 +43,21 @@ class CgnnL0Src(ctypes.Structure):
 
 LP = ctypes.POINTER(CgnnL0Src)
 
+BN_ACC_BYTES = 2112
+
+
+class CgnnBnTail(ctypes.Structure):
+    """Mirror of `struct cgnn_bn_tail` (include/cgnn.h): a layer's BatchNorm finalisation run by the last
+    workgroup of the kernel that produces its sums (csrc/bn_tail.h) instead of by a launch of its own."""
+    _fields_ = [("acc", c_void_p), ("count", ctypes.c_double), ("mode", c_int32), ("zero_coef", c_int32),
+                ("gamma", c_void_p), ("beta", c_void_p), ("running_mean", c_void_p), ("running_var", c_void_p),
+                ("momentum", ctypes.c_float), ("eps", ctypes.c_float), ("num_batches_tracked", c_void_p),
+                ("bn_out", c_void_p), ("rng_state", c_void_p), ("rng_n", c_int32), ("reserved", c_int32),
+                ("dgamma", c_void_p), ("dbeta", c_void_p), ("bwc", c_void_p)]
+
+
+BP = ctypes.POINTER(CgnnBnTail)
+
 DW_MAX_JOBS = 8
 
 
@@ -178,14 +193,14 @@ PROTOTYPES = {
     "cgnn_set_fused_grid": (c_int, [I32]),
     "cgnn_gcn_fused_fwd_first": (c_int, [TP, P, I32, P, P, P, P, I64, P]),
     "cgnn_rng_advance": (c_int, [P, I32, P]),
-    "cgnn_gcn_fused_fwd": (c_int, [TP, P, LP, P, F32, U64, P, P, P, P, P, P, I64, P]),
+    "cgnn_gcn_fused_fwd": (c_int, [TP, P, LP, P, F32, U64, P, P, P, P, P, P, I64, BP, P]),
     "cgnn_bn_reduce": (c_int, [P, I32, I32, P, P]),
     "cgnn_bn_finalize": (c_int, [P, F64, P, P, P, P, P, F32, F32, I32, P, P, P]),
     "cgnn_gcn_fused_pool_fwd": (c_int, [P, P, F32, U64, P, P, P, I32, P, P, P, P]),
     "cgnn_gcn_fused_pool_bwd_sums": (c_int, [P, P, P, P, I32, P, I64, P]),
     "cgnn_gcn_fused_pool_bwd": (c_int, [P, P, P, F32, P, P, I32, P, P, I64, P]),
     "cgnn_bn_bwd_finalize": (c_int, [P, F64, P, I32, P, P, P, P]),
-    "cgnn_gcn_fused_bwd": (c_int, [TP, P, P, P, P, P, LP, P, F32, P, P, P, P, I64, P, I64, P, I64, P, P, P, P, P]),
+    "cgnn_gcn_fused_bwd": (c_int, [TP, P, P, P, P, P, LP, P, F32, P, P, P, P, I64, P, I64, P, I64, P, P, P, P, BP, P]),
     "cgnn_gcn_fused_bwd_first": (c_int, [TP, P, P, P, P, P, I32, P, I64, P, I64, F32, P, P, P, P, P]),
     "cgnn_bn_stats_finalize": (c_int, [P, I32, F64, P, P, P, P, F32, F32, P, P, P]),
     "cgnn_bn_stats_finalize_rng": (c_int, [P, I32, F64, P, P, P, P, F32, F32, P, P, P, I32, P, P]),
@@ -196,7 +211,7 @@ PROTOTYPES = {
     "cgnn_adam_step": (c_int, [ctypes.POINTER(CgnnAdamJobs), P, P, I32, F64, F64, F64, F64, F64, P]),
     "cgnn_l0_grid": (c_int, [c_int64]),
     "cgnn_gcn_l0_center": (c_int, [TP, P, I32, P, P]),
-    "cgnn_gcn_l0_fwd": (c_int, [TP, P, I32, P, P, P, P, P, I64, P, P, P, P]),
+    "cgnn_gcn_l0_fwd": (c_int, [TP, P, I32, P, P, P, P, P, I64, P, P, P, BP, P]),
     "cgnn_gcn_l0_bwd": (c_int, [P, P, LP, P, P, P, I64, P, I64, P, I64, P, P]),
     "cgnn_slab_reduce_f32": (c_int, [P, I32, I32, I32, I32, P, I32, P]),
     "cgnn_slab_reduce_f64": (c_int, [P, I32, I32, P, P]),

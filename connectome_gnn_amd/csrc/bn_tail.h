@@ -1,0 +1,149 @@
+// bn_tail.h -- batch-wide BatchNorm sums WITHOUT a launch of their own (round 4).
+//
+// Every tile kernel of the per-tile GCN path ends with per-workgroup fp64 partials of 128 column sums
+// (sum y | sum y^2 in the forward pass, sum dz | sum dz*xhat in the backward pass).  Rounds 1-3 wrote them
+// to a [workgroups][128] slab and a separate one-block-per-channel kernel folded the slab and turned the
+// sums into the layer's coefficient block: five launches of 4-7 us per training step that do nothing but
+// wait for one load round trip, 24 us of a 0.31 ms step at 512 graphs per rank.
+//
+// Here the partials go into a 128-word accumulator with 64-bit ATOMIC adds and the workgroup that arrives
+// last (an arrival counter) finalises the layer in the producer's own tail:
+//
+//   * the sums are added as 128-bit FIXED-POINT integers (64 integer + 64 fractional bits, two 64-bit atomic
+//     adds with a carry): integer addition is associative, so the result does not depend on the order in
+//     which the workgroups arrive -- bit-identical reruns, which fp64 atomic adds would not give;
+//   * no fence: a returning atomic has been performed at the device's coherence point when its value comes
+//     back, so "wait for my 256 returns, then bump the counter" orders a workgroup's sums before its arrival
+//     without the release fence whose L2 write-back made the round-2 "last workgroup" tail slower than the
+//     separate kernels (it also read a 262 KB slab; the accumulator is 2 KB);
+//   * the last workgroup reads the accumulator with agent-scope atomic loads, writes the coefficient block
+//     (+ running statistics, num_batches_tracked, the step's fresh dropout words) and leaves the accumulator
+//     ZERO again, so one allocation serves every step and every HIP-graph replay;
+//   * non-finite partials cannot be represented: they raise a flag word and the tail writes NaN sums, as the
+//     slab path would have.
+#pragma once
+#include "common.h"
+
+namespace {
+
+struct BnAcc {
+  unsigned long long lo[128];   // fractional 64 bits
+  long long hi[128];            // integer part (two's complement)
+  unsigned int arrivals;
+  unsigned int nonfinite;
+  unsigned int pad[14];
+};
+static_assert(sizeof(BnAcc) == CGNN_BN_ACC_BYTES, "cgnn.h: CGNN_BN_ACC_BYTES");
+static_assert(sizeof(cgnn_bn_tail) == 120, "cgnn.h: struct cgnn_bn_tail (ctypes mirror: _lib.CgnnBnTail)");
+
+#define CGNN_AGENT __HIP_MEMORY_SCOPE_AGENT
+
+// column `c`'s partial of this workgroup -> accumulator.  Returns a value that depends on both atomics'
+// return values (consume it, e.g. store it to LDS, before bnacc_arrive: that is the wait).
+__device__ __forceinline__ unsigned long long bnacc_add(BnAcc* acc, int c, double x) {
+  if (!(fabs(x) < 9.0e18)) {                       // inf / nan / beyond 2^63: flagged, not added
+    return (unsigned long long)__hip_atomic_fetch_or(&acc->nonfinite, 1u, __ATOMIC_RELAXED, CGNN_AGENT);
+  }
+  const double fl = floor(x);
+  const long long hi = (long long)fl;
+  const unsigned long long lo = (unsigned long long)((x - fl) * 18446744073709551616.0);   // exact: < 2^64
+  const unsigned long long old = __hip_atomic_fetch_add(&acc->lo[c], lo, __ATOMIC_RELAXED, CGNN_AGENT);
+  const long long carry = (old + lo < old) ? 1 : 0;
+  const long long oldh = __hip_atomic_fetch_add(&acc->hi[c], hi + carry, __ATOMIC_RELAXED, CGNN_AGENT);
+  return old ^ (unsigned long long)oldh;
+}
+
+// Call from ALL threads of the workgroup after every bnacc_add of the workgroup has returned (its return
+// value consumed) and a __syncthreads().  True in every thread of the workgroup that arrived last.
+__device__ __forceinline__ bool bnacc_arrive(BnAcc* acc, int* lds_flag) {
+  if (threadIdx.x == 0) {
+    const unsigned int old = __hip_atomic_fetch_add(&acc->arrivals, 1u, __ATOMIC_RELAXED, CGNN_AGENT);
+    *lds_flag = (old == gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  return *lds_flag != 0;
+}
+
+// the finished sum of column c; the words are left zero (last workgroup only)
+__device__ __forceinline__ double bnacc_take(BnAcc* acc, int c) {
+  const unsigned long long lo = __hip_atomic_load(&acc->lo[c], __ATOMIC_RELAXED, CGNN_AGENT);
+  const long long hi = __hip_atomic_load(&acc->hi[c], __ATOMIC_RELAXED, CGNN_AGENT);
+  const unsigned int bad = __hip_atomic_load(&acc->nonfinite, __ATOMIC_RELAXED, CGNN_AGENT);
+  __hip_atomic_store(&acc->lo[c], 0ull, __ATOMIC_RELAXED, CGNN_AGENT);
+  __hip_atomic_store(&acc->hi[c], 0ll, __ATOMIC_RELAXED, CGNN_AGENT);
+  if (bad) return __builtin_nan("");
+  return (double)hi + (double)lo * 5.421010862427522e-20;          // 2^-64
+}
+
+// after every bnacc_take of the tail (one thread): counter and flag back to zero
+__device__ __forceinline__ void bnacc_reset(BnAcc* acc) {
+  __hip_atomic_store(&acc->arrivals, 0u, __ATOMIC_RELAXED, CGNN_AGENT);
+  __hip_atomic_store(&acc->nonfinite, 0u, __ATOMIC_RELAXED, CGNN_AGENT);
+}
+
+__device__ __forceinline__ uint32_t bn_tail_mix32(uint32_t x) {      // (= mix32 of the dropout hash)
+  x ^= x >> 16;
+  x *= 0x7FEB352Du;
+  x ^= x >> 15;
+  x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  return x;
+}
+
+// The finalisation itself, thread c < 64 of the last workgroup (the arithmetic of k_bn_fwd_stats /
+// k_bn_bwd_stats, fused_gcn.hip).  mean_off: the constant the statistics were taken without (centred layer 0).
+__device__ __forceinline__ void bn_tail_finalize(const cgnn_bn_tail& t, BnAcc* acc, int c, float mean_off) {
+  const double S1 = bnacc_take(acc, c), S2 = bnacc_take(acc, 64 + c);
+  if (t.mode == 0) {
+    const double m = S1 / t.count;
+    double v = S2 / t.count - m * m;
+    if (v < 0.0) v = 0.0;
+    const float mean = (float)m, var = (float)v;
+    const double unbiased = t.count > 1.0 ? v * t.count / (t.count - 1.0) : v;
+    const float mean_y = (float)(m + (double)mean_off);
+    t.running_mean[c] = (1.0f - t.momentum) * t.running_mean[c] + t.momentum * (mean_off != 0.f ? mean_y : mean);
+    t.running_var[c] = (1.0f - t.momentum) * t.running_var[c] + t.momentum * (float)unbiased;
+    const float invstd = 1.0f / sqrtf(var + t.eps);
+    const float a = t.gamma[c] * invstd;
+    t.bn_out[c] = a;
+    t.bn_out[64 + c] = t.beta[c] - mean * a;
+    t.bn_out[128 + c] = mean;
+    t.bn_out[192 + c] = invstd;
+    if (c == 0 && t.num_batches_tracked) *t.num_batches_tracked += 1;
+    if (t.rng_state && c < t.rng_n)
+      t.rng_state[c] = bn_tail_mix32(t.rng_state[c] + 0x9E3779B9u * (uint32_t)(c + 1));
+  } else {
+    t.dbeta[c] = (float)S1;
+    t.dgamma[c] = (float)S2;
+    t.bwc[c] = t.zero_coef ? 0.f : (float)(S1 / t.count);
+    t.bwc[64 + c] = t.zero_coef ? 0.f : (float)(S2 / t.count);
+  }
+}
+
+// The whole tail for a kernel whose threads t < 128 hold the workgroup's partial of column t in wg_sums[t]
+// (LDS, 128 doubles, written and synchronised by the caller); `scratch` >= 129 ints of LDS the caller no
+// longer needs.  Call from ALL threads.  mean_off_of(c): the centred layer 0's constant (0 elsewhere).
+template <typename MeanOff>
+__device__ __forceinline__ void bn_tail_run(const cgnn_bn_tail& t, const double* wg_sums, int* scratch,
+                                            MeanOff mean_off_of) {
+  BnAcc* acc = static_cast<BnAcc*>(t.acc);
+#ifdef CGNN_TAIL_DEBUG
+  if (threadIdx.x == 0 && wg_sums[0] != 0.0) printf("[tail] wg %d of %d adds col0 = %g (mode %d)\n", blockIdx.x, gridDim.x, wg_sums[0], t.mode);
+#endif
+  if (threadIdx.x < 128) {
+    const unsigned long long r = bnacc_add(acc, threadIdx.x, wg_sums[threadIdx.x]);
+    scratch[1 + threadIdx.x] = (int)(r & 1u);      // consuming the returns = waiting for the atomics
+  }
+  __syncthreads();
+  if (!bnacc_arrive(acc, scratch)) return;
+#ifdef CGNN_TAIL_DEBUG
+  if (threadIdx.x == 0) printf("[tail] wg %d is last (mode %d): lo0 %llu hi0 %lld\n", blockIdx.x, t.mode,
+                               __hip_atomic_load(&acc->lo[0], __ATOMIC_RELAXED, CGNN_AGENT), __hip_atomic_load(&acc->hi[0], __ATOMIC_RELAXED, CGNN_AGENT));
+  __syncthreads();
+#endif
+  if (threadIdx.x < 64) bn_tail_finalize(t, acc, threadIdx.x, mean_off_of(threadIdx.x));
+  __syncthreads();
+  if (threadIdx.x == 0) bnacc_reset(acc);
+}
+
+}  // namespace

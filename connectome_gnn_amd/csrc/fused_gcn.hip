@@ -33,6 +33,7 @@
 #include "common.h"
 #include "agg_block.h"
 #include "split_bf16.h"
+#include "bn_tail.h"
 #include "l0src.h"
 
 // streamed operands / results of the tile kernels (each read or written once per launch)
@@ -460,7 +461,7 @@ template <int MAXR, bool FROM_P0>
 __global__ void __launch_bounds__(PF_NTHR) k_gcn_fwd_pf(
     cgnn_tiles t, const float* __restrict__ Xin, cgnn_l0src l0, const float* __restrict__ bn_prev, DropCfg drop_in,
     int use_drop, uint8_t* __restrict__ mask_out, const float* __restrict__ W,
-    const float* __restrict__ bias, float* __restrict__ Y, double* __restrict__ stat_slab) {
+    const float* __restrict__ bias, float* __restrict__ Y, double* __restrict__ stat_slab, cgnn_bn_tail tail) {
   const DropCfg drop = drop_resolve(drop_in);
   __shared__ __attribute__((aligned(16))) float tile[MAXR * HID];
   __shared__ uint4 wsp[WSP_FRAGS];                               // split W^T panel, 24 KB
@@ -615,8 +616,14 @@ __global__ void __launch_bounds__(PF_NTHR) k_gcn_fwd_pf(
     }
     __syncthreads();
   }
-  if (stat_slab)
+  if (tail.acc) {
+    // the layer's BatchNorm finalised by the workgroup that arrives last (bn_tail.h): no slab, no launch
+    double* red = reinterpret_cast<double*>(tile);
+    reduce_stats<double, PF_NW>(s1, s2, red, red + PF_NW * 128);
+    bn_tail_run(tail, red + PF_NW * 128, reinterpret_cast<int*>(red + PF_NW * 128 + 128), [](int) { return 0.f; });
+  } else if (stat_slab) {
     reduce_stats<double, PF_NW>(s1, s2, reinterpret_cast<double*>(tile), stat_slab + (int64_t)blockIdx.x * 128);
+  }
 }
 
 // ==========================================================================================
@@ -643,7 +650,7 @@ __global__ void __launch_bounds__(NW * 64) k_gcn_bwd(
     const float* __restrict__ bn_prev, DropCfg drop, int use_drop,
     const uint8_t* __restrict__ mask_prev, const float* __restrict__ W,
     float* __restrict__ dZprev, double* __restrict__ s_slab, float* __restrict__ dW_slab,
-    double* __restrict__ db_slab) {
+    double* __restrict__ db_slab, cgnn_bn_tail tail) {
   __shared__ __attribute__((aligned(16))) float tile[MAXR * HID];
   __shared__ __attribute__((aligned(16))) float stg_all[NW * STG_FLOATS];
   __shared__ uint4 wsp[FIRST ? 1 : WSP_FRAGS];          // split W panel for dX = dT W (24 KB)
@@ -920,7 +927,16 @@ __global__ void __launch_bounds__(NW * 64) k_gcn_bwd(
     }
     __syncthreads();
   }
-  if (!FIRST) reduce_stats<float, NW>(s1, s2, reinterpret_cast<double*>(tile), s_slab + (int64_t)blockIdx.x * 128);
+  if (!FIRST) {
+    double* red = reinterpret_cast<double*>(tile);
+    if (tail.acc) {
+      // BatchNorm-backward coefficients of the layer below from the last workgroup's tail (bn_tail.h)
+      reduce_stats<float, NW>(s1, s2, red, red + NW * 128);
+      bn_tail_run(tail, red + NW * 128, reinterpret_cast<int*>(red + NW * 128 + 128), [](int) { return 0.f; });
+    } else {
+      reduce_stats<float, NW>(s1, s2, red, s_slab + (int64_t)blockIdx.x * 128);
+    }
+  }
   // dW: tree over the 8 waves through LDS (fixed order), wave 0 writes the partial.
   {
     constexpr int NTJ = FIRST ? 1 : 4;
@@ -1443,6 +1459,16 @@ bool l0src_ok(const cgnn_l0src* l0) {
   return l0 && l0->P0 && l0->W0 && l0->b0 && l0->F0 >= 1 && l0->F0 <= L0_FP;
 }
 
+// a tail descriptor the kernels can run (NULL = none = fine)
+bool tail_ok(const cgnn_bn_tail* tl, int mode) {
+  if (!tl) return true;
+  if (!tl->acc || tl->mode != mode || !(tl->count > 0.0) || (reinterpret_cast<uintptr_t>(tl->acc) & 7)) return false;
+  if (mode == 0)
+    return tl->gamma && tl->beta && tl->running_mean && tl->running_var && tl->bn_out && tl->rng_n >= 0 &&
+           tl->rng_n <= 64 && (tl->rng_n == 0 || tl->rng_state);
+  return tl->dgamma && tl->dbeta && tl->bwc;
+}
+
 bool tiles_ok(const cgnn_tiles* t) {
   return t && t->num_tiles >= 0 && t->num_nodes >= 0 && t->max_tile_rows <= CGNN_FUSED_MAX_ROWS &&
          (t->num_tiles == 0 || (t->tile_ptr && t->tile_blk && t->blk_off_dst && t->ent_dst &&
@@ -1494,19 +1520,21 @@ int cgnn_rng_advance(uint32_t* state, int32_t n, void* stream) {
 int cgnn_gcn_fused_fwd(const cgnn_tiles* t, const float* Yprev, const cgnn_l0src* l0,
                        const float* bn_prev, float p_drop, uint64_t seed, const uint32_t* seed_dev,
                        uint8_t* mask_out, const float* W, const float* bias, float* Y,
-                       double* stat_slab, int64_t stat_slab_bytes, void* stream) {
+                       double* stat_slab, int64_t stat_slab_bytes, const cgnn_bn_tail* tail, void* stream) {
   if (!tiles_ok(t)) return t && t->max_tile_rows > CGNN_FUSED_MAX_ROWS ? CGNN_EUNSUPPORTED : CGNN_EINVAL;
   if ((!Yprev && !l0src_ok(l0)) || !bn_prev || !W || !bias || !Y || p_drop < 0.f || p_drop >= 1.f) return CGNN_EINVAL;
+  if (!tail_ok(tail, 0)) return CGNN_EINVAL;
+  const cgnn_bn_tail tl = tail ? *tail : cgnn_bn_tail{};
   CGNN_NEED_BYTES(stat_slab, stat_slab_bytes, (int64_t)fused_grid() * 128 * (int64_t)sizeof(double));
   int use_drop;
   DropCfg d = make_drop(p_drop, seed, &use_drop);
   d.dev_key = seed_dev;
   if (Yprev)
     k_gcn_fwd_pf<CGNN_FUSED_MAX_ROWS, false><<<fused_grid(), PF_NTHR, 0, cgnn_stream(stream)>>>(
-        *t, Yprev, cgnn_l0src{}, bn_prev, d, use_drop, mask_out, W, bias, Y, stat_slab);
+        *t, Yprev, cgnn_l0src{}, bn_prev, d, use_drop, mask_out, W, bias, Y, stat_slab, tl);
   else
     k_gcn_fwd_pf<CGNN_FUSED_MAX_ROWS, true><<<fused_grid(), PF_NTHR, 0, cgnn_stream(stream)>>>(
-        *t, nullptr, *l0, bn_prev, d, use_drop, mask_out, W, bias, Y, stat_slab);
+        *t, nullptr, *l0, bn_prev, d, use_drop, mask_out, W, bias, Y, stat_slab, tl);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }
@@ -1586,11 +1614,13 @@ int cgnn_gcn_fused_bwd(const cgnn_tiles* t, const float* dZ, const float* Y, con
                        const float* bn_prev, float p_drop, const uint8_t* mask_prev, const float* W,
                        float* dZprev, double* s_slab_prev, int64_t s_slab_prev_bytes, float* dW_slab, int64_t dW_slab_bytes, double* db_slab, int64_t db_slab_bytes,
                        const float* dP, const int32_t* node_graph, const int32_t* gptr,
-                       const uint8_t* mask_cur, void* stream) {
+                       const uint8_t* mask_cur, const cgnn_bn_tail* tail, void* stream) {
   if (!tiles_ok(t)) return t && t->max_tile_rows > CGNN_FUSED_MAX_ROWS ? CGNN_EUNSUPPORTED : CGNN_EINVAL;
-  if (!Y || !bn || !bwc || (!Yprev && !l0src_ok(l0)) || !bn_prev || !W || !dZprev || !s_slab_prev ||
+  if (!Y || !bn || !bwc || (!Yprev && !l0src_ok(l0)) || !bn_prev || !W || !dZprev || (!s_slab_prev && !tail) ||
       !dW_slab || !db_slab || p_drop < 0.f || p_drop >= 1.f)
     return CGNN_EINVAL;
+  if (!tail_ok(tail, 1)) return CGNN_EINVAL;
+  const cgnn_bn_tail tl = tail ? *tail : cgnn_bn_tail{};
   if (p_drop > 0.f && !mask_prev) return CGNN_EINVAL;
   if (dP ? (!node_graph || !gptr || (p_drop > 0.f && !mask_cur)) : !dZ) return CGNN_EINVAL;
   CGNN_NEED_BYTES(s_slab_prev, s_slab_prev_bytes, (int64_t)fused_grid() * 128 * (int64_t)sizeof(double));
@@ -1604,7 +1634,7 @@ int cgnn_gcn_fused_bwd(const cgnn_tiles* t, const float* dZ, const float* Y, con
 #define CGNN_BWD_LAUNCH(POOL, XP)                                                                      \
   k_gcn_bwd<CGNN_FUSED_MAX_ROWS, false, POOL, XP, CGNN_BWD_NW><<<fused_grid(), CGNN_BWD_NW * 64, 0, cgnn_stream(stream)>>>( \
       *t, pin, src, dZ, Y, bn, bwc, Yprev, 0, bn_prev, d, use_drop, mask_prev, W, dZprev, s_slab_prev, \
-      dW_slab, db_slab)
+      dW_slab, db_slab, tl)
   if (dP) { if (Yprev) CGNN_BWD_LAUNCH(true, false); else CGNN_BWD_LAUNCH(true, true); }
   else    { if (Yprev) CGNN_BWD_LAUNCH(false, false); else CGNN_BWD_LAUNCH(false, true); }
 #undef CGNN_BWD_LAUNCH
@@ -1628,11 +1658,11 @@ int cgnn_gcn_fused_bwd_first(const cgnn_tiles* t, const float* dZ, const float* 
   if (dP)
     k_gcn_bwd<CGNN_FUSED_MAX_ROWS, true, true><<<fused_grid(), NTHR, 0, cgnn_stream(stream)>>>(
         *t, pin, cgnn_l0src{}, dZ, Y, bn, bwc, X0, F0, nullptr, d, use_drop, nullptr, nullptr, nullptr, nullptr,
-        dW_slab, db_slab);
+        dW_slab, db_slab, cgnn_bn_tail{});
   else
     k_gcn_bwd<CGNN_FUSED_MAX_ROWS, true, false><<<fused_grid(), NTHR, 0, cgnn_stream(stream)>>>(
         *t, pin, cgnn_l0src{}, dZ, Y, bn, bwc, X0, F0, nullptr, d, use_drop, nullptr, nullptr, nullptr, nullptr,
-        dW_slab, db_slab);
+        dW_slab, db_slab, cgnn_bn_tail{});
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }

@@ -17,6 +17,7 @@
 //              Y0 read from HBM or rebuilt from the P0 row it loads anyway).
 #include "common.h"
 #include "l0src.h"
+#include "bn_tail.h"
 
 namespace {
 
@@ -41,7 +42,7 @@ __global__ void __launch_bounds__(L0THR, WRITE_Y ? 5 : CGNN_L0_MINW) k_l0_fwd(cg
                                                   double* __restrict__ stat_slab,
                                                   const float* __restrict__ center,
                                                   float* __restrict__ w_eff,
-                                                  float* __restrict__ mean_offset) {
+                                                  float* __restrict__ mean_offset, cgnn_bn_tail tail) {
   __shared__ __attribute__((aligned(16))) float smem[2 * MAXR * FP];   // 24 KB -> 6 WGs per CU
   float* xs = smem;
   float* ps = smem + MAXR * FP;
@@ -177,7 +178,7 @@ __global__ void __launch_bounds__(L0THR, WRITE_Y ? 5 : CGNN_L0_MINW) k_l0_fwd(cg
     __syncthreads();
     if (!WRITE_Y) {
       // 3. second moments of this tile's P0 rows: wave w takes the 16-row blocks w, w + 6, ...
-      if (stat_slab) {
+      if (stat_slab || tail.acc) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ci = lane & 15, kq = lane >> 4;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         for (int rb = wave; 16 * rb < n; rb += L0THR / 64) {
@@ -222,7 +223,7 @@ __global__ void __launch_bounds__(L0THR, WRITE_Y ? 5 : CGNN_L0_MINW) k_l0_fwd(cg
     }
     __syncthreads();
   }
-  if (!stat_slab) return;
+  if (!stat_slab && !tail.acc) return;
   __syncthreads();
   if (!WRITE_Y) {
     // moments -> sums: the waves' accumulators folded in fixed order, then, with the moments M of
@@ -263,7 +264,20 @@ __global__ void __launch_bounds__(L0THR, WRITE_Y ? 5 : CGNN_L0_MINW) k_l0_fwd(cg
         }
         out = quad + 2.0 * bc * lin + cnt * bc * bc;
       }
-      stat_slab[(int64_t)blockIdx.x * 128 + threadIdx.x] = out;
+      if (tail.acc) red[1280 + threadIdx.x] = out;     // (red[0..1152) hold M and the threads' weight rows)
+      else stat_slab[(int64_t)blockIdx.x * 128 + threadIdx.x] = out;
+    }
+    if (tail.acc) {
+      // the layer's BatchNorm finalised by the workgroup that arrives last (bn_tail.h).  The centred form's
+      // constant b + rbar W0 c -- which the statistics were taken without and only the running mean sees --
+      // is recomputed by the tail's threads exactly as workgroup 0 wrote it to `mean_offset`
+      __syncthreads();
+      bn_tail_run(tail, red + 1280, reinterpret_cast<int*>(red + 1408), [&](int c) {
+        if (!centred) return 0.f;
+        double last = 0.0;
+        for (int k = 0; k < F0; ++k) last += (double)W0[c * F0 + k] * (double)center[k];
+        return (float)((double)bias[c] + (double)(float)last * (double)center[RC]);
+      });
     }
     return;
   }
@@ -451,22 +465,28 @@ int cgnn_gcn_l0_center(const cgnn_tiles* t, const float* X0, int32_t F0, float* 
 
 int cgnn_gcn_l0_fwd(const cgnn_tiles* t, const float* X0, int32_t F0, const float* W0,
                     const float* bias, float* P0, float* Y, double* stat_slab, int64_t stat_slab_bytes, const float* center,
-                    float* w_eff, float* mean_offset, void* stream) {
+                    float* w_eff, float* mean_offset, const cgnn_bn_tail* tail, void* stream) {
   if (!t || F0 <= 0 || F0 > FP || t->max_tile_rows > CGNN_FUSED_MAX_ROWS) return t && F0 > FP ? CGNN_EUNSUPPORTED : CGNN_EINVAL;
   if (Y && (center || w_eff || mean_offset)) return CGNN_EINVAL;   // the centred form belongs to the factored layer
   if (center && (!w_eff || !mean_offset || F0 >= FP)) return CGNN_EINVAL;   // column 7 must be spare
   if (!center && (w_eff || mean_offset)) return CGNN_EINVAL;
   if (t->num_tiles == 0) return CGNN_OK;
   CGNN_NEED_BYTES(stat_slab, stat_slab_bytes, (int64_t)l0_grid(t->num_nodes) * 128 * (int64_t)sizeof(double));
+  // (a tail finalises the FACTORED layer only: the statistics then come from the moments of P0)
+  if (tail && (Y || !tail->acc || tail->mode != 0 || !(tail->count > 0.0) || !tail->gamma || !tail->beta ||
+               !tail->running_mean || !tail->running_var || !tail->bn_out || tail->rng_n < 0 || tail->rng_n > 64 ||
+               (tail->rng_n > 0 && !tail->rng_state)))
+    return CGNN_EINVAL;
+  const cgnn_bn_tail tl = tail ? *tail : cgnn_bn_tail{};
   if (!X0 || !W0 || !bias || !P0 || !t->tile_ptr || !t->tile_blk || !t->blk_off_dst ||
       !t->ent_dst || !t->dis)
     return CGNN_EINVAL;
   if (Y)
     k_l0_fwd<true><<<l0_grid(t->num_nodes), L0THR, 0, cgnn_stream(stream)>>>(*t, X0, F0, W0, bias, P0, Y, stat_slab,
-                                                                             nullptr, nullptr, nullptr);
+                                                                             nullptr, nullptr, nullptr, cgnn_bn_tail{});
   else
     k_l0_fwd<false><<<l0_grid(t->num_nodes), L0THR, 0, cgnn_stream(stream)>>>(*t, X0, F0, W0, bias, P0, Y, stat_slab,
-                                                                              center, w_eff, mean_offset);
+                                                                              center, w_eff, mean_offset, tl);
   CGNN_CHECK_LAUNCH();
   return CGNN_OK;
 }

@@ -13,6 +13,7 @@ one dropout keep-byte per (node, 4-column chunk); activations are rebuilt in LDS
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import List, Optional
 
 import torch
@@ -91,13 +92,46 @@ def _l0_center(lib, s, x0: torch.Tensor, tiles_ref, stream) -> torch.Tensor:
 class _Ctx:
     """Everything of one forward pass that backward needs and autograd must not track."""
     __slots__ = ("s", "meta", "dis", "tiles", "grid", "ys", "bns", "masks", "p", "x0", "f0", "p0", "count_dev", "fsum", "l0src", "l0keep",
-                 "count", "sync_group", "num_layers", "training", "grad_dst")
+                 "count", "sync_group", "num_layers", "training", "grad_dst", "bn_modules")
 
 
 def _sync_sums(buf: torch.Tensor, group) -> None:
     """Full-batch BatchNorm across ranks (SURVEY 8e option i): one all-reduce of the fp64 block
     [sum | sumsq | rows]; everything, the row count included, stays on the device."""
     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+
+
+# diagnostic A/B switch (never set in the product): the slab + finalisation-launch protocol of rounds 1-3
+_NO_TAILS = bool(os.environ.get("CGNN_DIAG_NO_BN_TAILS"))
+
+
+def _bn_acc(bn_mod, dev, which: int) -> torch.Tensor:
+    """The module's accumulator for BatchNorm sums finalised in a producer kernel's tail (csrc/bn_tail.h):
+    zero when created, left zero by every launch that uses it.  which: 0 = forward statistics, 1 = backward."""
+    acc = bn_mod.__dict__.get("_cgnn_acc")
+    if acc is None or acc.device != dev:
+        acc = torch.zeros(2, _lib.BN_ACC_BYTES // 8, dtype=torch.int64, device=dev)
+        bn_mod.__dict__["_cgnn_acc"] = acc
+    return acc[which]
+
+
+def _tail_fwd(bn_mod, dev, count, gamma, beta, bn_out, rng, rng_n) -> "_lib.CgnnBnTail":
+    t = _lib.CgnnBnTail()
+    t.acc, t.count, t.mode = _bn_acc(bn_mod, dev, 0).data_ptr(), float(count), 0
+    t.gamma, t.beta = gamma.data_ptr(), beta.data_ptr()
+    t.running_mean, t.running_var = bn_mod.running_mean.data_ptr(), bn_mod.running_var.data_ptr()
+    t.momentum, t.eps = float(bn_mod.momentum), float(bn_mod.eps)
+    t.num_batches_tracked = bn_mod.num_batches_tracked.data_ptr()
+    t.bn_out = bn_out.data_ptr()
+    t.rng_state, t.rng_n = (rng.data_ptr(), rng_n) if rng is not None else (None, 0)
+    return t
+
+
+def _tail_bwd(bn_mod, dev, count, zero_coef, dgamma, dbeta, bwc) -> "_lib.CgnnBnTail":
+    t = _lib.CgnnBnTail()
+    t.acc, t.count, t.mode, t.zero_coef = _bn_acc(bn_mod, dev, 1).data_ptr(), float(count), 1, int(zero_coef)
+    t.dgamma, t.dbeta, t.bwc = dgamma.data_ptr(), dbeta.data_ptr(), bwc.data_ptr()
+    return t
 
 
 class FusedGCNEncode(torch.autograd.Function):
@@ -145,10 +179,20 @@ class FusedGCNEncode(torch.autograd.Function):
         with _lib.device_guard(dev):
             if rng is not None and p > 0 and not rng_in_finalize:
                 _lib.check(lib.cgnn_rng_advance(_lib.ptr(rng), L + 1, st()), "cgnn_rng_advance")
+            # per-rank BatchNorm in training: the layer's statistics are finalised by the LAST WORKGROUP of the
+            # kernel that produces them (csrc/bn_tail.h) -- no slab, no finalisation launch; with a sync group the
+            # sums have to cross the ranks between the two, so the slab protocol stays
+            tails = training and sync_group is None and not _NO_TAILS
             for l in range(L):
                 w, b, gamma, beta = (t.contiguous() for t in params[4 * l:4 * l + 4])
                 y = torch.empty(nn_, HID, **f32) if not (l == 0 and narrow0) else None
                 slab, slab_rows = stat_slab, grid
+                bn_mod = bns_mod[l]
+                bn = torch.empty(4 * HID, **f32)
+                tail = None
+                if tails and (l > 0 or narrow0):
+                    adv = rng_in_finalize and l == 0
+                    tail = _tail_fwd(bn_mod, dev, count, gamma, beta, bn, rng if adv else None, L + 1 if adv else 0)
                 if l == 0 and narrow0:
                     # layer 0, narrow form: Y0 = (A_hat X0) W0^T + b is NEVER written: only the
                     # narrow aggregate P0 = A_hat X0 (32 B per node) is kept and every consumer
@@ -171,11 +215,12 @@ class FusedGCNEncode(torch.autograd.Function):
                         l0src = _lib.CgnnL0Src(_lib.ptr(p0), _lib.ptr(w), _lib.ptr(b), f0)
                         l0keep = (w, b, None, None)
                     slab_rows = lib.cgnn_l0_grid(nn_)
-                    slab = torch.empty(slab_rows, 128, dtype=torch.float64, device=dev) if training else None
+                    slab = torch.empty(slab_rows, 128, dtype=torch.float64, device=dev) if (training and tail is None) else None
                     with _lib.timed("cgnn_gcn_l0_fwd"):
                         _lib.check(lib.cgnn_gcn_l0_fwd(
                             tp, _lib.ptr(x0), f0, _lib.ptr(w), _lib.ptr(b), _lib.ptr(p0), None, _lib.ptr(slab), _lib.nbytes(slab),
-                            _lib.ptr(center), _lib.ptr(w_eff), _lib.ptr(mean_off), st()), "cgnn_gcn_l0_fwd")
+                            _lib.ptr(center), _lib.ptr(w_eff), _lib.ptr(mean_off),
+                            ctypes.byref(tail) if tail is not None else None, st()), "cgnn_gcn_l0_fwd")
                 elif l == 0:
                     with _lib.timed("cgnn_gcn_fused_fwd_first"):
                         _lib.check(lib.cgnn_gcn_fused_fwd_first(
@@ -188,13 +233,15 @@ class FusedGCNEncode(torch.autograd.Function):
                         _lib.check(lib.cgnn_gcn_fused_fwd(
                             tp, _lib.ptr(ys[-1]), ctypes.byref(l0src) if ys[-1] is None else None,
                             _lib.ptr(bns[-1]), p, seed, rng_ptr(l), _lib.ptr(mask),
-                            _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), _lib.ptr(stat_slab), _lib.nbytes(stat_slab), st()),
+                            _lib.ptr(w), _lib.ptr(b), _lib.ptr(y),
+                            None if tail is not None else _lib.ptr(stat_slab), _lib.nbytes(stat_slab),
+                            ctypes.byref(tail) if tail is not None else None, st()),
                             "cgnn_gcn_fused_fwd")
                     masks.append(mask)
-                bn_mod = bns_mod[l]
-                bn = torch.empty(4 * HID, **f32)
                 cnt = count
-                if training and sync_group is None:
+                if tail is not None:
+                    pass                                   # finalised inside the producing launch
+                elif training and sync_group is None:
                     # one launch: reduce partials, finalise, update running stats and the counter
                     adv = rng_in_finalize and l == 0
                     _lib.check(lib.cgnn_bn_stats_finalize_rng(
@@ -244,6 +291,7 @@ class FusedGCNEncode(torch.autograd.Function):
         c.fsum = fsum
         c.l0src, c.l0keep = l0src, l0keep
         c.grad_dst = meta.get("grad_dst") or [None] * (4 * L)
+        c.bn_modules = bns_mod
         if meta.get("record") is not None:
             meta["record"]["layers"] = list(masks)
         ctx.c = c
@@ -328,22 +376,34 @@ class FusedGCNEncode(torch.autograd.Function):
                         _lib.ptr(c.masks[-1]), _lib.ptr(s.gptr), B, None, _lib.ptr(s_slab), _lib.nbytes(s_slab), st()),
                         "cgnn_gcn_fused_pool_bwd")
                 bwc = bn_backward(L - 1)
+            bns_mod = c.bn_modules
             for l in range(L - 1, 0, -1):
                 w = params[4 * l].contiguous()
                 extra = pool_args if l == L - 1 else none_args
                 dw_slab = torch.empty(grid, HID * HID, **f32)
                 db_slab = torch.empty(grid, HID, **f64)
+                # per-rank BatchNorm: the coefficients of the layer BELOW (its dgamma / dbeta / c1|c2) come out
+                # of this launch's tail (csrc/bn_tail.h) instead of a finalisation launch of their own
+                tail = nxt = None
+                if c.sync_group is None and not _NO_TAILS:
+                    nxt = (out(4 * (l - 1) + 2, HID), out(4 * (l - 1) + 3, HID), torch.empty(2 * HID, **f32))
+                    tail = _tail_bwd(bns_mod[l - 1], dev, c.count, not c.training, *nxt)
                 with _lib.timed("cgnn_gcn_fused_bwd"):
                     _lib.check(lib.cgnn_gcn_fused_bwd(
                         tp, _lib.ptr(dz), _lib.ptr(c.ys[l]), _lib.ptr(c.bns[l]), _lib.ptr(bwc),
                         _lib.ptr(c.ys[l - 1]), ctypes.byref(c.l0src) if c.ys[l - 1] is None else None,
                         _lib.ptr(c.bns[l - 1]), c.p, _lib.ptr(c.masks[l - 1]),
-                        _lib.ptr(w), _lib.ptr(dz_prev), _lib.ptr(s_slab), _lib.nbytes(s_slab), _lib.ptr(dw_slab), _lib.nbytes(dw_slab),
-                        _lib.ptr(db_slab), _lib.nbytes(db_slab), *extra, st()), "cgnn_gcn_fused_bwd")
+                        _lib.ptr(w), _lib.ptr(dz_prev), None if tail is not None else _lib.ptr(s_slab), _lib.nbytes(s_slab),
+                        _lib.ptr(dw_slab), _lib.nbytes(dw_slab),
+                        _lib.ptr(db_slab), _lib.nbytes(db_slab), *extra,
+                        ctypes.byref(tail) if tail is not None else None, st()), "cgnn_gcn_fused_bwd")
                 dw, db = out(4 * l, HID, HID), out(4 * l + 1, HID)
                 jobs.append((dw_slab, db_slab, grid, HID, HID, dw, db))
                 grads[4 * l], grads[4 * l + 1] = dw, db
-                bwc = bn_backward(l - 1)
+                if nxt is not None:
+                    grads[4 * (l - 1) + 2], grads[4 * (l - 1) + 3], bwc = nxt
+                else:
+                    bwc = bn_backward(l - 1)
                 dz, dz_prev = dz_prev, dz
             dw0, db0 = out(0, HID, c.f0), out(1, HID)
             if c.p0 is not None:

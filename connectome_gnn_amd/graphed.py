@@ -124,6 +124,22 @@ class GraphedTrainStep:
                 grad_sync.zero_grad()
 
     def _capture(self, split: bool, mode: dict) -> None:
+        # The cyclic garbage collector stays OFF while a stream is capturing: a collection pass runs in whichever
+        # thread happens to allocate (here: autograd's worker thread, in the middle of the captured backward) and
+        # finalises whatever cyclic garbage exists at that moment -- e.g. a dropped Trainer's captured steps, whose
+        # hipGraph / private-pool teardown is not a legal call during another capture and aborts the process
+        # (seen once the captured step allocated a few more Python objects and a pass landed inside the capture).
+        # torch.cuda.graph() itself collects right BEFORE the capture begins; reference counting is unaffected.
+        import gc
+        was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            self._capture_body(split, mode)
+        finally:
+            if was_enabled:
+                gc.enable()
+
+    def _capture_body(self, split: bool, mode: dict) -> None:
         if split:
             with torch.cuda.graph(self.graph, **mode):
                 self.loss = self._fwd_bwd()
@@ -317,10 +333,17 @@ class GraphedEvalStep:
             torch.cuda.current_stream(dev).wait_stream(side)
             self._state.zero_()
             self.graph = torch.cuda.CUDAGraph()
+            import gc
             import torch.distributed as dist
             mode = {"capture_error_mode": "thread_local"} if dist.is_available() and dist.is_initialized() else {}
-            with torch.cuda.graph(self.graph, **mode):
-                body()
+            was_enabled = gc.isenabled()
+            gc.disable()                                  # (no collection pass inside a capture: GraphedTrainStep._capture)
+            try:
+                with torch.cuda.graph(self.graph, **mode):
+                    body()
+            finally:
+                if was_enabled:
+                    gc.enable()
         self._state.zero_()
 
     def run(self, ids: torch.Tensor, steps: int):

@@ -449,6 +449,34 @@ int cgnn_band_aggregate_f32(const void* bfrag, const int32_t* bstep, const int32
                             void* stream);
 
 
+/* BatchNorm finalisation in the PRODUCER's tail (round 4; csrc/bn_tail.h): instead of writing its
+ * per-workgroup partial sums to a slab for cgnn_bn_stats_finalize_rng / cgnn_bn_bwd_stats_finalize to fold
+ * in a launch of their own, a tile kernel adds them to a 128-word accumulator (128-bit fixed-point atomic
+ * adds: order-independent, bit-identical reruns) and the workgroup that arrives last writes the layer's
+ * coefficient block.  `acc`: CGNN_BN_ACC_BYTES bytes of device memory, ZERO before the first launch that
+ * uses it; every launch leaves it zero again.  One accumulator may serve launches on ONE stream.
+ *   mode 0 (statistics of a forward layer): the arithmetic of cgnn_bn_stats_finalize_rng -- count rows,
+ *     gamma/beta, running statistics and num_batches_tracked updated in place, bn_out float[4*64], rng_state /
+ *     rng_n as there (the step's dropout words, refreshed by the tail; NULL / 0 = none);
+ *   mode 1 (sums of a backward layer): the arithmetic of cgnn_bn_bwd_stats_finalize -- dgamma, dbeta
+ *     float[64], bwc float[2*64], zero_coef as there.
+ * Passed as the last argument of cgnn_gcn_l0_fwd (mode 0; factored layer 0: the centred form's mean offset
+ * is the kernel's own), cgnn_gcn_fused_fwd (mode 0) and cgnn_gcn_fused_bwd (mode 1, the sums of the layer
+ * BELOW); NULL = the slab protocol.  With a tail the corresponding slab argument may be NULL. */
+#define CGNN_BN_ACC_BYTES 2112
+typedef struct cgnn_bn_tail {
+  void* acc;
+  double count;
+  int32_t mode, zero_coef;
+  const float* gamma; const float* beta;
+  float* running_mean; float* running_var;
+  float momentum, eps;
+  int64_t* num_batches_tracked;
+  float* bn_out;
+  uint32_t* rng_state; int32_t rng_n; int32_t reserved;
+  float* dgamma; float* dbeta; float* bwc;
+} cgnn_bn_tail;
+
 /* Layer 0 forward.  X0 [Nn,F0] (F0 <= 16), W0 [64,F0], bias [64] -> Y [Nn,64];
  * stat_slab [grid][128] fp64 (sum(y) | sum(y^2)) or NULL (eval). */
 int cgnn_gcn_fused_fwd_first(const cgnn_tiles* t, const float* X0, int32_t F0, const float* W0,
@@ -463,7 +491,7 @@ int cgnn_rng_advance(uint32_t* state, int32_t n, void* stream);
 int cgnn_gcn_fused_fwd(const cgnn_tiles* t, const float* Yprev, const cgnn_l0src* l0,
                        const float* bn_prev, float p_drop, uint64_t seed, const uint32_t* seed_dev,
                        uint8_t* mask_out, const float* W, const float* bias, float* Y,
-                       double* stat_slab, int64_t stat_slab_bytes, void* stream);
+                       double* stat_slab, int64_t stat_slab_bytes, const cgnn_bn_tail* tail, void* stream);
 
 /* slab [rows][width] fp64 -> sums [width] fp64 (fixed-order tree). */
 int cgnn_bn_reduce(const double* slab, int32_t rows, int32_t width, double* sums, void* stream);
@@ -522,7 +550,7 @@ int cgnn_gcn_fused_bwd(const cgnn_tiles* t, const float* dZ, const float* Y, con
                        const float* bn_prev, float p_drop, const uint8_t* mask_prev, const float* W,
                        float* dZprev, double* s_slab_prev, int64_t s_slab_prev_bytes, float* dW_slab, int64_t dW_slab_bytes, double* db_slab, int64_t db_slab_bytes,
                        const float* dP, const int32_t* node_graph, const int32_t* gptr,
-                       const uint8_t* mask_cur, void* stream);
+                       const uint8_t* mask_cur, const cgnn_bn_tail* tail, void* stream);
 
 /* Layer 0 backward: dW0 = dT^T X0 only.  dW_slab [grid][64*16] (columns >= F0 are zero). */
 int cgnn_gcn_fused_bwd_first(const cgnn_tiles* t, const float* dZ, const float* Y,
@@ -561,7 +589,7 @@ int cgnn_l0_grid(int64_t num_nodes);
 int cgnn_gcn_l0_center(const cgnn_tiles* t, const float* X0, int32_t F0, float* center, void* stream);
 int cgnn_gcn_l0_fwd(const cgnn_tiles* t, const float* X0, int32_t F0, const float* W0,
                     const float* bias, float* P0, float* Y, double* stat_slab, int64_t stat_slab_bytes, const float* center,
-                    float* w_eff, float* mean_offset, void* stream);
+                    float* w_eff, float* mean_offset, const cgnn_bn_tail* tail, void* stream);
 int cgnn_gcn_l0_bwd(const float* dZ, const float* Y, const cgnn_l0src* l0, const float* bn,
                     const float* bwc, const float* P0, int64_t num_nodes, float* dW_slab, int64_t dW_slab_bytes,
                     double* db_slab, int64_t db_slab_bytes, const float* center, void* stream);

@@ -327,3 +327,14 @@ def test_bench_rank_bookkeeping_for_eight_gpus():
     pr = bench.projection_8gpu(1.86, 0.327)
     assert "value" not in pr and pr["what"].startswith("projection") and pr["n_gpus"] == 8
     assert 4.5 < pr["speedup_vs_1gpu"][1] < pr["speedup_vs_1gpu"][0] < 6.0
+
+
+def test_bn_tail_struct_layout_matches_header():
+    """struct cgnn_bn_tail (include/cgnn.h; the library static_asserts 120 bytes) and its ctypes mirror."""
+    from connectome_gnn_amd import _lib
+    t = _lib.CgnnBnTail()
+    assert ctypes.sizeof(t) == 120 and _lib.BN_ACC_BYTES == 2112
+    assert _lib.CgnnBnTail.count.offset == 8 and _lib.CgnnBnTail.gamma.offset == 24
+    assert _lib.CgnnBnTail.momentum.offset == 56 and _lib.CgnnBnTail.rng_n.offset == 88 and _lib.CgnnBnTail.bwc.offset == 112
+    hdr = open(os.path.join(ROOT, "include", "cgnn.h")).read()
+    assert "#define CGNN_BN_ACC_BYTES 2112" in hdr
