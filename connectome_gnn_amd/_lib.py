@@ -43,7 +43,7 @@ class CgnnL0Src(ctypes.Structure):
 
 LP = ctypes.POINTER(CgnnL0Src)
 
-BN_ACC_BYTES = 2112
+BN_ACC_BYTES = 16448
 
 
 class CgnnBnTail(ctypes.Structure):

@@ -4,31 +4,48 @@
 // (sum y | sum y^2 in the forward pass, sum dz | sum dz*xhat in the backward pass).  Rounds 1-3 wrote them
 // to a [workgroups][128] slab and a separate one-block-per-channel kernel folded the slab and turned the
 // sums into the layer's coefficient block: five launches of 4-7 us per training step that do nothing but
-// wait for one load round trip, 24 us of a 0.31 ms step at 512 graphs per rank.
+// wait for one load round trip.
 //
-// Here the partials go into a 128-word accumulator with 64-bit ATOMIC adds and the workgroup that arrives
-// last (an arrival counter) finalises the layer in the producer's own tail:
+// Here the partials go into an accumulator with 64-bit ATOMIC adds and the workgroup that arrives last (an
+// arrival counter) finalises the layer in the producer's own tail:
 //
-//   * the sums are added as 128-bit FIXED-POINT integers (64 integer + 64 fractional bits, two 64-bit atomic
-//     adds with a carry): integer addition is associative, so the result does not depend on the order in
-//     which the workgroups arrive -- bit-identical reruns, which fp64 atomic adds would not give;
+//   * the sums are added as FIXED-POINT integers (integer part and fractional part x 2^52 in two signed
+//     64-bit words): integer addition is associative, so the result does not depend on the order in which
+//     the workgroups arrive -- bit-identical reruns, which fp64 atomic adds would not give -- and it equals
+//     the slab protocol's fp64 fold to the last bit on every parity case (the coefficient blocks compare with
+//     torch.equal);
 //   * no fence: a returning atomic has been performed at the device's coherence point when its value comes
-//     back, so "wait for my 256 returns, then bump the counter" orders a workgroup's sums before its arrival
+//     back, so "wait for my returns, then bump the counter" orders a workgroup's sums before its arrival
 //     without the release fence whose L2 write-back made the round-2 "last workgroup" tail slower than the
-//     separate kernels (it also read a 262 KB slab; the accumulator is 2 KB);
+//     separate kernels (it also read a 262 KB slab; the accumulator is 16 KB);
+//   * eight sub-accumulators (workgroup % 8): 256 workgroups adding to ONE set of 256 addresses serialise at
+//     the memory-side atomic unit -- the first version (one set, a 128-bit value with a carry between its two
+//     atomics = two dependent round trips) made every producer ~8 us longer and LOST to the separate kernels
+//     (cfg2 replay 0.183 vs 0.167 ms, 512-graph shard 0.342 vs 0.331, headline 1.864 vs 1.844);
 //   * the last workgroup reads the accumulator with agent-scope atomic loads, writes the coefficient block
 //     (+ running statistics, num_batches_tracked, the step's fresh dropout words) and leaves the accumulator
 //     ZERO again, so one allocation serves every step and every HIP-graph replay;
 //   * non-finite partials cannot be represented: they raise a flag word and the tail writes NaN sums, as the
 //     slab path would have.
+//
+// Measured (A/B/A/B on one box, CGNN_DIAG_NO_BN_TAILS=1 = the slab protocol): headline 1.842 vs 1.856 ms
+// (-0.8 %), 512-graph shard 0.328 vs 0.329, cfg2 replay 0.170 vs 0.167: three serialised round trips at the end
+// of a producer (sums, arrival, the last workgroup's reads) cost what the launch they replace cost, so under
+// HIP-graph replay it is a wash at small batches; what it buys is five launches fewer for eager callers and
+// the slabs' traffic at the headline size.
 #pragma once
 #include "common.h"
 
 namespace {
 
+// Eight sub-accumulators (workgroup % 8, i.e. one per XCD under round-robin dispatch) cut the contention on
+// an address eightfold; a column's sum is two independent signed 64-bit words -- integer part and fractional
+// part scaled by 2^52 (exact below the resolution 2^-52, far under BatchNorm's eps) -- so the two atomics of a
+// column have no carry between them and cost ONE round trip.
+constexpr int BN_SUB = 8;
 struct BnAcc {
-  unsigned long long lo[128];   // fractional 64 bits
-  long long hi[128];            // integer part (two's complement)
+  long long hi[BN_SUB][128];    // sum of floor(x)
+  long long lo[BN_SUB][128];    // sum of (x - floor(x)) * 2^52
   unsigned int arrivals;
   unsigned int nonfinite;
   unsigned int pad[14];
@@ -41,16 +58,16 @@ static_assert(sizeof(cgnn_bn_tail) == 120, "cgnn.h: struct cgnn_bn_tail (ctypes 
 // column `c`'s partial of this workgroup -> accumulator.  Returns a value that depends on both atomics'
 // return values (consume it, e.g. store it to LDS, before bnacc_arrive: that is the wait).
 __device__ __forceinline__ unsigned long long bnacc_add(BnAcc* acc, int c, double x) {
-  if (!(fabs(x) < 9.0e18)) {                       // inf / nan / beyond 2^63: flagged, not added
+  if (!(fabs(x) < 4.0e18)) {                       // inf / nan / beyond 2^62: flagged, not added
     return (unsigned long long)__hip_atomic_fetch_or(&acc->nonfinite, 1u, __ATOMIC_RELAXED, CGNN_AGENT);
   }
+  const int sub = blockIdx.x & (BN_SUB - 1);
   const double fl = floor(x);
   const long long hi = (long long)fl;
-  const unsigned long long lo = (unsigned long long)((x - fl) * 18446744073709551616.0);   // exact: < 2^64
-  const unsigned long long old = __hip_atomic_fetch_add(&acc->lo[c], lo, __ATOMIC_RELAXED, CGNN_AGENT);
-  const long long carry = (old + lo < old) ? 1 : 0;
-  const long long oldh = __hip_atomic_fetch_add(&acc->hi[c], hi + carry, __ATOMIC_RELAXED, CGNN_AGENT);
-  return old ^ (unsigned long long)oldh;
+  const long long lo = (long long)((x - fl) * 4503599627370496.0);                // [0, 2^52)
+  const long long a = __hip_atomic_fetch_add(&acc->hi[sub][c], hi, __ATOMIC_RELAXED, CGNN_AGENT);
+  const long long b = __hip_atomic_fetch_add(&acc->lo[sub][c], lo, __ATOMIC_RELAXED, CGNN_AGENT);
+  return (unsigned long long)(a ^ b);
 }
 
 // Call from ALL threads of the workgroup after every bnacc_add of the workgroup has returned (its return
@@ -66,13 +83,20 @@ __device__ __forceinline__ bool bnacc_arrive(BnAcc* acc, int* lds_flag) {
 
 // the finished sum of column c; the words are left zero (last workgroup only)
 __device__ __forceinline__ double bnacc_take(BnAcc* acc, int c) {
-  const unsigned long long lo = __hip_atomic_load(&acc->lo[c], __ATOMIC_RELAXED, CGNN_AGENT);
-  const long long hi = __hip_atomic_load(&acc->hi[c], __ATOMIC_RELAXED, CGNN_AGENT);
+  long long hi = 0, lo = 0;
+#pragma unroll
+  for (int s = 0; s < BN_SUB; ++s) {
+    hi += __hip_atomic_load(&acc->hi[s][c], __ATOMIC_RELAXED, CGNN_AGENT);
+    lo += __hip_atomic_load(&acc->lo[s][c], __ATOMIC_RELAXED, CGNN_AGENT);
+  }
   const unsigned int bad = __hip_atomic_load(&acc->nonfinite, __ATOMIC_RELAXED, CGNN_AGENT);
-  __hip_atomic_store(&acc->lo[c], 0ull, __ATOMIC_RELAXED, CGNN_AGENT);
-  __hip_atomic_store(&acc->hi[c], 0ll, __ATOMIC_RELAXED, CGNN_AGENT);
+#pragma unroll
+  for (int s = 0; s < BN_SUB; ++s) {
+    __hip_atomic_store(&acc->hi[s][c], 0ll, __ATOMIC_RELAXED, CGNN_AGENT);
+    __hip_atomic_store(&acc->lo[s][c], 0ll, __ATOMIC_RELAXED, CGNN_AGENT);
+  }
   if (bad) return __builtin_nan("");
-  return (double)hi + (double)lo * 5.421010862427522e-20;          // 2^-64
+  return (double)hi + (double)lo * 2.220446049250313e-16;          // 2^-52
 }
 
 // after every bnacc_take of the tail (one thread): counter and flag back to zero

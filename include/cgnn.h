@@ -451,8 +451,8 @@ int cgnn_band_aggregate_f32(const void* bfrag, const int32_t* bstep, const int32
 
 /* BatchNorm finalisation in the PRODUCER's tail (round 4; csrc/bn_tail.h): instead of writing its
  * per-workgroup partial sums to a slab for cgnn_bn_stats_finalize_rng / cgnn_bn_bwd_stats_finalize to fold
- * in a launch of their own, a tile kernel adds them to a 128-word accumulator (128-bit fixed-point atomic
- * adds: order-independent, bit-identical reruns) and the workgroup that arrives last writes the layer's
+ * in a launch of their own, a tile kernel adds them to an accumulator (fixed-point 64-bit atomic adds:
+ * order-independent, bit-identical reruns) and the workgroup that arrives last writes the layer's
  * coefficient block.  `acc`: CGNN_BN_ACC_BYTES bytes of device memory, ZERO before the first launch that
  * uses it; every launch leaves it zero again.  One accumulator may serve launches on ONE stream.
  *   mode 0 (statistics of a forward layer): the arithmetic of cgnn_bn_stats_finalize_rng -- count rows,
@@ -463,7 +463,7 @@ int cgnn_band_aggregate_f32(const void* bfrag, const int32_t* bstep, const int32
  * Passed as the last argument of cgnn_gcn_l0_fwd (mode 0; factored layer 0: the centred form's mean offset
  * is the kernel's own), cgnn_gcn_fused_fwd (mode 0) and cgnn_gcn_fused_bwd (mode 1, the sums of the layer
  * BELOW); NULL = the slab protocol.  With a tail the corresponding slab argument may be NULL. */
-#define CGNN_BN_ACC_BYTES 2112
+#define CGNN_BN_ACC_BYTES 16448
 typedef struct cgnn_bn_tail {
   void* acc;
   double count;

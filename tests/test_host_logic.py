@@ -333,8 +333,8 @@ def test_bn_tail_struct_layout_matches_header():
     """struct cgnn_bn_tail (include/cgnn.h; the library static_asserts 120 bytes) and its ctypes mirror."""
     from connectome_gnn_amd import _lib
     t = _lib.CgnnBnTail()
-    assert ctypes.sizeof(t) == 120 and _lib.BN_ACC_BYTES == 2112
+    assert ctypes.sizeof(t) == 120 and _lib.BN_ACC_BYTES == 16448
     assert _lib.CgnnBnTail.count.offset == 8 and _lib.CgnnBnTail.gamma.offset == 24
     assert _lib.CgnnBnTail.momentum.offset == 56 and _lib.CgnnBnTail.rng_n.offset == 88 and _lib.CgnnBnTail.bwc.offset == 112
     hdr = open(os.path.join(ROOT, "include", "cgnn.h")).read()
-    assert "#define CGNN_BN_ACC_BYTES 2112" in hdr
+    assert "#define CGNN_BN_ACC_BYTES 16448" in hdr
