@@ -68,11 +68,11 @@ def small_grid(request):
         assert int(lib.cgnn_fused_grid()) == full
 
 
-def _suite(fn, keep=None):
+def _suite(fn, keep=None, grids=GRIDS):
     cases = [c for c in _cases(fn) if keep is None or keep(c)]
     assert cases, fn.__name__
 
-    @pytest.mark.parametrize("small_grid", GRIDS, indirect=True)
+    @pytest.mark.parametrize("small_grid", grids, indirect=True)
     @pytest.mark.parametrize("case", cases, ids=_id)
     def run(small_grid, case):
         fn(**case)
@@ -84,12 +84,14 @@ def _suite(fn, keep=None):
 
 # ---------------------------------------------------------------- (A) the existing oracle suites, small grid
 test_models_vs_golden_small_grid = _suite(M.test_models_vs_golden)
-test_models_vs_oracle_fresh_small_grid = _suite(M.test_models_vs_oracle_fresh)
-test_dropout_replay_small_grid = _suite(M.test_dropout_on_matches_oracle_with_replayed_masks)
+# (the model-level suites spend their time in the CPU oracle: two grids -- 3: every workgroup takes several units,
+# the odd-grid fall-backs; 16: the row-pair form of the weight-stationary GEMM -- keep the GPU run inside its budget)
+test_models_vs_oracle_fresh_small_grid = _suite(M.test_models_vs_oracle_fresh, grids=[3, 16])
+test_dropout_replay_small_grid = _suite(M.test_dropout_on_matches_oracle_with_replayed_masks, grids=[3, 16])
 test_fused_gcn_vs_oracle_small_grid = _suite(M.test_fused_gcn_vs_oracle)
-test_cfg5_fp32_small_grid = _suite(M.test_cfg5_shape_gcn_1000roi_h256_vs_oracle, lambda c: c["ngraphs"] == 5)
-test_cfg5_fp16_small_grid = _suite(M.test_cfg5_fp16_storage_gcn_vs_fp32_oracle)
-test_sage_1000roi_small_grid = _suite(M.test_sage_1000roi_h128_band_aggregate_vs_oracle, lambda c: c["dropout"] > 0)
+test_cfg5_fp32_small_grid = _suite(M.test_cfg5_shape_gcn_1000roi_h256_vs_oracle, lambda c: c["ngraphs"] == 5, [3, 16])
+test_cfg5_fp16_small_grid = _suite(M.test_cfg5_fp16_storage_gcn_vs_fp32_oracle, grids=[3, 16])
+test_sage_1000roi_small_grid = _suite(M.test_sage_1000roi_h128_band_aggregate_vs_oracle, lambda c: c["dropout"] > 0, [3, 16])
 test_aggregate_tiled_small_grid = _suite(K.test_aggregate_tiled_forward_backward)
 test_aggregate_tiled_bn_prologue_small_grid = _suite(K.test_aggregate_tiled_with_bn_prologue_equals_two_passes)
 test_linear_small_grid = _suite(K.test_linear_forward_backward, lambda c: c["m"] >= 4096)
@@ -122,6 +124,16 @@ def test_units_per_workgroup_reached(small_grid, kind):
     assert tiles == (6 if kind == "gcn" else 4)           # one 360-ROI graph per tile whatever the grid
     if small_grid == 3:
         assert units >= 2 * small_grid                     # 6 tiles / 8 (tile, slice) units on 3 workgroups
+
+
+@pytest.mark.parametrize("small_grid", [1, 3], indirect=True)
+@pytest.mark.parametrize("kind,hidden", [("gcn", 64), ("sage", 128)])
+def test_many_units_per_workgroup_vs_oracle(small_grid, kind, hidden):
+    """The deepest walk of the persistent loops an oracle comparison reaches: 24 x 360-ROI graphs (24 one-graph
+    tiles; GraphSAGE h128: 48 (tile, slice) units) on 1 or 3 workgroups -- 24 / 8 tiles (48 / 16 units) per
+    workgroup, more than the 16 the headline runs -- dropout 0.3 replayed through the oracle."""
+    units, grid = _full_size(kind, 360, 14, hidden, 24, False, seed=31)
+    assert grid == small_grid and units == 24 * (hidden // 64)
 
 
 # ---------------------------------------------------------------- (B) real sizes on the full grid
