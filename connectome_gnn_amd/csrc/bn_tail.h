@@ -11,9 +11,10 @@
 //
 //   * the sums are added as FIXED-POINT integers (integer part and fractional part x 2^52 in two signed
 //     64-bit words): integer addition is associative, so the result does not depend on the order in which
-//     the workgroups arrive -- bit-identical reruns, which fp64 atomic adds would not give -- and it equals
-//     the slab protocol's fp64 fold to the last bit on every parity case (the coefficient blocks compare with
-//     torch.equal);
+//     the workgroups arrive -- bit-identical reruns, which fp64 atomic adds would not give (tools/tail_stress.py:
+//     600 training steps twice, every gradient and running statistic equal, at four batch sizes).  Against the
+//     slab protocol's fp64 tree fold of 256 rounded partials the exact sum differs in the last bits: the same
+//     coefficient block on small batches, gradients within 2e-7 of each other at 512 .. 4096 graphs;
 //   * no fence: a returning atomic has been performed at the device's coherence point when its value comes
 //     back, so "wait for my returns, then bump the counter" orders a workgroup's sums before its arrival
 //     without the release fence whose L2 write-back made the round-2 "last workgroup" tail slower than the
