@@ -152,20 +152,12 @@ template <typename MeanOff>
 __device__ __forceinline__ void bn_tail_run(const cgnn_bn_tail& t, const double* wg_sums, int* scratch,
                                             MeanOff mean_off_of) {
   BnAcc* acc = static_cast<BnAcc*>(t.acc);
-#ifdef CGNN_TAIL_DEBUG
-  if (threadIdx.x == 0 && wg_sums[0] != 0.0) printf("[tail] wg %d of %d adds col0 = %g (mode %d)\n", blockIdx.x, gridDim.x, wg_sums[0], t.mode);
-#endif
   if (threadIdx.x < 128) {
     const unsigned long long r = bnacc_add(acc, threadIdx.x, wg_sums[threadIdx.x]);
     scratch[1 + threadIdx.x] = (int)(r & 1u);      // consuming the returns = waiting for the atomics
   }
   __syncthreads();
   if (!bnacc_arrive(acc, scratch)) return;
-#ifdef CGNN_TAIL_DEBUG
-  if (threadIdx.x == 0) printf("[tail] wg %d is last (mode %d): lo0 %llu hi0 %lld\n", blockIdx.x, t.mode,
-                               __hip_atomic_load(&acc->lo[0], __ATOMIC_RELAXED, CGNN_AGENT), __hip_atomic_load(&acc->hi[0], __ATOMIC_RELAXED, CGNN_AGENT));
-  __syncthreads();
-#endif
   if (threadIdx.x < 64) bn_tail_finalize(t, acc, threadIdx.x, mean_off_of(threadIdx.x));
   __syncthreads();
   if (threadIdx.x == 0) bnacc_reset(acc);
