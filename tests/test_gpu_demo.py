@@ -309,3 +309,25 @@ def test_out_of_range_label_raises_when_the_dataset_is_packed():
     tr = C.Trainer(m, torch.optim.Adam(m.parameters(), lr=1e-3), device="cuda")
     with pytest.raises(IndexError, match="out of bounds"):
         tr.train_epoch(C.ConnectomeDataLoader(graphs, batch_size=8, shuffle=False))
+
+
+def test_plain_loader_path_with_twelve_features_and_one_loader_for_both_roles():
+    """The packed path with 9..16 input features (the per-tile kernels' non-factored layer 0 over the subject
+    cache) and the INTEGRATION.md idiom `fit(loader, loader)`: same trajectory as the host loader."""
+    import connectome_gnn_amd as C
+    base = C.generate_dataset(40, 84, 8, seed=9)
+    g = torch.Generator().manual_seed(4)
+    graphs = [C.ConnectomeGraph(torch.randn(gr.num_nodes, 12, generator=g), gr.edge_index, gr.edge_weight, gr.label)
+              for gr in base]
+    hist = {}
+    for mode in ("host", "default"):
+        torch.manual_seed(2)
+        m = C.GCNConnectome(12, 64, dropout=0.0)
+        tr = C.Trainer(m, torch.optim.Adam(m.parameters(), lr=1e-3), device="cuda",
+                       **({"resident": False, "graph": False} if mode == "host" else {}))
+        ld = C.ConnectomeDataLoader(graphs, batch_size=16, shuffle=True)
+        hist[mode] = tr.fit(ld, ld, num_epochs=3, patience=5, verbose=False)
+        if mode == "default":
+            assert tr.graph and m.impl_used == "fused"
+    for key in ("train_loss", "val_loss", "val_acc"):
+        torch.testing.assert_close(torch.tensor(hist["default"][key]), torch.tensor(hist["host"][key]), rtol=2e-4, atol=2e-6)
