@@ -101,7 +101,7 @@ def test_g7_trainer_trajectory(kind):
     for k, v in G.group(d, f"{kind}_final").items():
         if kind == "gcn" and (k.startswith("convs.") and k.endswith(".bias") or "running_mean" in k):
             continue    # zero-true-gradient bias ahead of BN: chaotic in the reference itself
-        torch.testing.assert_close(sd[k].cpu(), v, rtol=1e-3, atol=2e-5, msg=lambda s: f"{k}: {s}")
+        torch.testing.assert_close(sd[k].cpu(), v, rtol=1e-4, atol=2e-5, msg=lambda s: f"{k}: {s}")
 
 
 @pytest.mark.parametrize("kind,n,k,hidden,nb", [("gcn", 84, 8, 64, 32), ("sage", 84, 8, 64, 16),
