@@ -338,3 +338,37 @@ def test_bn_tail_struct_layout_matches_header():
     assert _lib.CgnnBnTail.momentum.offset == 56 and _lib.CgnnBnTail.rng_n.offset == 88 and _lib.CgnnBnTail.bwc.offset == 112
     hdr = open(os.path.join(ROOT, "include", "cgnn.h")).read()
     assert "#define CGNN_BN_ACC_BYTES 16448" in hdr
+
+
+def test_trainer_host_side_decisions_for_the_packed_path():
+    """CPU-checkable pieces of Trainer's packed path (train.py): the optimizer switch, the prepare-callback
+    signature probe, the claim / disarm protocol of direct gradient destinations."""
+    import connectome_gnn_amd as C
+    from connectome_gnn_amd import ops
+    from connectome_gnn_amd.structure import call_prepare
+    m = torch.nn.Linear(4, 2)
+    tr = C.Trainer.__new__(C.Trainer)
+    tr.optimizer = torch.optim.Adam(m.parameters(), lr=1e-3)
+    assert tr._make_capturable() and all(g["capturable"] for g in tr.optimizer.param_groups)
+    assert not any(g.get("fused") for g in tr.optimizer.param_groups)          # CPU parameters: no fused kernel
+    tr.optimizer = torch.optim.SGD(m.parameters(), lr=1e-3)
+    assert not tr._make_capturable()                                           # not an optimizer we know to switch
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    m(torch.randn(3, 4)).sum().backward()
+    opt.step()
+    tr.optimizer = opt
+    assert not tr._make_capturable()                                           # state exists on the host already
+    calls = []
+    call_prepare(lambda b, reuse=False: calls.append(("kw", reuse)), 1)
+    call_prepare(lambda b: calls.append(("plain",)), 1)
+
+    def raises_inside(b, reuse=False):
+        raise TypeError("from inside")
+    with pytest.raises(TypeError, match="from inside"):
+        call_prepare(raises_inside, 1)                                          # not swallowed, not retried
+    assert calls == [("kw", True), ("plain",)]
+    p = torch.nn.Parameter(torch.zeros(3))
+    assert ops.grad_destination(p) is None                                      # never armed
+    p._cgnn_direct = True
+    p.grad = torch.zeros(3)
+    assert ops.grad_destination(p) is None and p._cgnn_direct is False         # host tensors are never written to; disarmed
