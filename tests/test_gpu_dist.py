@@ -9,6 +9,7 @@ import os
 import socket
 import sys
 
+import numpy as np
 import pytest
 import torch
 import torch.multiprocessing as mp
@@ -169,3 +170,76 @@ def test_direct_gradient_writes_equal_autograd_accumulation(kind):
             assert torch.equal(a, c), (mode, name)
         for a, c in zip(got[mode][1], got["plain"][1]):
             torch.testing.assert_close(a, c, rtol=1e-6, atol=1e-7)       # (a + b summed in another order)
+
+
+def _trainer_worker(rank, world, port, q, resident):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    try:
+        import torch.distributed as dist
+        import connectome_gnn_amd as C
+        from connectome_gnn_amd import dist as cdist
+        cdist.init_from_env(backend="gloo")
+        torch.cuda.set_device(0)
+        graphs = C.generate_dataset(50, 84, 8, seed=13)
+        torch.manual_seed(3)
+        model = C.GCNConnectome(5, 64, dropout=0.0).to("cuda")
+        cdist.broadcast_parameters(model)
+        sync = cdist.GradSync(model.parameters())
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+        kw = {} if resident else {"resident": False, "graph": False}
+        tr = C.Trainer(model, opt, device="cuda", grad_sync=sync, **kw)
+        ld = C.ConnectomeDataLoader(graphs[:40], batch_size=16, shuffle=True, rank=rank, world_size=world)
+        vl = C.ConnectomeDataLoader(graphs[40:], batch_size=10, shuffle=False, rank=rank, world_size=world)
+        hist = tr.fit(ld, vl, num_epochs=3, patience=5, verbose=False)
+        out = {"hist": hist, "graph": bool(tr.graph), "graphs": len(tr._graphs),
+               "w": {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}}
+        dist.barrier()
+        q.put((rank, out))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_trainer_defaults_over_the_reference_loader_equal_the_host_path():
+    """Graph-sharded data parallelism through the drop-in API with its defaults: two ranks, each
+    `Trainer(model, torch.optim.Adam(...), grad_sync=GradSync(...))` over the reference's list-backed loader with
+    (rank, world_size) -- the dataset packed into HBM per rank, the shard's batches assembled on the device, one
+    captured step per shard size with the gradient all-reduce between its two graphs, gradients written straight
+    into the flat buffer -- against the same two ranks on the host-collate / eager path: same curves, same weights
+    on both ranks (per-rank BatchNorm both ways).  gloo on one shared device; RCCL runs the same code."""
+    ctx = mp.get_context("spawn")
+    runs = {}
+    for resident in (False, True):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_trainer_worker, args=(r, 2, port, q, resident)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = dict(q.get(timeout=300) for _ in procs)
+        for p in procs:
+            p.join(60)
+        for r in (0, 1):
+            assert not isinstance(res[r], str), res[r]
+        runs[resident] = res
+    T = torch.from_numpy
+    for r in (0, 1):
+        assert runs[True][r]["graph"] and runs[True][r]["graphs"] >= 2          # shards of 8 and 4 graphs (+ eval steps)
+        assert not runs[False][r]["graph"]
+        for key in ("train_loss", "val_loss", "val_acc"):
+            torch.testing.assert_close(torch.tensor(runs[True][r]["hist"][key]), torch.tensor(runs[False][r]["hist"][key]),
+                                       rtol=2e-4, atol=2e-6, msg=lambda s: f"rank {r} {key}: {s}")
+    # both ranks hold the same weights (they applied the same averaged gradients), and the two paths agree
+    for k, v in runs[True][0]["w"].items():
+        if v.dtype.kind != "f":
+            continue
+        if "running" not in k:                    # parameters: identical on the two ranks (running statistics are per rank)
+            assert np.array_equal(runs[True][1]["w"][k], v), f"{k} differs between the ranks"
+        if not (k.startswith("convs.") and k.endswith(".bias")) and "running_mean" not in k:
+            torch.testing.assert_close(T(v), T(runs[False][0]["w"][k]), rtol=2e-3, atol=2e-5, msg=lambda s: f"{k}: {s}")
