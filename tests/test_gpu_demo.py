@@ -205,6 +205,10 @@ def test_trainer_graph_mode_replays_fresh_shuffled_resident_batches():
     _trainer_replay_equals_eager(generate_packed(40, 84, 8, seed=4).to("cuda"), masks=False)
     # GraphSAGE over the same kind of loader (the cache's second family)
     _trainer_replay_equals_eager(generate_packed(40, 84, 8, seed=4).to("cuda"), masks=False, cls="sage")
+    # long epochs of a small step: runs of four consecutive steps replay as ONE graph (GraphedTrainStep.capture_run);
+    # 168 subjects = ten batches of 16 (two run-graphs + two single steps) and one of 8
+    runs = _trainer_replay_equals_eager(generate_packed(168, 84, 8, seed=6).to("cuda"), masks=False)
+    assert runs == [True, False]                 # the 16-graph step got its run-graph, the 8-graph tail step did not
 
 
 def _trainer_replay_equals_eager(ds, masks=True, cls="gcn"):
@@ -224,6 +228,7 @@ def _trainer_replay_equals_eager(ds, masks=True, cls="gcn"):
         if mode == "graph":
             assert len(tr._graphs) == 2                               # one per batch SIZE, not per batch
             assert all(isinstance(s, GraphedResidentStep) for s in tr._graphs.values())
+            run_graphs = [s._run_graph is not None for _, s in sorted(tr._graphs.items(), key=lambda kv: -kv[0][2])]
     torch.testing.assert_close(torch.tensor(hist["graph"]), torch.tensor(hist["eager"]), rtol=2e-5, atol=1e-6)
     for k, v in finals["eager"].items():
         # (GCN's bias ahead of BatchNorm has a zero true gradient -- Adam moves it by +-lr per step on the SIGN
@@ -234,7 +239,7 @@ def _trainer_replay_equals_eager(ds, masks=True, cls="gcn"):
         if v.is_floating_point() and not (k.startswith("convs.") and k.endswith(".bias")):
             torch.testing.assert_close(finals["graph"][k], v, rtol=1e-4, atol=1e-5, msg=lambda s: f"{k}: {s}")
     if not masks:
-        return
+        return run_graphs
     # with dropout the replays draw fresh masks: two epochs over the same subjects differ
     torch.manual_seed(1)
     m = C.GCNConnectome(5, 64, dropout=0.5)
