@@ -387,6 +387,8 @@ class GraphedEvalStep:
                 _lib.check(_lib.load().cgnn_epoch_advance(_lib.ptr(self.cursor), b, _lib.ptr(loss), float(b),
                                                           _lib.ptr(self.tally), _lib.stream_ptr(dev)), "cgnn_epoch_advance")
 
+        self._body, self._dev, self._nodes = body, dev, b * int(cache.n)
+        self._run_graph, self._run_failed = None, False
         with torch.no_grad():
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
@@ -416,6 +418,36 @@ class GraphedEvalStep:
             raise ValueError("run: ids must hold steps x batch_size subject ids (at most the dataset's size)")
         self.order_buf[:n].copy_(ids, non_blocking=True)
         self._state.zero_()
-        for _ in range(steps):
+        done = 0
+        k = self.RUN_LEN if (self._nodes <= self.RUN_MAX_NODES and steps >= 2 * self.RUN_LEN) else 1
+        if k > 1:
+            if self._run_graph is None and not self._run_failed:
+                self._capture_run(k)
+            if self._run_graph is not None:
+                while done + k <= steps:
+                    self._run_graph.replay()
+                    done += k
+        for _ in range(steps - done):
             self.graph.replay()
         return self.tally.clone().reshape(()), self.hits.clone().reshape(())
+
+    RUN_LEN, RUN_MAX_NODES = 4, 65536        # (as GraphedResidentStep: a graph of four consecutive small steps)
+
+    def _capture_run(self, k: int) -> None:
+        import gc
+        import torch.distributed as dist
+        mode = {"capture_error_mode": "thread_local"} if dist.is_available() and dist.is_initialized() else {}
+        g = torch.cuda.CUDAGraph()
+        was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.no_grad(), torch.cuda.graph(g, **mode):
+                for _ in range(k):
+                    self._body()
+            self._run_graph = g
+        except Exception:                                   # noqa: BLE001 -- optional: single steps remain
+            torch.cuda.synchronize(self._dev)
+            self._run_failed = True
+        finally:
+            if was_enabled:
+                gc.enable()

@@ -336,3 +336,25 @@ def test_plain_loader_path_with_twelve_features_and_one_loader_for_both_roles():
             assert tr.graph and m.impl_used == "fused"
     for key in ("train_loss", "val_loss", "val_acc"):
         torch.testing.assert_close(torch.tensor(hist["default"][key]), torch.tensor(hist["host"][key]), rtol=2e-4, atol=2e-6)
+
+
+def test_evaluation_replay_with_run_graphs_equals_eager():
+    """Trainer.evaluate over a resident loader: captured evaluation steps, long passes through graphs of four
+    consecutive steps (GraphedEvalStep._capture_run), against the eager evaluation of the same model."""
+    import connectome_gnn_amd as C
+    from connectome_gnn_amd.optim import Adam
+    from connectome_gnn_amd.resident import ResidentDataLoader
+    from connectome_gnn_amd.synthetic import generate_packed
+    ds = generate_packed(150, 84, 8, seed=8).to("cuda")            # nine batches of 16 + one of 6
+    torch.manual_seed(0)
+    m = C.GCNConnectome(5, 64).to("cuda")
+    res = {}
+    for graph in (False, True):
+        tr = C.Trainer(m, Adam(m.parameters(), lr=1e-3), device="cuda", graph=graph)
+        ld = ResidentDataLoader(ds, batch_size=16, shuffle=False, structure_cache=True)
+        res[graph] = [tr.evaluate(ld) for _ in range(2)][-1]
+        if graph:
+            steps = {k[2]: s for k, s in tr._graphs.items() if k[0] == "eval"}
+            assert sorted(steps) == [6, 16] and steps[16]._run_graph is not None and steps[6]._run_graph is None
+    assert res[True]["total"] == res[False]["total"] == 150 and res[True]["correct"] == res[False]["correct"]
+    assert abs(res[True]["loss"] - res[False]["loss"]) <= 1e-5 * abs(res[False]["loss"]) + 1e-6
